@@ -1,0 +1,294 @@
+// oracle/ref_harness.cpp -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+//
+// A thin extern "C" shim around the *real* VISFD templates, compiled from the
+// headers where they lie under /root/reference/lib/visfd (see oracle/Makefile,
+// target _ref/libvisfd_ref.so).  Nothing from the reference is copied here: this
+// file only builds pointer tables over flat arrays and forwards to the library.
+// It exists to (1) pin the CPU restatement in oracle/visfd_oracle.cpp,
+// (2) generate the golden fixtures under tests/golden/ (tests/golden/make_golden.py),
+// (3) optionally serve as the "reference" CPU baseline in bench.py.
+//
+// Build flags mirror the reference's setup_gcc.sh:7-10 (-O3 -DNDEBUG -fopenmp, no -march).
+//
+// All volumes are flat row-major [iz][iy][ix] float arrays (alloc3d.hpp:16-23 layout).
+
+#include <cstdint>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include <array>
+#include <limits>
+#include <algorithm>
+#include <iostream>
+using namespace std;
+
+#include <visfd.hpp>
+using namespace visfd;
+
+namespace {
+
+// Pointer tables over a caller-owned contiguous block (the reference's own
+// Alloc3D would allocate its own storage; we need views).
+template <typename T>
+struct View3 {
+  std::vector<T**> zp;
+  std::vector<T*> yp;
+  T*** p = nullptr;
+  View3(T* base, int nx, int ny, int nz) {
+    if (!base) return;
+    zp.resize(nz);
+    yp.resize((size_t)nz * ny);
+    for (int iz = 0; iz < nz; iz++) {
+      zp[iz] = &yp[(size_t)iz * ny];
+      for (int iy = 0; iy < ny; iy++)
+        yp[(size_t)iz * ny + iy] = base + ((size_t)iz * ny + iy) * nx;
+    }
+    p = zp.data();
+  }
+};
+
+typedef float const* const* const* cf3;
+
+}  // namespace
+
+extern "C" {
+
+// filter1d.hpp:409-460
+void vr_gauss_taps(float sigma, int halfwidth, float* taps_out) {
+  Filter1D<float, int> f = GenFilterGauss1D(sigma, halfwidth);
+  for (int i = -halfwidth; i <= halfwidth; i++) taps_out[i + halfwidth] = f.afH[i];
+}
+
+// filter3d_variants.hpp:513-518 : ratio = sqrt(-2 ln thr) evaluated in float
+float vr_ratio_from_threshold(float thr) {
+  float r = sqrt(-2 * log(thr));
+  return r;
+}
+
+// filter3d.hpp:1086 (sigma[3], halfwidth[3])
+float vr_apply_gauss_hw(const float* src, float* dst, const float* mask, int nx, int ny, int nz,
+                        const float sigma[3], const int hw[3], int normalize) {
+  int size[3] = {nx, ny, nz};
+  View3<float> s(const_cast<float*>(src), nx, ny, nz), d(dst, nx, ny, nz),
+      m(const_cast<float*>(mask), nx, ny, nz);
+  return ApplyGauss<float>(size, (cf3)s.p, d.p, (cf3)m.p, sigma, hw, normalize != 0, nullptr);
+}
+
+// filter3d.hpp:1226 (sigma[3], truncate_ratio)
+float vr_apply_gauss_ratio(const float* src, float* dst, const float* mask, int nx, int ny, int nz,
+                           const float sigma[3], float ratio, int normalize) {
+  int size[3] = {nx, ny, nz};
+  View3<float> s(const_cast<float*>(src), nx, ny, nz), d(dst, nx, ny, nz),
+      m(const_cast<float*>(mask), nx, ny, nz);
+  return ApplyGauss<float>(size, (cf3)s.p, d.p, (cf3)m.p, sigma, ratio, normalize != 0, nullptr);
+}
+
+// filter3d.hpp:1338
+void vr_apply_dog(const float* src, float* dst, const float* mask, int nx, int ny, int nz,
+                  const float sigma_a[3], const float sigma_b[3], const int hw[3], float* pA,
+                  float* pB) {
+  int size[3] = {nx, ny, nz};
+  View3<float> s(const_cast<float*>(src), nx, ny, nz), d(dst, nx, ny, nz),
+      m(const_cast<float*>(mask), nx, ny, nz);
+  ApplyDog<float>(size, (cf3)s.p, d.p, (cf3)m.p, sigma_a, sigma_b, hw, pA, pB, nullptr);
+}
+
+// filter3d.hpp:1428
+void vr_apply_log(const float* src, float* dst, const float* mask, int nx, int ny, int nz,
+                  const float sigma[3], float delta, float ratio, float* pA, float* pB) {
+  int size[3] = {nx, ny, nz};
+  View3<float> s(const_cast<float*>(src), nx, ny, nz), d(dst, nx, ny, nz),
+      m(const_cast<float*>(mask), nx, ny, nz);
+  ApplyLog<float>(size, (cf3)s.p, d.p, (cf3)m.p, sigma, delta, ratio, pA, pB, nullptr);
+}
+
+// feature.hpp:53 (BlobDog).  Rows of out_*: x,y,z,sigma,score.  Returns 0, or 1 if a
+// capacity was too small (counts are still reported).
+int vr_blob_dog(const float* src, const float* mask, int nx, int ny, int nz, const float* sigmas,
+                int nsig, const float* aspect /*nullable*/, float delta, float ratio,
+                float minima_threshold, float maxima_threshold, int use_ratios, float* out_min,
+                int64_t cap_min, int64_t* n_min, float* out_max, int64_t cap_max,
+                int64_t* n_max) {
+  int size[3] = {nx, ny, nz};
+  View3<float> s(const_cast<float*>(src), nx, ny, nz), m(const_cast<float*>(mask), nx, ny, nz);
+  vector<float> sig(sigmas, sigmas + nsig);
+  vector<array<float, 3>> cmin, cmax;
+  vector<float> smin, smax, scmin, scmax;
+  BlobDog<float>(size, (cf3)s.p, (cf3)m.p, sig, &cmin, &cmax, &smin, &smax, &scmin, &scmax,
+                 aspect, delta, ratio, minima_threshold, maxima_threshold, use_ratios != 0,
+                 nullptr, nullptr);
+  *n_min = (int64_t)cmin.size();
+  *n_max = (int64_t)cmax.size();
+  int rc = 0;
+  if ((int64_t)cmin.size() > cap_min || (int64_t)cmax.size() > cap_max) rc = 1;
+  for (int64_t i = 0; i < (int64_t)cmin.size() && i < cap_min; i++) {
+    out_min[5 * i + 0] = cmin[i][0]; out_min[5 * i + 1] = cmin[i][1]; out_min[5 * i + 2] = cmin[i][2];
+    out_min[5 * i + 3] = smin[i];    out_min[5 * i + 4] = scmin[i];
+  }
+  for (int64_t i = 0; i < (int64_t)cmax.size() && i < cap_max; i++) {
+    out_max[5 * i + 0] = cmax[i][0]; out_max[5 * i + 1] = cmax[i][1]; out_max[5 * i + 2] = cmax[i][2];
+    out_max[5 * i + 3] = smax[i];    out_max[5 * i + 4] = scmax[i];
+  }
+  return rc;
+}
+
+// feature.hpp:446 diameter<->sigma conversion as the library evaluates it (:475, :504)
+void vr_blob_diameters_to_sigmas(const float* diam, int n, float* sig) {
+  for (int i = 0; i < n; i++) sig[i] = diam[i] / (2.0 * sqrt(3));
+}
+void vr_blob_sigmas_to_diameters(const float* sig, int n, float* diam) {
+  for (int i = 0; i < n; i++) diam[i] = sig[i] * 2.0 * sqrt(3);
+}
+
+// feature.hpp:1203 (CalcHessian).  grad: 3 floats/voxel (nullable), hess: 6 floats/voxel
+// in MapIndices order (lin3_utils.hpp:400-406).  Voxels with mask==0 are left untouched.
+int vr_calc_hessian(const float* src, float* grad, float* hess, const float* mask, int nx, int ny,
+                    int nz, float sigma, float ratio) {
+  int size[3] = {nx, ny, nz};
+  View3<float> s(const_cast<float*>(src), nx, ny, nz), m(const_cast<float*>(mask), nx, ny, nz);
+  size_t n = (size_t)nx * ny * nz;
+  std::vector<float*> hp(n);
+  for (size_t i = 0; i < n; i++) hp[i] = hess + 6 * i;
+  View3<float*> h(hp.data(), nx, ny, nz);
+  View3<array<float, 3>> g(reinterpret_cast<array<float, 3>*>(grad), nx, ny, nz);
+  try {
+    CalcHessian<float, array<float, 3>, float*>(size, (cf3)s.p, g.p, h.p, (cf3)m.p, sigma, ratio,
+                                               nullptr);
+  } catch (VisfdErr& e) {
+    return 1;
+  }
+  return 0;
+}
+
+// eigen3_simple.hpp:271 (DiagonalizeFlatSym3), batched over n voxels. order = EigenOrderType.
+void vr_diagonalize_flat_sym3(const float* m6, float* out6, int64_t n, int order) {
+  for (int64_t i = 0; i < n; i++)
+    selfadjoint_eigen3::DiagonalizeFlatSym3(m6 + 6 * i, out6 + 6 * i,
+                                            (selfadjoint_eigen3::EigenOrderType)order);
+}
+
+// eigen3_simple.hpp:392 (ConvertFlatSym2Evects3<float>), batched.
+void vr_flat_sym_to_evects(const float* m6, float* eivals3, float* eivects9, int64_t n, int order) {
+  for (int64_t i = 0; i < n; i++) {
+    float ev[3];
+    float evec[3][3];
+    selfadjoint_eigen3::ConvertFlatSym2Evects3<float>(m6 + 6 * i, ev, evec,
+                                                      (selfadjoint_eigen3::EigenOrderType)order);
+    for (int d = 0; d < 3; d++) eivals3[3 * i + d] = ev[d];
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) eivects9[9 * i + 3 * a + b] = evec[a][b];
+  }
+}
+
+// The caller-side saliency/direction loop of HandleTV (handlers.cpp:1640-1746) built from the
+// library calls it makes (ConvertFlatSym2Evects3 + ScoreHessianPlanar).  SURFACE_RIDGE only,
+// no background subtraction (peak_height = 1).  saliency is zeroed first (handlers.cpp:1640-1643);
+// dir (3 floats/voxel) is only written where mask != 0.
+void vr_hessian_saliency(const float* hess, const float* mask, int64_t n, int order,
+                         float* saliency, float* dir) {
+  for (int64_t i = 0; i < n; i++) saliency[i] = 0.0;
+  #pragma omp parallel for
+  for (int64_t i = 0; i < n; i++) {
+    if (mask && mask[i] == 0.0) continue;
+    float eivals[3];
+    float eivects[3][3];
+    selfadjoint_eigen3::ConvertFlatSym2Evects3<float>(hess + 6 * i, eivals, eivects,
+                                                      (selfadjoint_eigen3::EigenOrderType)order);
+    float score;
+    score = ScoreHessianPlanar(eivals, (float*)nullptr);
+    float peak_height = 1.0;
+    score *= peak_height;
+    saliency[i] = score;
+    dir[3 * i + 0] = eivects[0][0];
+    dir[3 * i + 1] = eivects[0][1];
+    dir[3 * i + 2] = eivects[0][2];
+  }
+}
+
+// feature.hpp:1711 (TV3D::TVDenseStick) as HandleTV instantiates it
+// (TV3D<float,int,array<float,3>,float*>, handlers.cpp:1821-1836).
+// tensor: 6 floats/voxel; voxels whose mask_dst==0 have no storage in the reference's compact
+// container (null pointer) and are left untouched here.
+void vr_tv_dense_stick(const float* saliency, const float* dir, float* tensor,
+                       const float* mask_src, const float* mask_dst, int nx, int ny, int nz,
+                       float sigma_tv, int exponent, float cutoff_ratio, int curves,
+                       int normalize) {
+  int size[3] = {nx, ny, nz};
+  size_t n = (size_t)nx * ny * nz;
+  View3<float> s(const_cast<float*>(saliency), nx, ny, nz),
+      ms(const_cast<float*>(mask_src), nx, ny, nz), md(const_cast<float*>(mask_dst), nx, ny, nz);
+  View3<array<float, 3>> v(reinterpret_cast<array<float, 3>*>(const_cast<float*>(dir)), nx, ny, nz);
+  std::vector<float*> tp(n);
+  for (size_t i = 0; i < n; i++)
+    tp[i] = (mask_dst && mask_dst[i] == 0.0) ? nullptr : tensor + 6 * i;
+  View3<float*> t(tp.data(), nx, ny, nz);
+  TV3D<float, int, array<float, 3>, float*> tv(sigma_tv, exponent, cutoff_ratio);
+  tv.TVDenseStick(size, (cf3)s.p, (array<float, 3> const* const* const*)v.p, t.p, (cf3)ms.p,
+                  (cf3)md.p, curves != 0, normalize != 0, false, nullptr);
+}
+
+// filter3d.hpp:546 radial table as TV3D::Resize builds it (feature.hpp:2419-2428), plus the
+// displacement table (feature.hpp:2468-2482).  w: (2h+1)^3 floats, rhat: 3*(2h+1)^3 floats.
+int vr_tv_tables(float sigma_tv, float cutoff_ratio, float* w, float* rhat, int cap_h) {
+  int h = floor(sigma_tv * cutoff_ratio);
+  if (h > cap_h) return -h;
+  if (!w) return h;
+  int hw[3] = {h, h, h};
+  float sig[3] = {sigma_tv, sigma_tv, sigma_tv};
+  Filter3D<float, int> f = GenFilterGenGauss3D(sig, static_cast<float>(2.0), hw);
+  int n = 2 * h + 1;
+  for (int iz = -h; iz <= h; iz++)
+    for (int iy = -h; iy <= h; iy++)
+      for (int ix = -h; ix <= h; ix++) {
+        size_t k = ((size_t)(iz + h) * n + (iy + h)) * n + (ix + h);
+        w[k] = f.aaafH[iz][iy][ix];
+        float length = sqrt(ix * ix + iy * iy + iz * iz);
+        if (length == 0) length = 1.0;
+        rhat[3 * k + 0] = ix / length;
+        rhat[3 * k + 1] = iy / length;
+        rhat[3 * k + 2] = iz / length;
+      }
+  return h;
+}
+
+// Post-TV score loop of HandleTV (handlers.cpp:1870-1892), SURFACE (ScoreTensorPlanar).
+void vr_tensor_saliency(const float* tensor, const float* mask, int64_t n, int order,
+                        float* saliency_inout) {
+  for (int64_t i = 0; i < n; i++) {
+    if (mask && mask[i] == 0.0) continue;
+    float diag[6];
+    selfadjoint_eigen3::DiagonalizeFlatSym3(tensor + 6 * i, diag,
+                                            (selfadjoint_eigen3::EigenOrderType)order);
+    float score;
+    score = ScoreTensorPlanar(diag);
+    float peak_height = 1.0;
+    score *= peak_height;
+    saliency_inout[i] = score;
+  }
+}
+
+// Global top-fraction threshold of HandleTV (handlers.cpp:1751-1797), same statements.
+float vr_threshold_fraction(float* saliency, const float* mask, int64_t n, float fraction) {
+  size_t n_voxels = 0;
+  for (int64_t i = 0; i < n; i++) {
+    if (mask && (mask[i] == 0)) continue;
+    n_voxels++;
+  }
+  vector<float> saliencies(n_voxels);
+  size_t k = 0;
+  for (int64_t i = 0; i < n; i++) {
+    if (mask && (mask[i] == 0)) continue;
+    saliencies[k] = saliency[i];
+    k++;
+  }
+  sort(saliencies.rbegin(), saliencies.rend());
+  k = floor(n_voxels * fraction);
+  float thr = saliencies[k];
+  for (int64_t i = 0; i < n; i++)
+    if (saliency[i] < thr) saliency[i] = 0.0;
+  return thr;
+}
+
+int vr_version() { return 1; }
+
+}  // extern "C"
