@@ -1,0 +1,243 @@
+/* visfd_hip.h -- C ABI of libvisfd_hip.so: the MI355X (gfx950) implementation of VISFD's dense
+ * 3-D filtering hot path (separable Gaussian -> DoG/LoG blob detection -> Hessian/eigen ridge
+ * saliency -> dense stick tensor voting).
+ *
+ * This is the drop-in boundary.  The reference has no FFI layer: its interface
+ * for this path is the header-only template API in namespace visfd plus the filter_mrc handlers.
+ * Each entry point below names the reference function it replaces (file:line under the
+ * reference root).  include/visfd_hip.hpp re-creates the visfd:: templates on top of this ABI
+ * (float*** arguments), INTEGRATION.md shows the binding a maintainer adds.
+ *
+ * Conventions
+ *  - plain C, no torch/STL types; every function returns 0 on success or a VISFD_HIP_E* code;
+ *    visfd_hip_last_error() returns the message of the last failure on the calling thread.
+ *  - volumes are contiguous float32, row-major [iz][iy][ix], x fastest (lib/visfd/alloc3d.hpp:16-23);
+ *    sizes are 64-bit (the reference's int arithmetic overflows at 2^31 voxels, alloc3d.hpp:33-35).
+ *  - "mask" pointers may be NULL (= no mask); a voxel is masked out when mask == 0.
+ *  - two faces per operation:
+ *        visfd_hip_<op>      host pointers  (drop-in: copies in, runs, copies out, synchronous)
+ *        visfd_hip_<op>_dev  device pointers (asynchronous on the context's HIP stream; the caller
+ *                            owns the buffers; multi-channel fields are CHANNEL-PLANAR on the device)
+ *  - multi-channel fields on the HOST face use the reference's layouts: direction/gradient as
+ *    3 interleaved floats per voxel (array<float,3>***, handlers.cpp:1547-1556); Hessian / vote
+ *    tensor as 6 interleaved floats per voxel in the order xx,yy,zz,xy,yz,xz
+ *    (lib/visfd/lin3_utils.hpp:400-406).  On the DEVICE face they are channel-planar:
+ *    field[c*nvox + voxel].
+ *  - callee owns its temporaries (as the reference does: filter3d.hpp:731,1362; feature.hpp:1243),
+ *    kept in the context's workspace between calls.
+ */
+#ifndef VISFD_HIP_H
+#define VISFD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VISFD_HIP_OK 0
+#define VISFD_HIP_EINVAL 1   /* bad argument (the reference would assert or throw VisfdErr) */
+#define VISFD_HIP_EDEVICE 2  /* HIP runtime failure / no gfx950 device */
+#define VISFD_HIP_ENOMEM 3   /* device allocation failed */
+#define VISFD_HIP_ECAPACITY 4 /* an output list was too small; counts are still returned */
+
+/* selfadjoint_eigen3::EigenOrderType (lib/visfd/eigen3_simple.hpp:36-43); only the two orders
+ * the hot path uses (bin/filter_mrc/handlers.cpp:1524-1535). */
+#define VISFD_HIP_INCREASING_EIVALS 0
+#define VISFD_HIP_DECREASING_EIVALS 1
+
+typedef struct visfd_hip_ctx visfd_hip_ctx;
+
+/* ---- lifecycle ------------------------------------------------------------------------------- */
+/* device: HIP ordinal.  stream: a hipStream_t to run on (e.g. the caller's), or NULL to create one. */
+int visfd_hip_create(int device, void* stream, visfd_hip_ctx** out);
+int visfd_hip_destroy(visfd_hip_ctx* ctx);
+int visfd_hip_synchronize(visfd_hip_ctx* ctx);
+/* release the cached workspace (it otherwise persists between calls) */
+int visfd_hip_trim(visfd_hip_ctx* ctx);
+const char* visfd_hip_last_error(void);
+int visfd_hip_abi_version(void);
+/* bytes of device workspace currently held by the context */
+int64_t visfd_hip_workspace_bytes(visfd_hip_ctx* ctx);
+
+/* ---- a1: filter taps (host arithmetic, long double) ------------------------------------------ */
+/* GenFilterGauss1D<float>, lib/visfd/filter1d.hpp:409-460.  taps_out has 2*halfwidth+1 entries. */
+int visfd_hip_gauss_taps(float sigma, int halfwidth, float* taps_out);
+/* ratio = sqrt(-2 ln threshold) in float, bin/filter_mrc/filter3d_variants.hpp:513-518 */
+float visfd_hip_ratio_from_threshold(float truncate_threshold);
+
+/* ---- a4: ApplySeparable, lib/visfd/filter3d.hpp:686-1050 -------------------------------------- */
+/* taps_d has 2*h_d+1 entries, centre at index h_d.  A_out (nullable) = product of the centre taps. */
+int visfd_hip_separable3d(visfd_hip_ctx*, const float* src, float* dst, const float* mask,
+                          int64_t nx, int64_t ny, int64_t nz,
+                          const float* taps_x, int hx, const float* taps_y, int hy,
+                          const float* taps_z, int hz, int normalize, float* A_out);
+int visfd_hip_separable3d_dev(visfd_hip_ctx*, const float* src, float* dst, const float* mask,
+                              int64_t nx, int64_t ny, int64_t nz,
+                              const float* taps_x, int hx, const float* taps_y, int hy,
+                              const float* taps_z, int hz, int normalize, float* A_out);
+
+/* ---- a5: ApplyGauss(sigma[3], halfwidth[3]), lib/visfd/filter3d.hpp:1086-1124 ------------------ */
+int visfd_hip_apply_gauss(visfd_hip_ctx*, const float* src, float* dst, const float* mask,
+                          int64_t nx, int64_t ny, int64_t nz, const float sigma[3],
+                          const int halfwidth[3], int normalize, float* A_out);
+int visfd_hip_apply_gauss_dev(visfd_hip_ctx*, const float* src, float* dst, const float* mask,
+                              int64_t nx, int64_t ny, int64_t nz, const float sigma[3],
+                              const int halfwidth[3], int normalize, float* A_out);
+/* halfwidth[d] = max(1, floor(sigma[d]*ratio)), lib/visfd/filter3d.hpp:1240-1247 */
+int visfd_hip_gauss_halfwidths(const float sigma[3], float truncate_ratio, int halfwidth_out[3]);
+
+/* ---- a6: ApplyDog, lib/visfd/filter3d.hpp:1338-1402 -------------------------------------------- */
+int visfd_hip_apply_dog(visfd_hip_ctx*, const float* src, float* dst, const float* mask,
+                        int64_t nx, int64_t ny, int64_t nz, const float sigma_a[3],
+                        const float sigma_b[3], const int halfwidth[3], float* A_out, float* B_out);
+int visfd_hip_apply_dog_dev(visfd_hip_ctx*, const float* src, float* dst, const float* mask,
+                            int64_t nx, int64_t ny, int64_t nz, const float sigma_a[3],
+                            const float sigma_b[3], const int halfwidth[3], float* A_out,
+                            float* B_out);
+
+/* ---- a7: ApplyLog(sigma[3], delta, ratio), lib/visfd/filter3d.hpp:1428-1507 -------------------- */
+int visfd_hip_apply_log(visfd_hip_ctx*, const float* src, float* dst, const float* mask,
+                        int64_t nx, int64_t ny, int64_t nz, const float sigma[3],
+                        float delta_sigma_over_sigma, float truncate_ratio, float* A_out,
+                        float* B_out);
+int visfd_hip_apply_log_dev(visfd_hip_ctx*, const float* src, float* dst, const float* mask,
+                            int64_t nx, int64_t ny, int64_t nz, const float sigma[3],
+                            float delta_sigma_over_sigma, float truncate_ratio, float* A_out,
+                            float* B_out);
+
+/* ---- a8: BlobDog, lib/visfd/feature.hpp:53-427 -------------------------------------------------- */
+/* One record per detected blob.  ix,iy,iz are voxel indices (the reference stores them as floats,
+ * feature.hpp:275-279); scale = index into blob_sigma[] of the blob's scale (ir-1 in the reference);
+ * score = LoG value.  Lists are returned sorted by (scale, iz, iy, ix): the reference's in-memory
+ * order depends on OpenMP scheduling (feature.hpp:310-345) and its callers sort anyway
+ * (bin/filter_mrc/handlers.cpp:876-909). */
+typedef struct visfd_hip_blob {
+  int32_t ix, iy, iz;
+  int32_t scale;
+  float sigma; /* blob_sigma[scale] */
+  float score;
+} visfd_hip_blob;
+
+/* aspect_ratio: NULL = {1,1,1}.  minima/maxima thresholds and use_threshold_ratios as
+ * feature.hpp:72-74 (pass +INFINITY / -INFINITY to disable).  With ratios, a side whose threshold
+ * is infinite is treated as disabled (the reference's behaviour there depends on thread
+ * scheduling).  src and mask are HOST pointers in the first form, DEVICE pointers
+ * in the _dev form; the blob lists are always host arrays of the given capacities. */
+int visfd_hip_blob_dog(visfd_hip_ctx*, const float* src, const float* mask,
+                       int64_t nx, int64_t ny, int64_t nz, const float* blob_sigma, int n_sigma,
+                       const float* aspect_ratio, float delta_sigma_over_sigma,
+                       float truncate_ratio, float minima_threshold, float maxima_threshold,
+                       int use_threshold_ratios,
+                       visfd_hip_blob* minima, int64_t minima_capacity, int64_t* n_minima,
+                       visfd_hip_blob* maxima, int64_t maxima_capacity, int64_t* n_maxima);
+int visfd_hip_blob_dog_dev(visfd_hip_ctx*, const float* src, const float* mask,
+                           int64_t nx, int64_t ny, int64_t nz, const float* blob_sigma,
+                           int n_sigma, const float* aspect_ratio, float delta_sigma_over_sigma,
+                           float truncate_ratio, float minima_threshold, float maxima_threshold,
+                           int use_threshold_ratios,
+                           visfd_hip_blob* minima, int64_t minima_capacity, int64_t* n_minima,
+                           visfd_hip_blob* maxima, int64_t maxima_capacity, int64_t* n_maxima);
+/* BlobDogD's conversions, lib/visfd/feature.hpp:475 and :504 */
+int visfd_hip_blob_diameters_to_sigmas(const float* diameters, int n, float* sigmas);
+int visfd_hip_blob_sigmas_to_diameters(const float* sigmas, int n, float* diameters);
+
+/* ---- a9: CalcHessian, lib/visfd/feature.hpp:1203-1348 ------------------------------------------- */
+/* gradient (nullable): 3 channels; hessian: 6 channels (xx,yy,zz,xy,yz,xz).  Voxels with mask==0
+ * are left untouched.  Returns VISFD_HIP_EINVAL if any dimension < 3 (feature.hpp:1260-1264). */
+int visfd_hip_calc_hessian(visfd_hip_ctx*, const float* src, float* gradient, float* hessian,
+                           const float* mask, int64_t nx, int64_t ny, int64_t nz, float sigma,
+                           float truncate_ratio);
+int visfd_hip_calc_hessian_dev(visfd_hip_ctx*, const float* src, float* gradient, float* hessian,
+                               const float* mask, int64_t nx, int64_t ny, int64_t nz, float sigma,
+                               float truncate_ratio);
+
+/* ---- a10: DiagonalizeFlatSym3 (batched), lib/visfd/eigen3_simple.hpp:271-342 -------------------- */
+/* n matrices of 6 floats -> n x [lambda0,lambda1,lambda2, shoemake0..2]. Host: interleaved;
+ * device: channel-planar with stride n. */
+int visfd_hip_diagonalize_flat_sym3(visfd_hip_ctx*, const float* m6, float* out6, int64_t n,
+                                    int eival_order);
+int visfd_hip_diagonalize_flat_sym3_dev(visfd_hip_ctx*, const float* m6, float* out6, int64_t n,
+                                        int eival_order);
+
+/* ---- a12 (first half): ridge saliency + principal direction ------------------------------------- */
+/* The per-voxel loop of HandleTV, bin/filter_mrc/handlers.cpp:1640-1746 (SURFACE_RIDGE, no
+ * background subtraction): saliency = (l0^2-l1^2)^2 (feature.hpp:1557-1560), direction = first
+ * eigenvector after the float Shoemake round trip (eigen3_simple.hpp:392-405).  saliency is zero
+ * where mask==0; direction is written only where mask!=0. */
+int visfd_hip_hessian_saliency(visfd_hip_ctx*, const float* hessian, const float* mask,
+                               int64_t nvox, int eival_order, float* saliency, float* direction);
+int visfd_hip_hessian_saliency_dev(visfd_hip_ctx*, const float* hessian, const float* mask,
+                                   int64_t nvox, int eival_order, float* saliency,
+                                   float* direction);
+/* Fused form (no materialised Hessian): Gaussian smoothing + 19-point stencil + eigen + score.
+ * Equivalent to calc_hessian followed by hessian_saliency.  Device face only. */
+int visfd_hip_ridge_saliency_dev(visfd_hip_ctx*, const float* src, const float* mask,
+                                 int64_t nx, int64_t ny, int64_t nz, float sigma,
+                                 float truncate_ratio, int eival_order, float* saliency,
+                                 float* direction);
+
+/* ---- a12 (second half): global top-fraction threshold, handlers.cpp:1751-1797 -------------------- */
+/* threshold = (floor(n_unmasked*fraction))-th largest unmasked saliency; every voxel with
+ * saliency < threshold is zeroed in place.  threshold_out nullable. */
+int visfd_hip_threshold_fraction(visfd_hip_ctx*, float* saliency, const float* mask, int64_t nvox,
+                                 float fraction, float* threshold_out);
+int visfd_hip_threshold_fraction_dev(visfd_hip_ctx*, float* saliency, const float* mask,
+                                     int64_t nvox, float fraction, float* threshold_out);
+/* building blocks for the multi-GPU (Z-slab) form: per-rank 2^16-bin histogram of the order-
+ * preserving key's digit `pass` (0 = most significant 16 bits, 1 = least) restricted to keys whose
+ * higher digits equal `prefix`; counts are summed across ranks by the caller. */
+int visfd_hip_select_histogram_dev(visfd_hip_ctx*, const float* saliency, const float* mask,
+                                   int64_t nvox, int pass, uint32_t prefix,
+                                   uint64_t* hist_host /* 65536 */, uint64_t* n_unmasked_host);
+int visfd_hip_apply_threshold_dev(visfd_hip_ctx*, float* saliency, int64_t nvox, float threshold);
+
+/* ---- a13+a14: TV3D::TVDenseStick, lib/visfd/feature.hpp:1645-1675,1711-2037,2217-2384 ------------ */
+/* As instantiated by HandleTV (handlers.cpp:1821-1836): normalize=false, diagonalize=false.
+ * tensor (6 channels) is zeroed where mask_dst!=0 (or everywhere if NULL) and left untouched
+ * elsewhere.  detect_curves selects the curve vote field (feature.hpp:2317-2347). */
+int visfd_hip_tv_dense_stick(visfd_hip_ctx*, const float* saliency, const float* direction,
+                             float* tensor, const float* mask_src, const float* mask_dst,
+                             int64_t nx, int64_t ny, int64_t nz, float sigma_tv, int exponent,
+                             float cutoff_ratio, int detect_curves);
+int visfd_hip_tv_dense_stick_dev(visfd_hip_ctx*, const float* saliency, const float* direction,
+                                 float* tensor, const float* mask_src, const float* mask_dst,
+                                 int64_t nx, int64_t ny, int64_t nz, float sigma_tv, int exponent,
+                                 float cutoff_ratio, int detect_curves);
+/* Z-slab form for multi-GPU runs: the arrays cover planes [z_lo, z_lo+nz_local) of a volume whose
+ * true height is nz_global; receivers are computed for planes [z_out0, z_out1) (global indices) and
+ * senders outside the supplied planes are treated as absent (so the caller must supply
+ * halfwidth ghost planes on interior faces). */
+int visfd_hip_tv_dense_stick_slab_dev(visfd_hip_ctx*, const float* saliency, const float* direction,
+                                      float* tensor, const float* mask_src, const float* mask_dst,
+                                      int64_t nx, int64_t ny, int64_t nz_local, int64_t z_out0,
+                                      int64_t z_out1, float sigma_tv, int exponent,
+                                      float cutoff_ratio, int detect_curves);
+/* halfwidth of the vote window, floor(sigma_tv*cutoff) (feature.hpp:1671); tables (nullable):
+ * w[(2h+1)^3], rhat[(2h+1)^3][3] as built by filter3d.hpp:546-601 and feature.hpp:2468-2482. */
+int visfd_hip_tv_tables(float sigma_tv, float cutoff_ratio, int* halfwidth_out, float* w,
+                        float* rhat);
+
+/* ---- a15: post-voting score, bin/filter_mrc/handlers.cpp:1870-1892 ------------------------------ */
+/* saliency[v] = lambda0 - lambda1 of the diagonalised vote tensor where mask != 0; untouched elsewhere */
+int visfd_hip_tensor_saliency(visfd_hip_ctx*, const float* tensor, const float* mask, int64_t nvox,
+                              int eival_order, float* saliency_inout);
+int visfd_hip_tensor_saliency_dev(visfd_hip_ctx*, const float* tensor, const float* mask,
+                                  int64_t nvox, int eival_order, float* saliency_inout);
+
+/* ---- Z-slab helpers for the separable filter (multi-GPU) -------------------------- */
+/* Same as apply_gauss_dev on a slab: arrays hold planes [z_lo, z_lo+nz_local) of a volume of height
+ * nz_global; planes outside the slab are treated as outside the image ONLY at the true faces
+ * (z_lo==0 / z_lo+nz_local==nz_global); the unmasked normaliser uses global coordinates
+ * (filter3d.hpp:1004-1021).  Output planes within halfwidth[2] of an interior slab face are
+ * invalid and must be discarded by the caller (they are ghost planes). */
+int visfd_hip_apply_gauss_slab_dev(visfd_hip_ctx*, const float* src, float* dst,
+                                   int64_t nx, int64_t ny, int64_t nz_local, int64_t z_lo,
+                                   int64_t nz_global, const float sigma[3], const int halfwidth[3],
+                                   int normalize, float* A_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VISFD_HIP_H */

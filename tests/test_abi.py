@@ -1,0 +1,65 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/visfd_hip.h declares; the Python binding covers exactly that set; host-side arithmetic
+entry points (taps, tables) agree with the oracle bit-for-bit.  No GPU needed."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import volgen
+from conftest import ROOT, assert_bits_equal, golden
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "visfd_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(visfd_hip_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from visfd_amd import api
+    if not os.path.exists(api.LIB_PATH):
+        from visfd_amd import build
+        build.build(verbose=False)
+    return api
+
+
+def test_library_exports_every_declared_symbol(lib):
+    L = ctypes.CDLL(lib.LIB_PATH)
+    names = _header_symbols()
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(L, n), "libvisfd_hip.so does not export " + n
+    assert sorted(lib.exported_symbols()) == names, "visfd_amd/api.py and include/visfd_hip.h disagree"
+    assert L.visfd_hip_abi_version() == 1
+
+
+def test_host_arithmetic_matches_oracle(lib, oracle):
+    for s, h in volgen.TAP_CASES:
+        assert_bits_equal(lib.gauss_taps(s, h), oracle.gauss_taps(s, h), "taps")
+    g = golden("taps")
+    for s, h in volgen.TAP_CASES:
+        assert_bits_equal(lib.gauss_taps(s, h), g["s%g_h%d" % (s, h)], "taps vs golden")
+    assert np.float32(lib.ratio_from_threshold(0.03)) == g["ratio"]
+    assert lib.gauss_halfwidths((2, 2, 0.1), 2.6482) == (5, 5, 1)
+    for s, c in ((8.66, 2 ** 0.5), (3.2, 2 ** 0.5), (2.0, 2.5)):
+        h, w, r = lib.tv_tables(s, c)
+        ho, wo, ro = oracle.tv_tables(s, c)
+        assert h == ho
+        assert_bits_equal(w, wo, "tv w")
+        assert_bits_equal(r, ro, "tv rhat")
+    d = np.array([5, 5.8, 6.6, 100.0], np.float32)
+    assert_bits_equal(lib.diameters_to_sigmas(d), oracle.diameters_to_sigmas(d), "d2s")
+    assert_bits_equal(lib.sigmas_to_diameters(d), oracle.sigmas_to_diameters(d), "s2d")
+
+
+def test_no_cpu_fallback(lib):
+    """Without a GPU the product must fail loudly, not compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(lib.VisfdHipError):
+        lib.Context(0)

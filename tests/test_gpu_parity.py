@@ -1,0 +1,274 @@
+"""Parity of the HIP path (through the C ABI, host-pointer face) against the CPU oracle, the
+committed golden vectors of the real reference, and the reference's own test answers.
+
+Bars (BASELINE.json north_star): bit-exact for indices (blob lists, thresholds' selected sets) and
+for every stage whose arithmetic is plain IEEE float (Gaussian, DoG/LoG, Hessian, tensor voting
+with exponent 2/4); 1e-5 relative (to the field's scale) where device libm enters (eigen solver:
+atan2/sin/cos, pow for odd exponents)."""
+import os
+
+import numpy as np
+import pytest
+
+import volgen
+from conftest import GOLDEN, assert_bits_equal, assert_close_rel, golden
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from visfd_amd import api
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+RATIO = None
+
+
+def ratio(oracle):
+    return oracle.ratio_from_threshold(0.03)
+
+
+# ------------------------------------------------------------------------------------------ Gaussian
+def test_gauss_reference_fixture(ctx, oracle):
+    g = golden("gauss_blobrec")
+    img = volgen.read_mrc(os.path.join(GOLDEN, "test_blob_detect.rec"))
+    msk = volgen.read_mrc(os.path.join(GOLDEN, "test_blob_detect_mask.rec"))
+    out, A = ctx.gauss_ratio(img, (2, 2, 2), ratio(oracle))
+    assert_bits_equal(out, g["out"], "gauss on test_blob_detect.rec")
+    assert np.float32(A) == g["A"]
+    out, A = ctx.gauss_ratio(img, (2, 2, 2), ratio(oracle), msk)
+    assert_bits_equal(out, g["out_masked"], "masked gauss on test_blob_detect.rec")
+
+
+def test_gauss_dog_log_seeded(ctx, oracle):
+    g = golden("gauss_seeded")
+    r = ratio(oracle)
+    src = volgen.noise_volume(volgen.GAUSS_SHAPE, seed=101)
+    mask = volgen.block_mask(volgen.GAUSS_SHAPE, seed=102)
+    for tag, m in (("nomask", None), ("mask", mask)):
+        for norm in (True, False):
+            o, A = ctx.gauss_hw(src, volgen.ANISO_SIGMA, volgen.ANISO_HW, m, norm)
+            assert_bits_equal(o, g["aniso_%s_norm%d" % (tag, norm)], "aniso %s %d" % (tag, norm))
+            assert np.float32(A) == g["aniso_%s_norm%d_A" % (tag, norm)]
+    o, _ = ctx.gauss_hw(np.ascontiguousarray(src[:4, :5, :3]), (2, 2, 2), (5, 5, 5))
+    assert_bits_equal(o, g["tiny_n_lt_window"], "image smaller than the window")
+    o, A, B = ctx.log(src, (2, 2, 2), 0.02, r)
+    assert_bits_equal(o, g["log_nomask"], "log")
+    assert_bits_equal(np.array([A, B], np.float32), g["log_AB"], "log A,B")
+    o, _, _ = ctx.log(src, (2.5, 2, 1.5), 0.02, r, mask)
+    assert_bits_equal(o, g["log_mask_aniso"], "log masked aniso")
+    o, _, _ = ctx.dog(src, (1.5,) * 3, (2.5,) * 3, (6, 6, 6))
+    assert_bits_equal(o, g["dog_nomask"], "dog")
+
+
+@pytest.mark.parametrize("shape", [(40, 50, 70), (33, 17, 129), (7, 9, 200), (64, 64, 64)])
+@pytest.mark.parametrize("h", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12])
+def test_gauss_fused_vs_oracle(ctx, oracle, shape, h):
+    """Every fused-kernel instantiation (isotropic window h=1..10) and the 3-pass path (h=12),
+    on shapes with ragged tiles, against the oracle, with and without normalisation."""
+    if h > 6 and shape != (40, 50, 70):
+        pytest.skip("wide windows: one shape is enough")
+    src = volgen.noise_volume(shape, seed=1000 + h)
+    sigma = (h / 2.6,) * 3
+    for norm in (True, False):
+        a, A = ctx.gauss_hw(src, sigma, (h, h, h), None, norm)
+        b, B = oracle.gauss_hw(src, sigma, (h, h, h), None, norm)
+        assert_bits_equal(a, b, "gauss h=%d shape=%s norm=%d" % (h, shape, norm))
+        assert A == B
+
+
+def test_gauss_masked_vs_oracle(ctx, oracle):
+    shape = (30, 41, 67)
+    src = volgen.noise_volume(shape, seed=5)
+    mask = volgen.block_mask(shape, seed=6)
+    wmask = mask * np.float32(0.5) + np.float32(0.25) * (volgen.noise_volume(shape, 7, 0.5, 0.1) > 0.5)
+    for m in (mask, np.ascontiguousarray(wmask, np.float32)):
+        for norm in (True, False):
+            a, _ = ctx.gauss_hw(src, (1.7, 2.2, 1.1), (4, 5, 2), m, norm)
+            b, _ = oracle.gauss_hw(src, (1.7, 2.2, 1.1), (4, 5, 2), m, norm)
+            assert_bits_equal(a, b, "masked gauss norm=%d" % norm)
+
+
+def test_gauss_sparse_and_empty_mask(ctx, oracle):
+    rng = np.random.default_rng(5)
+    src = np.zeros((18, 20, 22), np.float32)
+    idx = rng.integers(0, src.size, 12)
+    src.reshape(-1)[idx] = rng.standard_normal(12).astype(np.float32) * 50
+    src[3, 4, 5] = -0.0
+    a, _ = ctx.gauss_hw(src, (1.2,) * 3, (3, 3, 3), None, False)
+    b, _ = oracle.gauss_hw(src, (1.2,) * 3, (3, 3, 3), None, False)
+    assert_bits_equal(a, b, "sparse gauss")
+    mask = np.zeros_like(src)
+    mask[5:12, 6:14, 7:15] = 1
+    a, _ = ctx.gauss_hw(src + 7, (1.2,) * 3, (3, 3, 3), mask, True)
+    b, _ = oracle.gauss_hw(src + 7, (1.2,) * 3, (3, 3, 3), mask, True)
+    assert_bits_equal(a, b, "mostly-zero mask")
+    a, _ = ctx.gauss_hw(src + 7, (1.2,) * 3, (3, 3, 3), np.zeros_like(src), True)
+    b, _ = oracle.gauss_hw(src + 7, (1.2,) * 3, (3, 3, 3), np.zeros_like(src), True)
+    assert_bits_equal(a, b, "all-zero mask")
+
+
+def test_separable_generic_taps(ctx, oracle):
+    """ApplySeparable with caller-supplied (non-Gaussian, signed) taps."""
+    src = volgen.noise_volume((20, 21, 22), seed=8)
+    rng = np.random.default_rng(9)
+    taps = [rng.standard_normal(2 * h + 1).astype(np.float32) for h in (3, 2, 4)]
+    a, A = ctx.separable3d(src, taps, None, False)
+    import ctypes as C
+    fp = C.POINTER(C.c_float)
+    b = np.empty_like(src)
+    oracle.lib.vo_separable3d.restype = C.c_float
+    oracle.lib.vo_separable3d.argtypes = [fp, fp, fp, C.c_int, C.c_int, C.c_int, fp, C.c_int, fp, C.c_int, fp,
+                                          C.c_int, C.c_int]
+    B = oracle.lib.vo_separable3d(src.ctypes.data_as(fp), b.ctypes.data_as(fp), None, 22, 21, 20,
+                                  taps[0].ctypes.data_as(fp), 3, taps[1].ctypes.data_as(fp), 2,
+                                  taps[2].ctypes.data_as(fp), 4, 0)
+    assert_bits_equal(a, b, "generic separable")
+    assert A == B
+
+
+# ------------------------------------------------------------------------------------------ blobs
+def test_blob_reference_test_command(ctx, oracle):
+    """The reference's own test (tests/test_blob_detection.sh:21): 58 scales with a mask; it finds
+    11 minima and writes the best one as '235.2 392 313.6 177.915 -140.018'."""
+    from visfd_amd import api
+    g = golden("blob_rec")
+    img = volgen.read_mrc(os.path.join(GOLDEN, "test_blob_detect.rec"))
+    msk = volgen.read_mrc(os.path.join(GOLDEN, "test_blob_detect_mask.rec"))
+    diam = volgen.cli_blob_diameters(160.0, 280.0, 1.01, 1.0) / np.float32(19.6)
+    sig = api.diameters_to_sigmas(diam)
+    assert_bits_equal(sig, g["sigmas"], "sigmas")
+    mins, maxs = ctx.blob_dog(img, sig, msk, None, 0.02, ratio(oracle), 0.0, -np.inf, False)
+    mins = volgen.sort_blobs(mins, True)
+    assert len(mins) == 11
+    assert_bits_equal(mins, g["minima"], "minima (x,y,z,sigma,score)")
+    d = api.sigmas_to_diameters(np.ascontiguousarray(mins[:, 3]))
+    w = np.float32(19.6)
+    line = "%g %g %g %g %g" % (mins[0, 0] * w, mins[0, 1] * w, mins[0, 2] * w, d[0] * w, mins[0, 4])
+    assert line == "235.2 392 313.6 177.915 -140.018"
+
+
+def test_blob_seeded(ctx, oracle):
+    from visfd_amd import api
+    g = golden("blob_seeded")
+    src = volgen.blob_volume(volgen.BLOB_SHAPE, seed=201)
+    mask = volgen.block_mask(volgen.BLOB_SHAPE, seed=202)
+    sig = api.diameters_to_sigmas(volgen.BLOB_DIAMS)
+    for tag, m in (("nomask", None), ("mask", mask)):
+        for mode, kw in volgen.BLOB_MODES.items():
+            a, b = ctx.blob_dog(src, sig, m, None, 0.02, ratio(oracle), **kw)
+            assert_bits_equal(volgen.sort_blobs(a, True), g["%s_%s_min" % (tag, mode)], tag + mode + " min")
+            assert_bits_equal(volgen.sort_blobs(b, False), g["%s_%s_max" % (tag, mode)], tag + mode + " max")
+
+
+def test_blob_noise_many_candidates(ctx, oracle):
+    """Pure noise produces hundreds of extrema per scale: a stress test of index parity."""
+    src = volgen.noise_volume((40, 44, 48), seed=31)
+    sig = np.array([1.2, 1.5, 1.9, 2.4, 3.0], np.float32)
+    a = ctx.blob_dog(src, sig, None, None, 0.02, 2.5)
+    b = oracle.blob_dog(src, sig, None, None, 0.02, 2.5)
+    assert len(b[0]) > 50 and len(b[1]) > 50
+    assert_bits_equal(volgen.sort_blobs(a[0], True), volgen.sort_blobs(b[0], True), "noise minima")
+    assert_bits_equal(volgen.sort_blobs(a[1], False), volgen.sort_blobs(b[1], False), "noise maxima")
+
+
+def test_blob_tiny_images(ctx, oracle):
+    src = volgen.noise_volume((2, 9, 9), seed=3)
+    a = ctx.blob_dog(src, np.array([1, 1.3, 1.7], np.float32), None, None, 0.02, 2.5)
+    assert len(a[0]) == 0 and len(a[1]) == 0
+
+
+# ------------------------------------------------------------------------------------------ ridges
+def test_hessian_bit_exact(ctx, oracle):
+    g = golden("membrane_seeded")
+    src = volgen.membrane_volume(volgen.MEM_SHAPE, seed=301)
+    for tag, m in (("nomask", None), ("mask", volgen.block_mask(volgen.MEM_SHAPE, seed=302))):
+        grad, hess = ctx.calc_hessian(src, volgen.MEM_SIGMA, ratio(oracle), m)
+        assert_bits_equal(hess, g[tag + "_hess"], "hessian " + tag)
+        assert_bits_equal(grad, g[tag + "_grad"], "gradient " + tag)
+    with pytest.raises(Exception):
+        ctx.calc_hessian(np.zeros((2, 5, 5), np.float32), 1.0, 2.5)
+
+
+def test_eigen_solver(ctx, oracle):
+    g = golden("eigen")
+    mats = g["mats"]
+    for oname, order in (("inc", 0), ("dec", 1)):
+        d = ctx.diagonalize(mats, order)
+        ref = g["diag_" + oname]
+        scale = np.max(np.abs(ref[:, :3]), axis=1, keepdims=True) + 1e-30
+        err = np.max(np.abs(d[:, :3].astype(np.float64) - ref[:, :3]) / scale)
+        assert err <= 1e-5, "eigenvalues rel err %g" % err
+
+
+def test_saliency_direction_threshold(ctx, oracle):
+    g = golden("membrane_seeded")
+    for tag, m in (("nomask", None), ("mask", volgen.block_mask(volgen.MEM_SHAPE, seed=302))):
+        hess = g[tag + "_hess"]
+        sal, dirs = ctx.hessian_saliency(hess, po.ORDER_DECREASING, m)
+        assert_close_rel(sal, g[tag + "_sal"], 1e-5, "saliency " + tag)
+        # the principal direction is a unit vector: compare component-wise on that scale, on voxels
+        # whose top two eigenvalues are well separated (elsewhere the eigenvector is ill-conditioned)
+        ref = g[tag + "_dir"]
+        ev = oracle.diagonalize(hess, po.ORDER_DECREASING)
+        gap = np.abs(ev[..., 0] - ev[..., 1]) / (np.max(np.abs(ev[..., :3]), axis=-1) + 1e-30)
+        ok = gap > 1e-2
+        if m is not None:
+            ok &= m != 0
+        assert ok.mean() > 0.5
+        assert np.max(np.abs(dirs[ok] - ref[ok])) <= 2e-5
+        # threshold selection is exact given the same saliency input
+        s_in = g[tag + "_sal"].copy()
+        thr = ctx.threshold_fraction(s_in, volgen.MEM_FRACTION, m)
+        assert np.float32(thr) == g[tag + "_thr"]
+        assert_bits_equal(s_in, g[tag + "_salthr"], "thresholded saliency " + tag)
+
+
+# ------------------------------------------------------------------------------------------ tensor voting
+@pytest.mark.parametrize("tag", ["nomask", "mask"])
+def test_tensor_voting_seeded(ctx, oracle, tag, monkeypatch):
+    g = golden("membrane_seeded")
+    m = volgen.block_mask(volgen.MEM_SHAPE, seed=302) if tag == "mask" else None
+    sal, dirs = g[tag + "_salthr"], g[tag + "_dir"]
+    for dense in ("0", "1"):
+        monkeypatch.setenv("VISFD_HIP_TV_DENSE", dense)
+        for ex in (4, 2):
+            ten = ctx.tv_dense_stick(sal, dirs, volgen.MEM_TV_SIGMA, ex, 2.0 ** 0.5, m, m)
+            assert_bits_equal(ten, g["%s_tensor_e%d" % (tag, ex)], "tensor e%d dense=%s" % (ex, dense))
+        ten = ctx.tv_dense_stick(sal, dirs, volgen.MEM_TV_SIGMA, 3, 2.0 ** 0.5, m, m)
+        assert_close_rel(ten, g[tag + "_tensor_e3"], 1e-5, "tensor e3")
+        ten = ctx.tv_dense_stick(sal, dirs, volgen.MEM_TV_SIGMA, 4, 2.0 ** 0.5, m, m, curves=True)
+        assert_bits_equal(ten, g[tag + "_tensor_curves"], "curve-mode tensor")
+    ten = g[tag + "_tensor_e4"]
+    s2 = sal.copy()
+    ctx.tensor_saliency(ten, po.ORDER_DECREASING, s2, m)
+    assert_close_rel(s2, g[tag + "_tvsal"], 1e-5, "post-TV saliency")
+
+
+def test_membrane_reference_fixture_end_to_end(ctx, oracle):
+    """tests/test_image_membrane.rec through Hessian -> saliency -> threshold -> TV -> score, every
+    stage fed by the previous DEVICE stage, compared with the reference's outputs."""
+    g = golden("membrane_rec")
+    mem = volgen.read_mrc(os.path.join(GOLDEN, "test_image_membrane.rec"))
+    sigma = np.float32(1.5)
+    grad, hess = ctx.calc_hessian(mem, sigma, ratio(oracle))
+    assert_bits_equal(hess, g["hess"], "hessian")
+    sal, dirs = ctx.hessian_saliency(hess, po.ORDER_DECREASING)
+    assert_close_rel(sal, g["sal_dec"], 1e-5, "saliency")
+    thr = ctx.threshold_fraction(sal, 0.1)
+    assert abs(thr - float(g["thr_dec"])) <= 1e-5 * abs(float(g["thr_dec"]))
+    kept, kept_ref = sal != 0, g["salthr_dec"] != 0
+    # the selected set may differ only where the saliency ties the threshold to within tolerance
+    diff = kept != kept_ref
+    if diff.any():
+        near = np.abs(g["sal_dec"][diff] - g["thr_dec"]) <= 1e-5 * abs(float(g["thr_dec"]))
+        assert near.all(), "threshold membership differs away from the tie band"
+    ten = ctx.tv_dense_stick(sal, dirs, 4 * sigma / 2, 4, 2.0 ** 0.5)
+    assert_close_rel(ten, g["tensor_dec"], 1e-4 if diff.any() else 1e-5, "vote tensor")
+    s2 = sal.copy()
+    ctx.tensor_saliency(ten, po.ORDER_DECREASING, s2)
+    assert_close_rel(s2, g["tvsal_dec"], 1e-4 if diff.any() else 1e-5, "post-TV saliency")

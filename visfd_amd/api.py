@@ -1,0 +1,395 @@
+"""ctypes binding of libvisfd_hip.so (include/visfd_hip.h) for Python hosts.
+
+Two faces, like the C ABI:
+  * `Context.<op>(numpy arrays)`      host face  (drop-in: synchronous, copies in and out)
+  * `Context.<op>_dev(torch tensors)` device face (asynchronous on the context's stream; tensors
+                                      live in HBM; multi-channel fields are channel-planar:
+                                      dir (3,nz,ny,nx), tensor (6,nz,ny,nx))
+
+There is NO CPU fallback: loading fails loudly when the HIP library is missing, and creating a
+context fails when no GPU is present.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvisfd_hip.so")
+
+INCREASING_EIVALS = 0
+DECREASING_EIVALS = 1
+
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int)
+_i64 = C.c_int64
+_vp = C.c_void_p
+
+
+class VisfdHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("visfd_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Blob(C.Structure):
+    _fields_ = [("ix", C.c_int32), ("iy", C.c_int32), ("iz", C.c_int32), ("scale", C.c_int32),
+                ("sigma", C.c_float), ("score", C.c_float)]
+
+
+_VOL = [_vp, _vp, _vp, _i64, _i64, _i64]  # src, dst, mask, nx, ny, nz  (pointers as void*)
+
+_SIGS = {
+    "visfd_hip_create": (C.c_int, [C.c_int, _vp, C.POINTER(_vp)]),
+    "visfd_hip_destroy": (C.c_int, [_vp]),
+    "visfd_hip_synchronize": (C.c_int, [_vp]),
+    "visfd_hip_trim": (C.c_int, [_vp]),
+    "visfd_hip_last_error": (C.c_char_p, []),
+    "visfd_hip_abi_version": (C.c_int, []),
+    "visfd_hip_workspace_bytes": (_i64, [_vp]),
+    "visfd_hip_gauss_taps": (C.c_int, [C.c_float, C.c_int, _fp]),
+    "visfd_hip_ratio_from_threshold": (C.c_float, [C.c_float]),
+    "visfd_hip_gauss_halfwidths": (C.c_int, [_fp, C.c_float, _ip]),
+    "visfd_hip_separable3d": (C.c_int, [_vp] + _VOL + [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, _fp]),
+    "visfd_hip_separable3d_dev": (C.c_int, [_vp] + _VOL + [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, _fp]),
+    "visfd_hip_apply_gauss": (C.c_int, [_vp] + _VOL + [_fp, _ip, C.c_int, _fp]),
+    "visfd_hip_apply_gauss_dev": (C.c_int, [_vp] + _VOL + [_fp, _ip, C.c_int, _fp]),
+    "visfd_hip_apply_gauss_slab_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _fp, _ip, C.c_int, _fp]),
+    "visfd_hip_apply_dog": (C.c_int, [_vp] + _VOL + [_fp, _fp, _ip, _fp, _fp]),
+    "visfd_hip_apply_dog_dev": (C.c_int, [_vp] + _VOL + [_fp, _fp, _ip, _fp, _fp]),
+    "visfd_hip_apply_log": (C.c_int, [_vp] + _VOL + [_fp, C.c_float, C.c_float, _fp, _fp]),
+    "visfd_hip_apply_log_dev": (C.c_int, [_vp] + _VOL + [_fp, C.c_float, C.c_float, _fp, _fp]),
+    "visfd_hip_blob_dog": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _fp, C.c_int, _fp, C.c_float, C.c_float,
+                                     C.c_float, C.c_float, C.c_int, C.POINTER(Blob), _i64, C.POINTER(_i64),
+                                     C.POINTER(Blob), _i64, C.POINTER(_i64)]),
+    "visfd_hip_blob_dog_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _fp, C.c_int, _fp, C.c_float, C.c_float,
+                                         C.c_float, C.c_float, C.c_int, C.POINTER(Blob), _i64, C.POINTER(_i64),
+                                         C.POINTER(Blob), _i64, C.POINTER(_i64)]),
+    "visfd_hip_blob_diameters_to_sigmas": (C.c_int, [_fp, C.c_int, _fp]),
+    "visfd_hip_blob_sigmas_to_diameters": (C.c_int, [_fp, C.c_int, _fp]),
+    "visfd_hip_calc_hessian": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, C.c_float, C.c_float]),
+    "visfd_hip_calc_hessian_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, C.c_float, C.c_float]),
+    "visfd_hip_diagonalize_flat_sym3": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int]),
+    "visfd_hip_diagonalize_flat_sym3_dev": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int]),
+    "visfd_hip_hessian_saliency": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, _vp, _vp]),
+    "visfd_hip_hessian_saliency_dev": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, _vp, _vp]),
+    "visfd_hip_ridge_saliency_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, C.c_float, C.c_float, C.c_int,
+                                               _vp, _vp]),
+    "visfd_hip_threshold_fraction": (C.c_int, [_vp, _vp, _vp, _i64, C.c_float, _fp]),
+    "visfd_hip_threshold_fraction_dev": (C.c_int, [_vp, _vp, _vp, _i64, C.c_float, _fp]),
+    "visfd_hip_select_histogram_dev": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_uint32,
+                                                 C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "visfd_hip_apply_threshold_dev": (C.c_int, [_vp, _vp, _i64, C.c_float]),
+    "visfd_hip_tv_dense_stick": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, C.c_float, C.c_int,
+                                           C.c_float, C.c_int]),
+    "visfd_hip_tv_dense_stick_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, C.c_float, C.c_int,
+                                               C.c_float, C.c_int]),
+    "visfd_hip_tv_dense_stick_slab_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
+                                                    C.c_float, C.c_int, C.c_float, C.c_int]),
+    "visfd_hip_tv_tables": (C.c_int, [C.c_float, C.c_float, _ip, _fp, _fp]),
+    "visfd_hip_tensor_saliency": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, _vp]),
+    "visfd_hip_tensor_saliency_dev": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, _vp]),
+}
+
+_lib = None
+
+
+def load_library():
+    """Load libvisfd_hip.so; raises if it has not been built (python -m visfd_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: build it with `python -m visfd_amd.build` "
+                              "(there is no CPU fallback)" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def _np(a):
+    if a is None:
+        return None
+    assert isinstance(a, np.ndarray) and a.dtype == np.float32 and a.flags["C_CONTIGUOUS"], "need C float32"
+    return a.ctypes.data
+
+
+def _dev(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous() and str(t.dtype) == "torch.float32", "need contiguous cuda float32"
+    return t.data_ptr()
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def _i3(v):
+    return (C.c_int * 3)(*[int(x) for x in v])
+
+
+def gauss_taps(sigma, h):
+    out = np.empty(2 * h + 1, np.float32)
+    rc = load_library().visfd_hip_gauss_taps(float(sigma), int(h), out.ctypes.data_as(_fp))
+    if rc:
+        raise VisfdHipError(rc, load_library().visfd_hip_last_error().decode())
+    return out
+
+
+def ratio_from_threshold(thr):
+    return float(load_library().visfd_hip_ratio_from_threshold(float(thr)))
+
+
+def gauss_halfwidths(sigma, ratio):
+    hw = (C.c_int * 3)()
+    load_library().visfd_hip_gauss_halfwidths(_f3(sigma), float(ratio), hw)
+    return tuple(hw)
+
+
+def tv_tables(sigma_tv, cutoff):
+    L = load_library()
+    h = C.c_int()
+    L.visfd_hip_tv_tables(float(sigma_tv), float(cutoff), C.byref(h), None, None)
+    n = 2 * h.value + 1
+    w = np.empty((n, n, n), np.float32)
+    r = np.empty((n, n, n, 3), np.float32)
+    L.visfd_hip_tv_tables(float(sigma_tv), float(cutoff), C.byref(h), w.ctypes.data_as(_fp), r.ctypes.data_as(_fp))
+    return h.value, w, r
+
+
+def diameters_to_sigmas(d):
+    d = np.ascontiguousarray(d, np.float32)
+    s = np.empty_like(d)
+    load_library().visfd_hip_blob_diameters_to_sigmas(d.ctypes.data_as(_fp), len(d), s.ctypes.data_as(_fp))
+    return s
+
+
+def sigmas_to_diameters(s):
+    s = np.ascontiguousarray(s, np.float32)
+    d = np.empty_like(s)
+    load_library().visfd_hip_blob_sigmas_to_diameters(s.ctypes.data_as(_fp), len(s), d.ctypes.data_as(_fp))
+    return d
+
+
+def _blobs_to_rows(arr, n):
+    """-> float32 rows x,y,z,sigma,score (the reference's list layout) plus the scale indices."""
+    rows = np.empty((n, 5), np.float32)
+    scale = np.empty(n, np.int32)
+    for i in range(n):
+        b = arr[i]
+        rows[i] = (b.ix, b.iy, b.iz, b.sigma, b.score)
+        scale[i] = b.scale
+    return rows, scale
+
+
+class Context:
+    """One GPU, one HIP stream, one workspace (visfd_hip_ctx)."""
+
+    def __init__(self, device=0, stream=None):
+        self._L = load_library()
+        h = _vp()
+        rc = self._L.visfd_hip_create(int(device), _vp(stream) if stream else None, C.byref(h))
+        if rc:
+            raise VisfdHipError(rc, self._L.visfd_hip_last_error().decode())
+        self._h = h
+
+    def _chk(self, rc):
+        if rc:
+            raise VisfdHipError(rc, self._L.visfd_hip_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.visfd_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        self._chk(self._L.visfd_hip_synchronize(self._h))
+
+    def trim(self):
+        self._chk(self._L.visfd_hip_trim(self._h))
+
+    def workspace_bytes(self):
+        return int(self._L.visfd_hip_workspace_bytes(self._h))
+
+    # ---------------------------------------------------------------- host face (numpy)
+    def separable3d(self, src, taps_xyz, mask=None, normalize=True):
+        nz, ny, nx = src.shape
+        dst = np.empty_like(src)
+        A = C.c_float()
+        t = [np.ascontiguousarray(x, np.float32) for x in taps_xyz]
+        h = [(len(x) - 1) // 2 for x in t]
+        self._chk(self._L.visfd_hip_separable3d(self._h, _np(src), _np(dst), _np(mask), nx, ny, nz,
+                                                t[0].ctypes.data_as(_fp), h[0], t[1].ctypes.data_as(_fp), h[1],
+                                                t[2].ctypes.data_as(_fp), h[2], int(normalize), C.byref(A)))
+        return dst, A.value
+
+    def gauss_hw(self, src, sigma, hw, mask=None, normalize=True):
+        nz, ny, nx = src.shape
+        dst = np.empty_like(src)
+        A = C.c_float()
+        self._chk(self._L.visfd_hip_apply_gauss(self._h, _np(src), _np(dst), _np(mask), nx, ny, nz, _f3(sigma),
+                                                _i3(hw), int(normalize), C.byref(A)))
+        return dst, A.value
+
+    def gauss_ratio(self, src, sigma, ratio, mask=None, normalize=True):
+        return self.gauss_hw(src, sigma, gauss_halfwidths(sigma, ratio), mask, normalize)
+
+    def dog(self, src, sigma_a, sigma_b, hw, mask=None):
+        nz, ny, nx = src.shape
+        dst = np.empty_like(src)
+        A, B = C.c_float(), C.c_float()
+        self._chk(self._L.visfd_hip_apply_dog(self._h, _np(src), _np(dst), _np(mask), nx, ny, nz, _f3(sigma_a),
+                                              _f3(sigma_b), _i3(hw), C.byref(A), C.byref(B)))
+        return dst, A.value, B.value
+
+    def log(self, src, sigma, delta, ratio, mask=None):
+        nz, ny, nx = src.shape
+        dst = np.empty_like(src)
+        A, B = C.c_float(), C.c_float()
+        self._chk(self._L.visfd_hip_apply_log(self._h, _np(src), _np(dst), _np(mask), nx, ny, nz, _f3(sigma),
+                                              float(delta), float(ratio), C.byref(A), C.byref(B)))
+        return dst, A.value, B.value
+
+    def _blob_call(self, fn, psrc, pmask, shape, sigmas, aspect, delta, ratio, minima_threshold, maxima_threshold,
+                   use_ratios, cap):
+        nz, ny, nx = shape
+        sig = np.ascontiguousarray(sigmas, np.float32)
+        amin = (Blob * cap)()
+        amax = (Blob * cap)()
+        nmin, nmax = _i64(), _i64()
+        asp = _f3(aspect) if aspect is not None else None
+        self._chk(fn(self._h, psrc, pmask, nx, ny, nz, sig.ctypes.data_as(_fp), len(sig), asp, float(delta),
+                     float(ratio), float(minima_threshold), float(maxima_threshold), int(use_ratios), amin, cap,
+                     C.byref(nmin), amax, cap, C.byref(nmax)))
+        return _blobs_to_rows(amin, nmin.value)[0], _blobs_to_rows(amax, nmax.value)[0]
+
+    def blob_dog(self, src, sigmas, mask=None, aspect=None, delta=0.02, ratio=2.5, minima_threshold=np.inf,
+                 maxima_threshold=-np.inf, use_ratios=False, cap=1 << 16):
+        return self._blob_call(self._L.visfd_hip_blob_dog, _np(src), _np(mask), src.shape, sigmas, aspect, delta,
+                               ratio, minima_threshold, maxima_threshold, use_ratios, cap)
+
+    def calc_hessian(self, src, sigma, ratio, mask=None, want_grad=True):
+        nz, ny, nx = src.shape
+        hess = np.zeros((nz, ny, nx, 6), np.float32)
+        grad = np.zeros((nz, ny, nx, 3), np.float32) if want_grad else None
+        self._chk(self._L.visfd_hip_calc_hessian(self._h, _np(src), _np(grad), _np(hess), _np(mask), nx, ny, nz,
+                                                 float(sigma), float(ratio)))
+        return grad, hess
+
+    def diagonalize(self, m6, order):
+        m6 = np.ascontiguousarray(m6, np.float32)
+        out = np.empty_like(m6)
+        self._chk(self._L.visfd_hip_diagonalize_flat_sym3(self._h, _np(m6), _np(out), m6.size // 6, int(order)))
+        return out
+
+    def hessian_saliency(self, hess, order, mask=None):
+        shp = hess.shape[:-1]
+        sal = np.empty(shp, np.float32)
+        dirs = np.zeros(shp + (3,), np.float32)
+        self._chk(self._L.visfd_hip_hessian_saliency(self._h, _np(hess), _np(mask), sal.size, int(order), _np(sal),
+                                                     _np(dirs)))
+        return sal, dirs
+
+    def threshold_fraction(self, sal, fraction, mask=None):
+        thr = C.c_float()
+        self._chk(self._L.visfd_hip_threshold_fraction(self._h, _np(sal), _np(mask), sal.size, float(fraction),
+                                                       C.byref(thr)))
+        return thr.value
+
+    def tv_dense_stick(self, sal, dirs, sigma_tv, exponent=4, cutoff=2.0 ** 0.5, mask_src=None, mask_dst=None,
+                       curves=False):
+        nz, ny, nx = sal.shape
+        tensor = np.zeros((nz, ny, nx, 6), np.float32)
+        self._chk(self._L.visfd_hip_tv_dense_stick(self._h, _np(sal), _np(dirs), _np(tensor), _np(mask_src),
+                                                   _np(mask_dst), nx, ny, nz, float(sigma_tv), int(exponent),
+                                                   float(cutoff), int(curves)))
+        return tensor
+
+    def tensor_saliency(self, tensor, order, sal_inout, mask=None):
+        self._chk(self._L.visfd_hip_tensor_saliency(self._h, _np(tensor), _np(mask), sal_inout.size, int(order),
+                                                    _np(sal_inout)))
+        return sal_inout
+
+    # ---------------------------------------------------------------- device face (torch)
+    def gauss_dev(self, src, dst, sigma, hw, mask=None, normalize=True):
+        nz, ny, nx = src.shape
+        A = C.c_float()
+        self._chk(self._L.visfd_hip_apply_gauss_dev(self._h, _dev(src), _dev(dst), _dev(mask), nx, ny, nz,
+                                                    _f3(sigma), _i3(hw), int(normalize), C.byref(A)))
+        return A.value
+
+    def gauss_slab_dev(self, src, dst, z_lo, nz_global, sigma, hw, normalize=True):
+        nz, ny, nx = src.shape
+        A = C.c_float()
+        self._chk(self._L.visfd_hip_apply_gauss_slab_dev(self._h, _dev(src), _dev(dst), nx, ny, nz, int(z_lo),
+                                                         int(nz_global), _f3(sigma), _i3(hw), int(normalize),
+                                                         C.byref(A)))
+        return A.value
+
+    def log_dev(self, src, dst, sigma, delta, ratio, mask=None):
+        nz, ny, nx = src.shape
+        self._chk(self._L.visfd_hip_apply_log_dev(self._h, _dev(src), _dev(dst), _dev(mask), nx, ny, nz,
+                                                  _f3(sigma), float(delta), float(ratio), None, None))
+
+    def blob_dog_dev(self, src, sigmas, mask=None, aspect=None, delta=0.02, ratio=2.5, minima_threshold=np.inf,
+                     maxima_threshold=-np.inf, use_ratios=False, cap=1 << 16):
+        return self._blob_call(self._L.visfd_hip_blob_dog_dev, _dev(src), _dev(mask), tuple(src.shape), sigmas,
+                               aspect, delta, ratio, minima_threshold, maxima_threshold, use_ratios, cap)
+
+    def calc_hessian_dev(self, src, grad, hess, sigma, ratio, mask=None):
+        nz, ny, nx = src.shape
+        self._chk(self._L.visfd_hip_calc_hessian_dev(self._h, _dev(src), _dev(grad), _dev(hess), _dev(mask), nx,
+                                                     ny, nz, float(sigma), float(ratio)))
+
+    def hessian_saliency_dev(self, hess, sal, dirs, order, mask=None):
+        self._chk(self._L.visfd_hip_hessian_saliency_dev(self._h, _dev(hess), _dev(mask), sal.numel(), int(order),
+                                                         _dev(sal), _dev(dirs)))
+
+    def ridge_saliency_dev(self, src, sal, dirs, sigma, ratio, order, mask=None):
+        nz, ny, nx = src.shape
+        self._chk(self._L.visfd_hip_ridge_saliency_dev(self._h, _dev(src), _dev(mask), nx, ny, nz, float(sigma),
+                                                       float(ratio), int(order), _dev(sal), _dev(dirs)))
+
+    def threshold_fraction_dev(self, sal, fraction, mask=None):
+        thr = C.c_float()
+        self._chk(self._L.visfd_hip_threshold_fraction_dev(self._h, _dev(sal), _dev(mask), sal.numel(),
+                                                           float(fraction), C.byref(thr)))
+        return thr.value
+
+    def select_histogram_dev(self, sal, pass_, prefix, mask=None):
+        hist = np.zeros(65536, np.uint64)
+        n = C.c_uint64()
+        self._chk(self._L.visfd_hip_select_histogram_dev(self._h, _dev(sal), _dev(mask), sal.numel(), int(pass_),
+                                                         int(prefix), hist.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                         C.byref(n)))
+        return hist, int(n.value)
+
+    def apply_threshold_dev(self, sal, thr):
+        self._chk(self._L.visfd_hip_apply_threshold_dev(self._h, _dev(sal), sal.numel(), float(thr)))
+
+    def tv_dense_stick_dev(self, sal, dirs, tensor, sigma_tv, exponent=4, cutoff=2.0 ** 0.5, mask_src=None,
+                           mask_dst=None, curves=False, z_out=None):
+        nz, ny, nx = sal.shape
+        z0, z1 = (0, nz) if z_out is None else z_out
+        self._chk(self._L.visfd_hip_tv_dense_stick_slab_dev(self._h, _dev(sal), _dev(dirs), _dev(tensor),
+                                                            _dev(mask_src), _dev(mask_dst), nx, ny, nz, int(z0),
+                                                            int(z1), float(sigma_tv), int(exponent), float(cutoff),
+                                                            int(curves)))
+
+    def tensor_saliency_dev(self, tensor, sal, order, mask=None):
+        self._chk(self._L.visfd_hip_tensor_saliency_dev(self._h, _dev(tensor), _dev(mask), sal.numel(), int(order),
+                                                        _dev(sal)))

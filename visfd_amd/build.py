@@ -1,0 +1,75 @@
+"""Build libvisfd_hip.so (the HIP kernels + C ABI) in-tree with hipcc for gfx950.
+
+    python -m visfd_amd.build [--force] [-j N]
+
+Objects go to build/ (git-ignored); the shared library is written next to this file so that it
+travels with the repository snapshot to the GPU box.  hipcc cross-compiles without a GPU.
+-ffp-contract=off is part of the numerical contract (see csrc/gauss.hip).
+"""
+import concurrent.futures
+import os
+import subprocess
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OBJDIR = os.path.join(ROOT, "build", "visfd_hip")
+LIB = os.path.join(HERE, "libvisfd_hip.so")
+
+SOURCES = ["host_math.cpp", "api.hip", "gauss.hip", "gauss_fused.hip", "blob.hip", "ridge.hip", "select.hip",
+           "tv.hip", "tv_tiled.hip"]
+HEADERS = ["common.hpp", "eigen3.hpp", os.path.join("..", "..", "include", "visfd_hip.h")]
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+         "-Wall", "-Wno-unused-function"]
+
+
+def _mtime(p):
+    return os.path.getmtime(p) if os.path.exists(p) else 0.0
+
+
+def _compile(src, obj):
+    t0 = time.time()
+    cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    return src, r.returncode, r.stdout + r.stderr, time.time() - t0
+
+
+def build(force=False, jobs=4, verbose=True):
+    os.makedirs(OBJDIR, exist_ok=True)
+    newest_header = max(_mtime(os.path.join(CSRC, h)) for h in HEADERS)
+    todo, objs = [], []
+    for s in SOURCES:
+        obj = os.path.join(OBJDIR, os.path.splitext(s)[0] + ".o")
+        objs.append(obj)
+        if force or _mtime(obj) < max(_mtime(os.path.join(CSRC, s)), newest_header):
+            todo.append((s, obj))
+    if todo:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:
+            for src, rc, out, dt in ex.map(lambda a: _compile(*a), todo):
+                if verbose:
+                    print("[visfd_amd.build] %-18s %5.1fs %s" % (src, dt, "ok" if rc == 0 else "FAILED"))
+                if rc != 0:
+                    sys.stderr.write(out)
+                    raise RuntimeError("hipcc failed on " + src)
+                elif out.strip() and verbose:
+                    sys.stderr.write(out)
+    if todo or not os.path.exists(LIB) or _mtime(LIB) < max(_mtime(o) for o in objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout + r.stderr)
+            raise RuntimeError("link failed")
+        if verbose:
+            print("[visfd_amd.build] linked", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    j = 4
+    if "-j" in sys.argv:
+        j = int(sys.argv[sys.argv.index("-j") + 1])
+    build(force="--force" in sys.argv, jobs=j)

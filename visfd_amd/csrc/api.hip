@@ -1,0 +1,653 @@
+// api.hip -- the extern "C" surface declared in include/visfd_hip.h.
+// Device-pointer entry points orchestrate the stage functions; host-pointer entry points stage the
+// caller's volumes through the context workspace (H2D, run, D2H) and are synchronous.
+#include <cmath>
+#include <limits>
+#include <vector>
+
+#include "common.hpp"
+
+namespace vh {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+int ws_get(visfd_hip_ctx* ctx, Slot s, size_t bytes, void** out) {
+  if (bytes == 0) bytes = 16;
+  if (ctx->slot_bytes[s] < bytes) {
+    if (ctx->slot_ptr[s]) {
+      // buffers may still be in use by queued kernels
+      VH_HIP(hipStreamSynchronize(ctx->stream));
+      VH_HIP(hipFree(ctx->slot_ptr[s]));
+      ctx->slot_ptr[s] = nullptr;
+      ctx->slot_bytes[s] = 0;
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess)
+      return fail(VISFD_HIP_ENOMEM, "hipMalloc of " + std::to_string(bytes) + " bytes failed: " +
+                                        hipGetErrorString(e));
+    ctx->slot_ptr[s] = p;
+    ctx->slot_bytes[s] = bytes;
+  }
+  *out = ctx->slot_ptr[s];
+  return VISFD_HIP_OK;
+}
+
+namespace {
+
+struct Staged {  // a host volume mirrored in a workspace slot
+  float* d = nullptr;
+};
+
+int upload(visfd_hip_ctx* ctx, Slot s, const float* host, size_t count, float** dev) {
+  if (!host) { *dev = nullptr; return VISFD_HIP_OK; }
+  VH_TRY(ws(ctx, s, count, dev));
+  VH_HIP(hipMemcpyAsync(*dev, host, sizeof(float) * count, hipMemcpyHostToDevice, ctx->stream));
+  return VISFD_HIP_OK;
+}
+int download(visfd_hip_ctx* ctx, float* host, const float* dev, size_t count) {
+  VH_HIP(hipMemcpyAsync(host, dev, sizeof(float) * count, hipMemcpyDeviceToHost, ctx->stream));
+  VH_HIP(hipStreamSynchronize(ctx->stream));
+  return VISFD_HIP_OK;
+}
+
+int halfwidths_from_ratio(const float sigma[3], float ratio, int hw[3]) {
+  // filter3d.hpp:1240-1247: floor of the float product, at least 1
+  for (int d = 0; d < 3; d++) {
+    hw[d] = (int)std::floor(sigma[d] * ratio);
+    if (hw[d] < 1) hw[d] = 1;
+  }
+  return VISFD_HIP_OK;
+}
+
+int gauss_dev(visfd_hip_ctx* ctx, const float* src, float* dst, const float* mask, i64 nx, i64 ny, i64 nz,
+              const float sigma[3], const int hw[3], bool normalize, SlabInfo slab, float* A_out) {
+  VH_REQUIRE(ctx && src && dst && sigma && hw, "null argument");
+  std::vector<float> t[3];
+  for (int d = 0; d < 3; d++) {
+    VH_REQUIRE(sigma[d] >= 0.0f, "sigma must be non-negative");
+    VH_REQUIRE(hw[d] >= 0 && hw[d] <= MAX_HALFWIDTH, "filter halfwidth must be in [0, 64]");
+    t[d].resize(2 * hw[d] + 1);
+    host_gauss_taps(sigma[d], hw[d], t[d].data());
+  }
+  return dev_separable3d(ctx, src, dst, mask, nx, ny, nz, t[0].data(), hw[0], t[1].data(), hw[1],
+                         t[2].data(), hw[2], normalize, slab, A_out);
+}
+
+// ApplyDog with a caller-provided temp volume (filter3d.hpp:1338-1402)
+int dog_dev(visfd_hip_ctx* ctx, const float* src, float* dst, float* tmp, const float* mask, i64 nx, i64 ny,
+            i64 nz, const float sa[3], const float sb[3], const int hw[3], float scale, bool do_scale,
+            float* A, float* B) {
+  const SlabInfo whole = {0, nz};
+  VH_TRY(gauss_dev(ctx, src, dst, mask, nx, ny, nz, sa, hw, true, whole, A));
+  VH_TRY(gauss_dev(ctx, src, tmp, mask, nx, ny, nz, sb, hw, true, whole, B));
+  return dev_sub_scale(ctx, dst, tmp, nx * ny * nz, scale, do_scale);
+}
+
+struct LogPlan {
+  float sa[3], sb[3];
+  int hw[3];
+  float scale;
+};
+// ApplyLog parameter derivation (filter3d.hpp:1451-1464, :1493)
+LogPlan plan_log(const float sigma[3], float delta, float ratio) {
+  LogPlan p;
+  for (int d = 0; d < 3; d++) {
+    p.sa[d] = (float)(sigma[d] * (1.0 - 0.5 * delta));
+    p.sb[d] = (float)(sigma[d] * (1.0 + 0.5 * delta));
+    p.hw[d] = (int)std::floor(ratio * std::fmax(p.sa[d], p.sb[d]));
+  }
+  p.scale = (float)(1.0 / (delta * delta));
+  return p;
+}
+
+int log_dev(visfd_hip_ctx* ctx, const float* src, float* dst, float* tmp, const float* mask, i64 nx, i64 ny,
+            i64 nz, const float sigma[3], float delta, float ratio, float* A, float* B) {
+  const LogPlan p = plan_log(sigma, delta, ratio);
+  for (int d = 0; d < 3; d++)
+    VH_REQUIRE(p.hw[d] >= 0 && p.hw[d] <= MAX_HALFWIDTH, "LoG filter halfwidth must be in [0, 64]");
+  float a = 0, b = 0;
+  VH_TRY(dog_dev(ctx, src, dst, tmp, mask, nx, ny, nz, p.sa, p.sb, p.hw, p.scale, true, &a, &b));
+  if (A) *A = a * p.scale;   // filter3d.hpp:1502-1505
+  if (B) *B = b * p.scale;
+  return VISFD_HIP_OK;
+}
+
+int blob_dog_dev(visfd_hip_ctx* ctx, const float* src, const float* mask, i64 nx, i64 ny, i64 nz,
+                 const float* blob_sigma, int n_sigma, const float* aspect, float delta, float ratio,
+                 float min_thr, float max_thr, bool use_ratios, visfd_hip_blob* minima, int64_t min_cap,
+                 int64_t* n_min, visfd_hip_blob* maxima, int64_t max_cap, int64_t* n_max) {
+  VH_REQUIRE(ctx && src && blob_sigma && n_min && n_max, "null argument");
+  VH_REQUIRE(n_sigma >= 0, "negative scale count");
+  VH_TRY(check_dims(nx, ny, nz));
+  const i64 n = nx * ny * nz;
+  const float inf = std::numeric_limits<float>::infinity();
+  float* vol[3];
+  VH_TRY(ws(ctx, WS_LOG0, (size_t)n, &vol[0]));
+  VH_TRY(ws(ctx, WS_LOG1, (size_t)n, &vol[1]));
+  VH_TRY(ws(ctx, WS_LOG2, (size_t)n, &vol[2]));
+  float* tmp = nullptr;
+  VH_TRY(ws(ctx, WS_C, (size_t)n, &tmp));
+  float asp[3] = {1.0f, 1.0f, 1.0f};
+  if (aspect) for (int d = 0; d < 3; d++) asp[d] = aspect[d];
+  std::vector<visfd_hip_blob> mins, maxs;
+  // running thresholds: absolute mode applies them in the scan (strict, feature.hpp:270-291);
+  // ratio mode keeps every candidate and prunes at the end (feature.hpp:362-417), see header.
+  const float scan_min = use_ratios ? inf : min_thr;
+  const float scan_max = use_ratios ? -inf : max_thr;
+  for (int ir = 0; ir < n_sigma; ir++) {
+    const float sg[3] = {blob_sigma[ir] * asp[0], blob_sigma[ir] * asp[1], blob_sigma[ir] * asp[2]};
+    VH_TRY(log_dev(ctx, src, vol[ir % 3], tmp, mask, nx, ny, nz, sg, delta, ratio, nullptr, nullptr));
+    if (ir < 2) continue;
+    VH_TRY(dev_blob_scan(ctx, vol[(ir - 2) % 3], vol[(ir - 1) % 3], vol[ir % 3], mask, nx, ny, nz, ir - 1,
+                         blob_sigma[ir - 1], scan_min, scan_max, true, true, &mins, &maxs));
+  }
+  if ((min_thr != inf) || (max_thr != -inf)) {
+    float tmin = min_thr, tmax = max_thr;
+    if (use_ratios) {
+      float gmin = 1.0f, gmax = -1.0f;  // feature.hpp:122-123
+      for (auto& b : mins) if (b.score < gmin) gmin = b.score;
+      for (auto& b : maxs) if (b.score > gmax) gmax = b.score;
+      // a side whose ratio threshold is infinite is "disabled": keep everything on that side
+      tmin = (min_thr == inf) ? inf : min_thr * gmin;
+      tmax = (max_thr == -inf) ? -inf : max_thr * gmax;
+    }
+    std::vector<visfd_hip_blob> a, b;
+    for (auto& m : mins) if (m.score <= tmin) a.push_back(m);
+    for (auto& m : maxs) if (m.score >= tmax) b.push_back(m);
+    mins.swap(a);
+    maxs.swap(b);
+  }
+  *n_min = (int64_t)mins.size();
+  *n_max = (int64_t)maxs.size();
+  int rc = VISFD_HIP_OK;
+  if ((int64_t)mins.size() > min_cap || (int64_t)maxs.size() > max_cap)
+    rc = fail(VISFD_HIP_ECAPACITY, "blob list capacity too small");
+  for (int64_t i = 0; i < (int64_t)mins.size() && i < min_cap; i++) minima[i] = mins[i];
+  for (int64_t i = 0; i < (int64_t)maxs.size() && i < max_cap; i++) maxima[i] = maxs[i];
+  return rc;
+}
+
+int calc_hessian_dev(visfd_hip_ctx* ctx, const float* src, float* grad, float* hess, const float* mask,
+                     i64 nx, i64 ny, i64 nz, float sigma, float ratio) {
+  VH_REQUIRE(ctx && src, "null argument");
+  VH_TRY(check_dims(nx, ny, nz));
+  const int hwv = (int)std::floor(sigma * ratio);  // feature.hpp:1223 (no lower bound of 1 here)
+  VH_REQUIRE(hwv >= 0 && hwv <= MAX_HALFWIDTH, "filter halfwidth must be in [0, 64]");
+  float* S = nullptr;
+  VH_TRY(ws(ctx, WS_D, (size_t)(nx * ny * nz), &S));
+  const float sg[3] = {sigma, sigma, sigma};
+  const int hw[3] = {hwv, hwv, hwv};
+  const SlabInfo whole = {0, nz};
+  VH_TRY(gauss_dev(ctx, src, S, mask, nx, ny, nz, sg, hw, true, whole, nullptr));
+  return dev_hessian(ctx, S, mask, nx, ny, nz, sigma, grad, hess);
+}
+
+}  // namespace
+}  // namespace vh
+
+using namespace vh;
+
+extern "C" {
+
+int visfd_hip_abi_version(void) { return 1; }
+const char* visfd_hip_last_error(void) { return g_last_error.c_str(); }
+
+int visfd_hip_create(int device, void* stream, visfd_hip_ctx** out) {
+  VH_REQUIRE(out, "null output pointer");
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(VISFD_HIP_EDEVICE, "no HIP device available (libvisfd_hip has no CPU fallback)");
+  VH_REQUIRE(device >= 0 && device < count, "bad device ordinal");
+  VH_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  VH_HIP(hipGetDeviceProperties(&prop, device));
+  visfd_hip_ctx* ctx = new visfd_hip_ctx();
+  ctx->device = device;
+  ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (stream) {
+    ctx->stream = (hipStream_t)stream;
+    ctx->own_stream = false;
+  } else {
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      delete ctx;
+      return fail(VISFD_HIP_EDEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    ctx->own_stream = true;
+  }
+  *out = ctx;
+  return VISFD_HIP_OK;
+}
+
+int visfd_hip_trim(visfd_hip_ctx* ctx) {
+  VH_REQUIRE(ctx, "null context");
+  VH_HIP(hipSetDevice(ctx->device));
+  VH_HIP(hipStreamSynchronize(ctx->stream));
+  for (int s = 0; s < WS_NSLOTS; s++) {
+    if (ctx->slot_ptr[s]) VH_HIP(hipFree(ctx->slot_ptr[s]));
+    ctx->slot_ptr[s] = nullptr;
+    ctx->slot_bytes[s] = 0;
+  }
+  return VISFD_HIP_OK;
+}
+
+int visfd_hip_destroy(visfd_hip_ctx* ctx) {
+  if (!ctx) return VISFD_HIP_OK;
+  int rc = visfd_hip_trim(ctx);
+  if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return rc;
+}
+
+int visfd_hip_synchronize(visfd_hip_ctx* ctx) {
+  VH_REQUIRE(ctx, "null context");
+  VH_HIP(hipStreamSynchronize(ctx->stream));
+  return VISFD_HIP_OK;
+}
+
+int64_t visfd_hip_workspace_bytes(visfd_hip_ctx* ctx) {
+  if (!ctx) return 0;
+  int64_t t = 0;
+  for (int s = 0; s < WS_NSLOTS; s++) t += (int64_t)ctx->slot_bytes[s];
+  return t;
+}
+
+// ---- a1 ------------------------------------------------------------------------------------
+int visfd_hip_gauss_taps(float sigma, int halfwidth, float* taps_out) {
+  VH_REQUIRE(taps_out && halfwidth >= 0 && sigma >= 0.0f, "bad tap request");
+  host_gauss_taps(sigma, halfwidth, taps_out);
+  return VISFD_HIP_OK;
+}
+float visfd_hip_ratio_from_threshold(float thr) { return std::sqrt(-2 * std::log(thr)); }
+int visfd_hip_gauss_halfwidths(const float sigma[3], float ratio, int hw[3]) {
+  VH_REQUIRE(sigma && hw, "null argument");
+  return halfwidths_from_ratio(sigma, ratio, hw);
+}
+
+// ---- a4 ------------------------------------------------------------------------------------
+int visfd_hip_separable3d_dev(visfd_hip_ctx* ctx, const float* src, float* dst, const float* mask,
+                              int64_t nx, int64_t ny, int64_t nz, const float* tx, int hx,
+                              const float* ty, int hy, const float* tz, int hz, int normalize,
+                              float* A_out) {
+  VH_REQUIRE(ctx && src && dst && tx && ty && tz, "null argument");
+  VH_HIP(hipSetDevice(ctx->device));
+  const SlabInfo whole = {0, nz};
+  return dev_separable3d(ctx, src, dst, mask, nx, ny, nz, tx, hx, ty, hy, tz, hz, normalize != 0, whole,
+                         A_out);
+}
+
+int visfd_hip_separable3d(visfd_hip_ctx* ctx, const float* src, float* dst, const float* mask,
+                          int64_t nx, int64_t ny, int64_t nz, const float* tx, int hx,
+                          const float* ty, int hy, const float* tz, int hz, int normalize,
+                          float* A_out) {
+  VH_REQUIRE(ctx && src && dst, "null argument");
+  VH_HIP(hipSetDevice(ctx->device));
+  VH_TRY(check_dims(nx, ny, nz));
+  const size_t n = (size_t)(nx * ny * nz);
+  float *ds, *dm, *dd;
+  VH_TRY(upload(ctx, WS_H2D_0, src, n, &ds));
+  VH_TRY(upload(ctx, WS_H2D_1, mask, n, &dm));
+  VH_TRY(ws(ctx, WS_H2D_2, n, &dd));
+  VH_TRY(visfd_hip_separable3d_dev(ctx, ds, dd, dm, nx, ny, nz, tx, hx, ty, hy, tz, hz, normalize, A_out));
+  return download(ctx, dst, dd, n);
+}
+
+// ---- a5 ------------------------------------------------------------------------------------
+int visfd_hip_apply_gauss_dev(visfd_hip_ctx* ctx, const float* src, float* dst, const float* mask,
+                              int64_t nx, int64_t ny, int64_t nz, const float sigma[3],
+                              const int hw[3], int normalize, float* A_out) {
+  VH_REQUIRE(ctx, "null context");
+  VH_HIP(hipSetDevice(ctx->device));
+  const SlabInfo whole = {0, nz};
+  return gauss_dev(ctx, src, dst, mask, nx, ny, nz, sigma, hw, normalize != 0, whole, A_out);
+}
+
+int visfd_hip_apply_gauss_slab_dev(visfd_hip_ctx* ctx, const float* src, float* dst, int64_t nx,
+                                   int64_t ny, int64_t nz_local, int64_t z_lo, int64_t nz_global,
+                                   const float sigma[3], const int hw[3], int normalize, float* A_out) {
+  VH_REQUIRE(ctx, "null context");
+  VH_REQUIRE(z_lo >= 0 && z_lo + nz_local <= nz_global, "slab outside the volume");
+  VH_HIP(hipSetDevice(ctx->device));
+  const SlabInfo slab = {z_lo, nz_global};
+  return gauss_dev(ctx, src, dst, nullptr, nx, ny, nz_local, sigma, hw, normalize != 0, slab, A_out);
+}
+
+int visfd_hip_apply_gauss(visfd_hip_ctx* ctx, const float* src, float* dst, const float* mask,
+                          int64_t nx, int64_t ny, int64_t nz, const float sigma[3], const int hw[3],
+                          int normalize, float* A_out) {
+  VH_REQUIRE(ctx && src && dst, "null argument");
+  VH_HIP(hipSetDevice(ctx->device));
+  VH_TRY(check_dims(nx, ny, nz));
+  const size_t n = (size_t)(nx * ny * nz);
+  float *ds, *dm, *dd;
+  VH_TRY(upload(ctx, WS_H2D_0, src, n, &ds));
+  VH_TRY(upload(ctx, WS_H2D_1, mask, n, &dm));
+  VH_TRY(ws(ctx, WS_H2D_2, n, &dd));
+  VH_TRY(visfd_hip_apply_gauss_dev(ctx, ds, dd, dm, nx, ny, nz, sigma, hw, normalize, A_out));
+  return download(ctx, dst, dd, n);
+}
+
+// ---- a6 ------------------------------------------------------------------------------------
+int visfd_hip_apply_dog_dev(visfd_hip_ctx* ctx, const float* src, float* dst, const float* mask,
+                            int64_t nx, int64_t ny, int64_t nz, const float sa[3], const float sb[3],
+                            const int hw[3], float* A, float* B) {
+  VH_REQUIRE(ctx && src && dst && sa && sb && hw, "null argument");
+  VH_HIP(hipSetDevice(ctx->device));
+  VH_TRY(check_dims(nx, ny, nz));
+  float* tmp = nullptr;
+  VH_TRY(ws(ctx, WS_C, (size_t)(nx * ny * nz), &tmp));
+  return dog_dev(ctx, src, dst, tmp, mask, nx, ny, nz, sa, sb, hw, 1.0f, false, A, B);
+}
+
+int visfd_hip_apply_dog(visfd_hip_ctx* ctx, const float* src, float* dst, const float* mask,
+                        int64_t nx, int64_t ny, int64_t nz, const float sa[3], const float sb[3],
+                        const int hw[3], float* A, float* B) {
+  VH_REQUIRE(ctx && src && dst, "null argument");
+  VH_HIP(hipSetDevice(ctx->device));
+  VH_TRY(check_dims(nx, ny, nz));
+  const size_t n = (size_t)(nx * ny * nz);
+  float *ds, *dm, *dd;
+  VH_TRY(upload(ctx, WS_H2D_0, src, n, &ds));
+  VH_TRY(upload(ctx, WS_H2D_1, mask, n, &dm));
+  VH_TRY(ws(ctx, WS_H2D_2, n, &dd));
+  VH_TRY(visfd_hip_apply_dog_dev(ctx, ds, dd, dm, nx, ny, nz, sa, sb, hw, A, B));
+  return download(ctx, dst, dd, n);
+}
+
+// ---- a7 ------------------------------------------------------------------------------------
+int visfd_hip_apply_log_dev(visfd_hip_ctx* ctx, const float* src, float* dst, const float* mask,
+                            int64_t nx, int64_t ny, int64_t nz, const float sigma[3], float delta,
+                            float ratio, float* A, float* B) {
+  VH_REQUIRE(ctx && src && dst && sigma, "null argument");
+  VH_HIP(hipSetDevice(ctx->device));
+  VH_TRY(check_dims(nx, ny, nz));
+  float* tmp = nullptr;
+  VH_TRY(ws(ctx, WS_C, (size_t)(nx * ny * nz), &tmp));
+  return log_dev(ctx, src, dst, tmp, mask, nx, ny, nz, sigma, delta, ratio, A, B);
+}
+
+int visfd_hip_apply_log(visfd_hip_ctx* ctx, const float* src, float* dst, const float* mask,
+                        int64_t nx, int64_t ny, int64_t nz, const float sigma[3], float delta,
+                        float ratio, float* A, float* B) {
+  VH_REQUIRE(ctx && src && dst, "null argument");
+  VH_HIP(hipSetDevice(ctx->device));
+  VH_TRY(check_dims(nx, ny, nz));
+  const size_t n = (size_t)(nx * ny * nz);
+  float *ds, *dm, *dd;
+  VH_TRY(upload(ctx, WS_H2D_0, src, n, &ds));
+  VH_TRY(upload(ctx, WS_H2D_1, mask, n, &dm));
+  VH_TRY(ws(ctx, WS_H2D_2, n, &dd));
+  VH_TRY(visfd_hip_apply_log_dev(ctx, ds, dd, dm, nx, ny, nz, sigma, delta, ratio, A, B));
+  return download(ctx, dst, dd, n);
+}
+
+// ---- a8 ------------------------------------------------------------------------------------
+int visfd_hip_blob_dog_dev(visfd_hip_ctx* ctx, const float* src, const float* mask, int64_t nx,
+                           int64_t ny, int64_t nz, const float* blob_sigma, int n_sigma,
+                           const float* aspect, float delta, float ratio, float min_thr, float max_thr,
+                           int use_ratios, visfd_hip_blob* minima, int64_t min_cap, int64_t* n_min,
+                           visfd_hip_blob* maxima, int64_t max_cap, int64_t* n_max) {
+  VH_REQUIRE(ctx, "null context");
+  VH_HIP(hipSetDevice(ctx->device));
+  return blob_dog_dev(ctx, src, mask, nx, ny, nz, blob_sigma, n_sigma, aspect, delta, ratio, min_thr,
+                      max_thr, use_ratios != 0, minima, min_cap, n_min, maxima, max_cap, n_max);
+}
+
+int visfd_hip_blob_dog(visfd_hip_ctx* ctx, const float* src, const float* mask, int64_t nx, int64_t ny,
+                       int64_t nz, const float* blob_sigma, int n_sigma, const float* aspect,
+                       float delta, float ratio, float min_thr, float max_thr, int use_ratios,
+                       visfd_hip_blob* minima, int64_t min_cap, int64_t* n_min, visfd_hip_blob* maxima,
+                       int64_t max_cap, int64_t* n_max) {
+  VH_REQUIRE(ctx && src, "null argument");
+  VH_HIP(hipSetDevice(ctx->device));
+  VH_TRY(check_dims(nx, ny, nz));
+  const size_t n = (size_t)(nx * ny * nz);
+  float *ds, *dm;
+  VH_TRY(upload(ctx, WS_H2D_0, src, n, &ds));
+  VH_TRY(upload(ctx, WS_H2D_1, mask, n, &dm));
+  return blob_dog_dev(ctx, ds, dm, nx, ny, nz, blob_sigma, n_sigma, aspect, delta, ratio, min_thr, max_thr,
+                      use_ratios != 0, minima, min_cap, n_min, maxima, max_cap, n_max);
+}
+
+int visfd_hip_blob_diameters_to_sigmas(const float* d, int n, float* s) {
+  VH_REQUIRE(d && s && n >= 0, "bad argument");
+  for (int i = 0; i < n; i++) s[i] = (float)(d[i] / (2.0 * std::sqrt(3.0)));  // feature.hpp:475
+  return VISFD_HIP_OK;
+}
+int visfd_hip_blob_sigmas_to_diameters(const float* s, int n, float* d) {
+  VH_REQUIRE(d && s && n >= 0, "bad argument");
+  for (int i = 0; i < n; i++) d[i] = (float)(s[i] * 2.0 * std::sqrt(3.0));  // feature.hpp:504
+  return VISFD_HIP_OK;
+}
+
+// ---- a9 ------------------------------------------------------------------------------------
+int visfd_hip_calc_hessian_dev(visfd_hip_ctx* ctx, const float* src, float* grad, float* hess,
+                               const float* mask, int64_t nx, int64_t ny, int64_t nz, float sigma,
+                               float ratio) {
+  VH_REQUIRE(ctx, "null context");
+  VH_HIP(hipSetDevice(ctx->device));
+  return calc_hessian_dev(ctx, src, grad, hess, mask, nx, ny, nz, sigma, ratio);
+}
+
+int visfd_hip_calc_hessian(visfd_hip_ctx* ctx, const float* src, float* grad, float* hess,
+                           const float* mask, int64_t nx, int64_t ny, int64_t nz, float sigma,
+                           float ratio) {
+  VH_REQUIRE(ctx && src, "null argument");
+  VH_HIP(hipSetDevice(ctx->device));
+  VH_TRY(check_dims(nx, ny, nz));
+  const size_t n = (size_t)(nx * ny * nz);
+  float *ds, *dm, *dg = nullptr, *dh = nullptr, *aos = nullptr;
+  VH_TRY(upload(ctx, WS_H2D_0, src, n, &ds));
+  VH_TRY(upload(ctx, WS_H2D_1, mask, n, &dm));
+  if (grad) VH_TRY(ws(ctx, WS_H2D_2, 3 * n, &dg));
+  if (hess) VH_TRY(ws(ctx, WS_H2D_3, 6 * n, &dh));
+  VH_TRY(ws(ctx, WS_H2D_4, 6 * n, &aos));
+  VH_TRY(calc_hessian_dev(ctx, ds, dg, dh, dm, nx, ny, nz, sigma, ratio));
+  // interleave on the device; voxels with mask==0 keep the caller's values
+  if (grad) {
+    VH_HIP(hipMemcpyAsync(aos, grad, sizeof(float) * 3 * n, hipMemcpyHostToDevice, ctx->stream));
+    VH_TRY(dev_planar_to_interleaved(ctx, dg, aos, (i64)n, 3, dm));
+    VH_TRY(download(ctx, grad, aos, 3 * n));
+  }
+  if (hess) {
+    VH_HIP(hipMemcpyAsync(aos, hess, sizeof(float) * 6 * n, hipMemcpyHostToDevice, ctx->stream));
+    VH_TRY(dev_planar_to_interleaved(ctx, dh, aos, (i64)n, 6, dm));
+    VH_TRY(download(ctx, hess, aos, 6 * n));
+  }
+  return VISFD_HIP_OK;
+}
+
+// ---- a10 -----------------------------------------------------------------------------------
+int visfd_hip_diagonalize_flat_sym3_dev(visfd_hip_ctx* ctx, const float* m6, float* out6, int64_t n,
+                                        int order) {
+  VH_REQUIRE(ctx && m6 && out6 && n >= 0, "bad argument");
+  VH_REQUIRE(order == 0 || order == 1, "unsupported eigenvalue order");
+  VH_HIP(hipSetDevice(ctx->device));
+  if (n == 0) return VISFD_HIP_OK;
+  return dev_diagonalize(ctx, m6, out6, n, order);
+}
+
+int visfd_hip_diagonalize_flat_sym3(visfd_hip_ctx* ctx, const float* m6, float* out6, int64_t n,
+                                    int order) {
+  VH_REQUIRE(ctx && m6 && out6 && n >= 0, "bad argument");
+  VH_REQUIRE(order == 0 || order == 1, "unsupported eigenvalue order");
+  VH_HIP(hipSetDevice(ctx->device));
+  if (n == 0) return VISFD_HIP_OK;
+  float *aos, *pin, *pout;
+  VH_TRY(upload(ctx, WS_H2D_0, m6, 6 * (size_t)n, &aos));
+  VH_TRY(ws(ctx, WS_H2D_1, 6 * (size_t)n, &pin));
+  VH_TRY(ws(ctx, WS_H2D_2, 6 * (size_t)n, &pout));
+  VH_TRY(dev_interleaved_to_planar(ctx, aos, pin, n, 6));
+  VH_TRY(dev_diagonalize(ctx, pin, pout, n, order));
+  VH_TRY(dev_planar_to_interleaved(ctx, pout, aos, n, 6, nullptr));
+  return download(ctx, out6, aos, 6 * (size_t)n);
+}
+
+// ---- a12 (saliency) --------------------------------------------------------------------------
+int visfd_hip_hessian_saliency_dev(visfd_hip_ctx* ctx, const float* hess, const float* mask, int64_t nvox,
+                                   int order, float* sal, float* dir) {
+  VH_REQUIRE(ctx && hess && sal && dir && nvox > 0, "bad argument");
+  VH_REQUIRE(order == 0 || order == 1, "unsupported eigenvalue order");
+  VH_HIP(hipSetDevice(ctx->device));
+  return dev_hessian_saliency(ctx, hess, mask, nvox, order, sal, dir);
+}
+
+int visfd_hip_hessian_saliency(visfd_hip_ctx* ctx, const float* hess, const float* mask, int64_t nvox,
+                               int order, float* sal, float* dir) {
+  VH_REQUIRE(ctx && hess && sal && dir && nvox > 0, "bad argument");
+  VH_REQUIRE(order == 0 || order == 1, "unsupported eigenvalue order");
+  VH_HIP(hipSetDevice(ctx->device));
+  const size_t n = (size_t)nvox;
+  float *aos, *ph, *dm, *dsal, *pdir;
+  VH_TRY(upload(ctx, WS_H2D_0, hess, 6 * n, &aos));
+  VH_TRY(upload(ctx, WS_H2D_1, mask, n, &dm));
+  VH_TRY(ws(ctx, WS_H2D_2, 6 * n, &ph));
+  VH_TRY(ws(ctx, WS_H2D_3, n, &dsal));
+  VH_TRY(ws(ctx, WS_H2D_4, 3 * n, &pdir));
+  VH_TRY(dev_interleaved_to_planar(ctx, aos, ph, nvox, 6));
+  VH_TRY(dev_hessian_saliency(ctx, ph, dm, nvox, order, dsal, pdir));
+  VH_TRY(download(ctx, sal, dsal, n));
+  // direction: only voxels with mask != 0 are written (handlers.cpp:1650-1651,1738-1740)
+  VH_HIP(hipMemcpyAsync(aos, dir, sizeof(float) * 3 * n, hipMemcpyHostToDevice, ctx->stream));
+  VH_TRY(dev_planar_to_interleaved(ctx, pdir, aos, nvox, 3, dm));
+  return download(ctx, dir, aos, 3 * n);
+}
+
+int visfd_hip_ridge_saliency_dev(visfd_hip_ctx* ctx, const float* src, const float* mask, int64_t nx,
+                                 int64_t ny, int64_t nz, float sigma, float ratio, int order, float* sal,
+                                 float* dir) {
+  VH_REQUIRE(ctx && src && sal && dir, "null argument");
+  VH_REQUIRE(order == 0 || order == 1, "unsupported eigenvalue order");
+  VH_HIP(hipSetDevice(ctx->device));
+  VH_TRY(check_dims(nx, ny, nz));
+  const int hwv = (int)std::floor(sigma * ratio);
+  VH_REQUIRE(hwv >= 0 && hwv <= MAX_HALFWIDTH, "filter halfwidth must be in [0, 64]");
+  float* S = nullptr;
+  VH_TRY(ws(ctx, WS_D, (size_t)(nx * ny * nz), &S));
+  const float sg[3] = {sigma, sigma, sigma};
+  const int hw[3] = {hwv, hwv, hwv};
+  const SlabInfo whole = {0, nz};
+  VH_TRY(gauss_dev(ctx, src, S, mask, nx, ny, nz, sg, hw, true, whole, nullptr));
+  return dev_ridge_saliency_fused(ctx, S, mask, nx, ny, nz, sigma, order, sal, dir);
+}
+
+// ---- a12 (threshold) -------------------------------------------------------------------------
+int visfd_hip_threshold_fraction_dev(visfd_hip_ctx* ctx, float* sal, const float* mask, int64_t nvox,
+                                     float fraction, float* thr_out) {
+  VH_REQUIRE(ctx && sal && nvox > 0, "bad argument");
+  VH_REQUIRE(fraction >= 0.0f && fraction <= 1.0f, "fraction must be in [0,1]");
+  VH_HIP(hipSetDevice(ctx->device));
+  return dev_threshold_fraction(ctx, sal, mask, nvox, fraction, thr_out);
+}
+
+int visfd_hip_threshold_fraction(visfd_hip_ctx* ctx, float* sal, const float* mask, int64_t nvox,
+                                 float fraction, float* thr_out) {
+  VH_REQUIRE(ctx && sal && nvox > 0, "bad argument");
+  VH_REQUIRE(fraction >= 0.0f && fraction <= 1.0f, "fraction must be in [0,1]");
+  VH_HIP(hipSetDevice(ctx->device));
+  float *ds, *dm;
+  VH_TRY(upload(ctx, WS_H2D_0, sal, (size_t)nvox, &ds));
+  VH_TRY(upload(ctx, WS_H2D_1, mask, (size_t)nvox, &dm));
+  VH_TRY(dev_threshold_fraction(ctx, ds, dm, nvox, fraction, thr_out));
+  return download(ctx, sal, ds, (size_t)nvox);
+}
+
+int visfd_hip_select_histogram_dev(visfd_hip_ctx* ctx, const float* sal, const float* mask, int64_t nvox,
+                                   int pass, uint32_t prefix, uint64_t* hist_host, uint64_t* n_unmasked) {
+  VH_REQUIRE(ctx && sal && hist_host && nvox > 0, "bad argument");
+  VH_REQUIRE(pass == 0 || pass == 1, "pass must be 0 or 1");
+  VH_HIP(hipSetDevice(ctx->device));
+  return dev_select_histogram(ctx, sal, mask, nvox, pass, prefix, hist_host, n_unmasked);
+}
+
+int visfd_hip_apply_threshold_dev(visfd_hip_ctx* ctx, float* sal, int64_t nvox, float thr) {
+  VH_REQUIRE(ctx && sal && nvox > 0, "bad argument");
+  VH_HIP(hipSetDevice(ctx->device));
+  return dev_apply_threshold(ctx, sal, nvox, thr);
+}
+
+// ---- a13 + a14 -------------------------------------------------------------------------------
+int visfd_hip_tv_tables(float sigma_tv, float cutoff, int* h_out, float* w, float* rhat) {
+  const int h = host_tv_halfwidth(sigma_tv, cutoff);
+  VH_REQUIRE(h >= 0, "negative window");
+  if (h_out) *h_out = h;
+  if (w) host_tv_tables(sigma_tv, h, w, rhat);
+  return VISFD_HIP_OK;
+}
+
+int visfd_hip_tv_dense_stick_slab_dev(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* ten,
+                                      const float* mask_src, const float* mask_dst, int64_t nx,
+                                      int64_t ny, int64_t nz_local, int64_t z_out0, int64_t z_out1,
+                                      float sigma_tv, int exponent, float cutoff, int curves) {
+  VH_REQUIRE(ctx && sal && dir && ten, "null argument");
+  VH_HIP(hipSetDevice(ctx->device));
+  return dev_tv_dense_stick(ctx, sal, dir, ten, mask_src, mask_dst, nx, ny, nz_local, z_out0, z_out1,
+                            sigma_tv, exponent, cutoff, curves != 0);
+}
+
+int visfd_hip_tv_dense_stick_dev(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* ten,
+                                 const float* mask_src, const float* mask_dst, int64_t nx, int64_t ny,
+                                 int64_t nz, float sigma_tv, int exponent, float cutoff, int curves) {
+  return visfd_hip_tv_dense_stick_slab_dev(ctx, sal, dir, ten, mask_src, mask_dst, nx, ny, nz, 0, nz,
+                                           sigma_tv, exponent, cutoff, curves);
+}
+
+int visfd_hip_tv_dense_stick(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* ten,
+                             const float* mask_src, const float* mask_dst, int64_t nx, int64_t ny,
+                             int64_t nz, float sigma_tv, int exponent, float cutoff, int curves) {
+  VH_REQUIRE(ctx && sal && dir && ten, "null argument");
+  VH_HIP(hipSetDevice(ctx->device));
+  VH_TRY(check_dims(nx, ny, nz));
+  const size_t n = (size_t)(nx * ny * nz);
+  float *dsal, *aos, *pdir, *pten, *dms = nullptr, *dmd = nullptr;
+  VH_TRY(upload(ctx, WS_H2D_0, sal, n, &dsal));
+  VH_TRY(upload(ctx, WS_H2D_1, dir, 3 * n, &aos));
+  VH_TRY(ws(ctx, WS_H2D_2, 3 * n, &pdir));
+  VH_TRY(dev_interleaved_to_planar(ctx, aos, pdir, (i64)n, 3));
+  VH_TRY(ws(ctx, WS_H2D_3, 6 * n, &pten));
+  VH_TRY(upload(ctx, WS_H2D_4, mask_src, n, &dms));
+  if (mask_dst == mask_src) dmd = dms;
+  else VH_TRY(upload(ctx, WS_A, mask_dst, n, &dmd));
+  VH_TRY(dev_tv_dense_stick(ctx, dsal, pdir, pten, dms, dmd, nx, ny, nz, 0, nz, sigma_tv, exponent, cutoff,
+                            curves != 0));
+  // tensors of voxels with mask_dst == 0 keep the caller's values (no storage in the reference)
+  float* aos6 = nullptr;
+  VH_TRY(ws(ctx, WS_B, 6 * n, &aos6));
+  VH_HIP(hipMemcpyAsync(aos6, ten, sizeof(float) * 6 * n, hipMemcpyHostToDevice, ctx->stream));
+  VH_TRY(dev_planar_to_interleaved(ctx, pten, aos6, (i64)n, 6, dmd));
+  return download(ctx, ten, aos6, 6 * n);
+}
+
+// ---- a15 -------------------------------------------------------------------------------------
+int visfd_hip_tensor_saliency_dev(visfd_hip_ctx* ctx, const float* ten, const float* mask, int64_t nvox,
+                                  int order, float* sal) {
+  VH_REQUIRE(ctx && ten && sal && nvox > 0, "bad argument");
+  VH_REQUIRE(order == 0 || order == 1, "unsupported eigenvalue order");
+  VH_HIP(hipSetDevice(ctx->device));
+  return dev_tensor_saliency(ctx, ten, mask, nvox, order, sal);
+}
+
+int visfd_hip_tensor_saliency(visfd_hip_ctx* ctx, const float* ten, const float* mask, int64_t nvox,
+                              int order, float* sal) {
+  VH_REQUIRE(ctx && ten && sal && nvox > 0, "bad argument");
+  VH_REQUIRE(order == 0 || order == 1, "unsupported eigenvalue order");
+  VH_HIP(hipSetDevice(ctx->device));
+  const size_t n = (size_t)nvox;
+  float *aos, *pten, *dm, *dsal;
+  VH_TRY(upload(ctx, WS_H2D_0, ten, 6 * n, &aos));
+  VH_TRY(ws(ctx, WS_H2D_1, 6 * n, &pten));
+  VH_TRY(dev_interleaved_to_planar(ctx, aos, pten, nvox, 6));
+  VH_TRY(upload(ctx, WS_H2D_2, mask, n, &dm));
+  VH_TRY(upload(ctx, WS_H2D_3, sal, n, &dsal));
+  VH_TRY(dev_tensor_saliency(ctx, pten, dm, nvox, order, dsal));
+  return download(ctx, sal, dsal, n);
+}
+
+}  // extern "C"

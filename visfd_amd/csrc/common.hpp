@@ -1,0 +1,147 @@
+// common.hpp -- context, workspace and error plumbing shared by the HIP translation units.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/visfd_hip.h"
+
+namespace vh {
+
+typedef int64_t i64;
+
+// ---- error reporting -------------------------------------------------------------------------
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define VH_HIP(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess)                                                                    \
+      return vh::fail(_e == hipErrorOutOfMemory ? VISFD_HIP_ENOMEM : VISFD_HIP_EDEVICE,      \
+                      std::string(#expr) + ": " + hipGetErrorString(_e));                    \
+  } while (0)
+
+#define VH_TRY(expr)           \
+  do {                         \
+    int _rc = (expr);          \
+    if (_rc != VISFD_HIP_OK) return _rc; \
+  } while (0)
+
+#define VH_REQUIRE(cond, msg) \
+  do {                        \
+    if (!(cond)) return vh::fail(VISFD_HIP_EINVAL, msg); \
+  } while (0)
+
+// ---- workspace: named slots that only grow; freed by visfd_hip_trim/destroy -------------------
+enum Slot {
+  WS_A = 0, WS_B, WS_C, WS_D,      // full-volume float scratch
+  WS_DEN_A, WS_DEN_B,              // masked-normalisation denominators
+  WS_NORM,                         // Dx|Dy|Dz normaliser lines
+  WS_LOG0, WS_LOG1, WS_LOG2,       // rolling LoG volumes of the blob detector
+  WS_CAND, WS_COUNTER,             // candidate list + counters
+  WS_HIST,                         // radix-select histograms
+  WS_TVTAB,                        // tensor-voting lookup table
+  WS_TVAUX,                        // tensor-voting auxiliaries
+  WS_H2D_0, WS_H2D_1, WS_H2D_2, WS_H2D_3, WS_H2D_4,  // staging for the host-pointer face
+  WS_NSLOTS
+};
+
+}  // namespace vh
+
+struct visfd_hip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  void* slot_ptr[vh::WS_NSLOTS] = {};
+  size_t slot_bytes[vh::WS_NSLOTS] = {};
+  int num_cus = 256;
+};
+
+namespace vh {
+
+// returns a device buffer of at least `bytes` bytes in slot `s` (contents undefined)
+int ws_get(visfd_hip_ctx* ctx, Slot s, size_t bytes, void** out);
+template <typename T>
+inline int ws(visfd_hip_ctx* ctx, Slot s, size_t count, T** out) {
+  void* p = nullptr;
+  int rc = ws_get(ctx, s, count * sizeof(T), &p);
+  *out = static_cast<T*>(p);
+  return rc;
+}
+
+inline int check_dims(i64 nx, i64 ny, i64 nz) {
+  if (nx <= 0 || ny <= 0 || nz <= 0) return fail(VISFD_HIP_EINVAL, "image dimensions must be positive");
+  return VISFD_HIP_OK;
+}
+
+// ---- taps carried in the kernel-argument segment (scalar loads, SGPR operands) ---------------
+constexpr int MAX_HALFWIDTH = 64;
+struct Taps {
+  float t[2 * MAX_HALFWIDTH + 1];  // t[j + h], j = -h..h
+  int h;
+};
+
+// host-side arithmetic (taps.cpp)
+void host_gauss_taps(float sigma, int h, float* t);
+void host_conv_ones(i64 n, const float* t, int h, float* out);  // filter applied to a line of ones
+int host_tv_halfwidth(float sigma, float cutoff);
+void host_tv_tables(float sigma, int h, float* w, float* rhat);
+
+// ---- device stages (each in its own .hip; all asynchronous on ctx->stream) -------------------
+struct SlabInfo {   // Z-slab placement for multi-GPU runs; whole volume: z_lo=0, nz_global=nz
+  i64 z_lo;
+  i64 nz_global;
+};
+
+int dev_separable3d(visfd_hip_ctx* ctx, const float* src, float* dst, const float* mask, i64 nx,
+                    i64 ny, i64 nz, const float* tx, int hx, const float* ty, int hy,
+                    const float* tz, int hz, bool normalize, SlabInfo slab, float* A_out);
+// dst = (a - b) * scale  with two roundings (filter3d.hpp:1387-1390,1495-1498); scale==1: no multiply
+int dev_sub_scale(visfd_hip_ctx* ctx, float* a_inout, const float* b, i64 n, float scale, bool do_scale);
+
+int dev_blob_scan(visfd_hip_ctx* ctx, const float* lo, const float* mid, const float* hi,
+                  const float* mask, i64 nx, i64 ny, i64 nz, int scale_index, float sigma,
+                  float min_thr, float max_thr, bool want_min, bool want_max,
+                  std::vector<visfd_hip_blob>* minima, std::vector<visfd_hip_blob>* maxima);
+
+int dev_hessian(visfd_hip_ctx* ctx, const float* smoothed, const float* mask, i64 nx, i64 ny, i64 nz,
+                float sigma, float* grad_planar, float* hess_planar);
+int dev_hessian_saliency(visfd_hip_ctx* ctx, const float* hess_planar, const float* mask, i64 nvox,
+                         int order, float* saliency, float* dir_planar);
+int dev_ridge_saliency_fused(visfd_hip_ctx* ctx, const float* smoothed, const float* mask, i64 nx,
+                             i64 ny, i64 nz, float sigma, int order, float* saliency,
+                             float* dir_planar);
+int dev_diagonalize(visfd_hip_ctx* ctx, const float* m6_planar, float* out6_planar, i64 n, int order);
+int dev_tensor_saliency(visfd_hip_ctx* ctx, const float* tensor_planar, const float* mask, i64 nvox,
+                        int order, float* saliency);
+
+int dev_select_histogram(visfd_hip_ctx* ctx, const float* sal, const float* mask, i64 nvox, int pass,
+                         uint32_t prefix, uint64_t* hist_host, uint64_t* n_unmasked_host);
+int dev_apply_threshold(visfd_hip_ctx* ctx, float* sal, i64 nvox, float thr);
+int dev_threshold_fraction(visfd_hip_ctx* ctx, float* sal, const float* mask, i64 nvox, float fraction,
+                           float* thr_out);
+
+int dev_tv_dense_stick(visfd_hip_ctx* ctx, const float* sal, const float* dir_planar,
+                       float* tensor_planar, const float* mask_src, const float* mask_dst, i64 nx,
+                       i64 ny, i64 nz, i64 z_out0, i64 z_out1, float sigma_tv, int exponent,
+                       float cutoff, bool curves);
+
+// layout helpers for the host-pointer face
+int dev_interleaved_to_planar(visfd_hip_ctx* ctx, const float* aos, float* planar, i64 n, int channels);
+int dev_planar_to_interleaved(visfd_hip_ctx* ctx, const float* planar, float* aos, i64 n, int channels,
+                              const float* mask /*nullable: only where mask!=0*/);
+
+inline unsigned grid_for(i64 n, int block, i64 cap = (i64)1 << 30) {
+  i64 g = (n + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace vh

@@ -1,0 +1,167 @@
+// tv.hip -- dense stick tensor voting (reference lib/visfd/feature.hpp:1914-2037, :2217-2384).
+//
+// Receiver-centric gather, one thread per receiver voxel, so that each receiver accumulates its
+// votes in exactly the reference's order (jz, jy, jx ascending over the window, sender = r - j):
+//   u   = (rhat_x*n_x + rhat_y*n_y) + rhat_z*n_z          rhat = unit vector sender -> receiver
+//   ang = 1 - u*u  (surfaces)   |   u*u (curves)
+//   dec = ang (exponent 2) | ang*ang (exponent 4) | pow(ang, exponent/2) otherwise
+//   m   = 2u*rhat - n  (surfaces)  |  n - 2u*rhat (curves)
+//   T_ab += (((sal * (w*mask_src)) * dec) * m_a) * m_b      for a <= b
+// all in float with separate multiplies and adds (-ffp-contract=off).
+//
+// Device layout: direction is 3 planes, tensor is 6 planes (xx,yy,zz,xy,yz,xz), each nvox floats.
+#include <vector>
+
+#include "common.hpp"
+
+namespace vh {
+
+namespace {
+
+constexpr int BLOCK = 256;
+
+struct TvParams {
+  int nx, ny, nz;        // local array extent
+  int z_out0, z_out1;    // receiver planes [z_out0, z_out1)
+  int h;
+  int exponent;
+  int curves;
+};
+
+__device__ __forceinline__ float decay_of(float ang, int exponent) {
+  if (exponent == 2) return ang;
+  if (exponent == 4) return ang * ang;
+  return (float)pow((double)ang, 0.5 * (double)exponent);
+}
+
+// One vote, accumulated into T[6] (xx,yy,zz,xy,yz,xz).
+__device__ __forceinline__ void add_vote(float T[6], float sal, float fv, float r0, float r1, float r2,
+                                         float n0, float n1, float n2, int exponent, int curves) {
+  const float u = (r0 * n0 + r1 * n1) + r2 * n2;
+  const float ux2 = u * 2.0f;
+  const float u2 = u * u;
+  const float c2 = 1.0f - u2;
+  const float ang = curves ? u2 : c2;
+  const float dec = decay_of(ang, exponent);
+  float m0, m1, m2;
+  if (curves) {
+    m0 = n0 - ux2 * r0; m1 = n1 - ux2 * r1; m2 = n2 - ux2 * r2;
+  } else {
+    m0 = ux2 * r0 - n0; m1 = ux2 * r1 - n1; m2 = ux2 * r2 - n2;
+  }
+  const float base = (sal * fv) * dec;
+  const float b0 = base * m0, b1 = base * m1, b2 = base * m2;
+  T[0] = T[0] + b0 * m0;
+  T[3] = T[3] + b0 * m1;
+  T[5] = T[5] + b0 * m2;
+  T[1] = T[1] + b1 * m1;
+  T[4] = T[4] + b1 * m2;
+  T[2] = T[2] + b2 * m2;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Baseline kernel: every thread walks the whole window.  Lanes of a wave are consecutive x, so
+// the tap (jz,jy,jx) -- and with it w and rhat -- is wave-uniform; zero-weight taps are skipped
+// for the whole wave.  Used for windows whose lookup table does not fit the tiled kernel and as
+// an in-library cross-check (tests compare both against the CPU oracle).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK)
+tv_dense_kernel(const float* __restrict__ sal, const float* __restrict__ dir,
+                float* __restrict__ ten, const float* __restrict__ mask_src,
+                const float* __restrict__ mask_dst, const float4* __restrict__ table /* w,rx,ry,rz */,
+                TvParams p) {
+  const int xblocks = (p.nx + BLOCK - 1) / BLOCK;
+  unsigned b = blockIdx.x;
+  const int bx = b % xblocks;
+  b /= xblocks;
+  const int iy = b % p.ny;
+  const int iz = p.z_out0 + (int)(b / p.ny);
+  const int ix = bx * BLOCK + (int)threadIdx.x;
+  if (ix >= p.nx) return;
+  const i64 plane = (i64)p.nx * p.ny;
+  const i64 nvox = plane * p.nz;
+  const i64 c = (i64)iz * plane + (i64)iy * p.nx + ix;
+  if (mask_dst && mask_dst[c] == 0.0f) return;
+  float T[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  const int h = p.h, n = 2 * h + 1;
+  for (int jz = -h; jz <= h; jz++) {
+    const int sz = iz - jz;
+    if (sz < 0 || sz >= p.nz) continue;
+    for (int jy = -h; jy <= h; jy++) {
+      const int sy = iy - jy;
+      if (sy < 0 || sy >= p.ny) continue;
+      const i64 row = (i64)sz * plane + (i64)sy * p.nx;
+      const float4* trow = table + ((i64)(jz + h) * n + (jy + h)) * n + h;
+      for (int jx = -h; jx <= h; jx++) {
+        const float4 t = trow[jx];
+        if (t.x == 0.0f) continue;  // wave-uniform
+        const int sx = ix - jx;
+        if (sx < 0 || sx >= p.nx) continue;
+        const i64 s = row + sx;
+        float fv = t.x;
+        if (mask_src) {
+          const float mv = mask_src[s];
+          if (mv == 0.0f) continue;
+          fv = fv * mv;
+        }
+        const float sv = sal[s];
+        if (sv == 0.0f) continue;
+        if (fv == 0.0f) continue;
+        add_vote(T, sv, fv, t.y, t.z, t.w, dir[s], dir[nvox + s], dir[2 * nvox + s], p.exponent,
+                 p.curves);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 6; k++) ten[k * nvox + c] = T[k];
+}
+
+}  // namespace
+
+// declared in tv_tiled.hip
+int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* ten,
+                 const float* mask_src, const float* mask_dst, i64 nx, i64 ny, i64 nz, i64 z_out0,
+                 i64 z_out1, int h, const float* w, const float* rhat, int exponent, bool curves,
+                 bool* handled);
+
+int dev_tv_dense_stick(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* ten,
+                       const float* mask_src, const float* mask_dst, i64 nx, i64 ny, i64 nz,
+                       i64 z_out0, i64 z_out1, float sigma_tv, int exponent, float cutoff, bool curves) {
+  VH_TRY(check_dims(nx, ny, nz));
+  if (nx >= (1LL << 31) || ny >= (1LL << 31) || nz >= (1LL << 31))
+    return fail(VISFD_HIP_EINVAL, "dimension too large");
+  VH_REQUIRE(z_out0 >= 0 && z_out1 <= nz && z_out0 <= z_out1, "bad receiver plane range");
+  if (z_out0 == z_out1) return VISFD_HIP_OK;
+  const int h = host_tv_halfwidth(sigma_tv, cutoff);
+  VH_REQUIRE(h >= 0 && h <= 255, "tensor-voting window halfwidth out of range");
+  const int n = 2 * h + 1;
+  const size_t m = (size_t)n * n * n;
+  std::vector<float> w(m), rh(3 * m);
+  host_tv_tables(sigma_tv, h, w.data(), rh.data());
+
+  bool handled = false;
+  const char* force_dense = getenv("VISFD_HIP_TV_DENSE");
+  if (!(force_dense && force_dense[0] == '1'))
+    VH_TRY(dev_tv_tiled(ctx, sal, dir, ten, mask_src, mask_dst, nx, ny, nz, z_out0, z_out1, h, w.data(),
+                        rh.data(), exponent, curves, &handled));
+  if (handled) return VISFD_HIP_OK;
+
+  std::vector<float4> tab(m);
+  for (size_t k = 0; k < m; k++) tab[k] = make_float4(w[k], rh[3 * k], rh[3 * k + 1], rh[3 * k + 2]);
+  float4* dtab = nullptr;
+  VH_TRY(ws(ctx, WS_TVTAB, m, &dtab));
+  hipStream_t st = ctx->stream;
+  VH_HIP(hipMemcpyAsync(dtab, tab.data(), sizeof(float4) * m, hipMemcpyHostToDevice, st));
+  VH_HIP(hipStreamSynchronize(st));
+  TvParams p;
+  p.nx = (int)nx; p.ny = (int)ny; p.nz = (int)nz;
+  p.z_out0 = (int)z_out0; p.z_out1 = (int)z_out1;
+  p.h = h; p.exponent = exponent; p.curves = curves ? 1 : 0;
+  const i64 nb = ((nx + BLOCK - 1) / BLOCK) * ny * (z_out1 - z_out0);
+  if (nb > 0x7fffffffLL) return fail(VISFD_HIP_EINVAL, "volume too large for one launch");
+  tv_dense_kernel<<<dim3((unsigned)nb), dim3(BLOCK), 0, st>>>(sal, dir, ten, mask_src, mask_dst, dtab, p);
+  VH_HIP(hipGetLastError());
+  return VISFD_HIP_OK;
+}
+
+}  // namespace vh
