@@ -185,12 +185,16 @@ int visfd_hip_threshold_fraction(visfd_hip_ctx*, float* saliency, const float* m
                                  float fraction, float* threshold_out);
 int visfd_hip_threshold_fraction_dev(visfd_hip_ctx*, float* saliency, const float* mask,
                                      int64_t nvox, float fraction, float* threshold_out);
-/* building blocks for the multi-GPU (Z-slab) form: per-rank 2^16-bin histogram of the order-
- * preserving key's digit `pass` (0 = most significant 16 bits, 1 = least) restricted to keys whose
- * higher digits equal `prefix`; counts are summed across ranks by the caller. */
+/* building blocks for the multi-GPU (Z-slab) form of the same select: the order-preserving 32-bit
+ * key of the float is split into three digits (round 0: bits 31..21, round 1: bits 20..10, round 2:
+ * bits 9..0); each call returns this rank's 2048-bin histogram of digit `round` over unmasked
+ * voxels whose higher digits equal `prefix` (right-aligned; 0 for round 0).  The caller sums the
+ * histograms across ranks, walks them from the top to find the digit of the k-th largest key, and
+ * finally applies the threshold with visfd_hip_apply_threshold_dev.
+ * visfd_amd/slab.py holds the host logic. */
 int visfd_hip_select_histogram_dev(visfd_hip_ctx*, const float* saliency, const float* mask,
-                                   int64_t nvox, int pass, uint32_t prefix,
-                                   uint64_t* hist_host /* 65536 */, uint64_t* n_unmasked_host);
+                                   int64_t nvox, int round, uint32_t prefix,
+                                   uint64_t* hist_host /* 2048 */, uint64_t* n_unmasked_host);
 int visfd_hip_apply_threshold_dev(visfd_hip_ctx*, float* saliency, int64_t nvox, float threshold);
 
 /* ---- a13+a14: TV3D::TVDenseStick, lib/visfd/feature.hpp:1645-1675,1711-2037,2217-2384 ------------ */

@@ -165,13 +165,13 @@ def test_blob_seeded(ctx, oracle):
             assert_bits_equal(volgen.sort_blobs(b, False), g["%s_%s_max" % (tag, mode)], tag + mode + " max")
 
 
-def test_blob_noise_many_candidates(ctx, oracle):
-    """Pure noise produces hundreds of extrema per scale: a stress test of index parity."""
-    src = volgen.noise_volume((40, 44, 48), seed=31)
-    sig = np.array([1.2, 1.5, 1.9, 2.4, 3.0], np.float32)
+def test_blob_many_candidates(ctx, oracle):
+    """Sixty overlapping blobs in noise: dozens of extrema, a stress test of index parity."""
+    src = volgen.blob_volume((40, 44, 48), seed=31, nblobs=60)
+    sig = np.array([1.2, 1.5, 1.9, 2.4, 3.0, 3.7], np.float32)
     a = ctx.blob_dog(src, sig, None, None, 0.02, 2.5)
     b = oracle.blob_dog(src, sig, None, None, 0.02, 2.5)
-    assert len(b[0]) > 50 and len(b[1]) > 50
+    assert len(b[0]) > 30 and len(b[1]) > 30
     assert_bits_equal(volgen.sort_blobs(a[0], True), volgen.sort_blobs(b[0], True), "noise minima")
     assert_bits_equal(volgen.sort_blobs(a[1], False), volgen.sort_blobs(b[1], False), "noise maxima")
 
@@ -272,3 +272,47 @@ def test_membrane_reference_fixture_end_to_end(ctx, oracle):
     s2 = sal.copy()
     ctx.tensor_saliency(ten, po.ORDER_DECREASING, s2)
     assert_close_rel(s2, g["tvsal_dec"], 1e-4 if diff.any() else 1e-5, "post-TV saliency")
+
+
+def _sparse_field(shape, seed, fraction=0.06):
+    """Random saliency (a fraction non-zero, clustered on a plane) + random unit directions."""
+    rng = np.random.default_rng(seed)
+    sal = np.zeros(shape, np.float32)
+    pick = rng.random(shape) < fraction
+    zz = np.arange(shape[0])[:, None, None] + 0 * np.arange(shape[1])[None, :, None]
+    pick |= (np.abs(zz - shape[0] // 2) <= 1) & (rng.random(shape) < 0.5)
+    sal[pick] = rng.uniform(1.0, 1e6, int(pick.sum())).astype(np.float32)
+    d = rng.standard_normal(shape + (3,)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True).astype(np.float32)
+    return sal, np.ascontiguousarray(d, np.float32)
+
+
+@pytest.mark.parametrize("sigma_tv,shape", [(8.66, (20, 37, 45)), (11.0, (12, 40, 50)), (1.0, (9, 20, 33))])
+def test_tensor_voting_wide_windows(ctx, oracle, sigma_tv, shape, monkeypatch):
+    """BASELINE config 4's window (sigma_tv = 8.66 -> h = 12) and a window whose sender region is
+    split into two bands (h = 15), on ragged tiles, tiled kernel and baseline kernel."""
+    sal, dirs = _sparse_field(shape, seed=int(sigma_tv * 10))
+    mask = volgen.block_mask(shape, seed=3)
+    ref = oracle.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5)
+    ref_m = oracle.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5, mask, mask)
+    assert np.abs(ref).max() > 0
+    for dense in ("0", "1"):
+        if dense == "1" and sigma_tv > 9:
+            continue
+        monkeypatch.setenv("VISFD_HIP_TV_DENSE", dense)
+        ten = ctx.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5)
+        assert_bits_equal(ten, ref, "tensor sigma_tv=%g dense=%s" % (sigma_tv, dense))
+        ten = ctx.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5, mask, mask)
+        assert_bits_equal(ten, ref_m, "masked tensor sigma_tv=%g dense=%s" % (sigma_tv, dense))
+
+
+def test_tensor_voting_dense_saliency(ctx, oracle):
+    """Every voxel salient: the per-band list overflows one 64-entry chunk many times over."""
+    shape = (7, 24, 28)
+    rng = np.random.default_rng(12)
+    sal = rng.uniform(0.5, 2.0, shape).astype(np.float32)
+    d = rng.standard_normal(shape + (3,)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True).astype(np.float32)
+    d = np.ascontiguousarray(d, np.float32)
+    ten = ctx.tv_dense_stick(sal, d, 3.0, 2, 2.0 ** 0.5)
+    assert_bits_equal(ten, oracle.tv_dense_stick(sal, d, 3.0, 2, 2.0 ** 0.5), "dense-saliency tensor")

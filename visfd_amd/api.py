@@ -371,7 +371,7 @@ class Context:
         return thr.value
 
     def select_histogram_dev(self, sal, pass_, prefix, mask=None):
-        hist = np.zeros(65536, np.uint64)
+        hist = np.zeros(2048, np.uint64)
         n = C.c_uint64()
         self._chk(self._L.visfd_hip_select_histogram_dev(self._h, _dev(sal), _dev(mask), sal.numel(), int(pass_),
                                                          int(prefix), hist.ctypes.data_as(C.POINTER(C.c_uint64)),

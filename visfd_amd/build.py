@@ -18,8 +18,11 @@ CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(ROOT, "build", "visfd_hip")
 LIB = os.path.join(HERE, "libvisfd_hip.so")
 
-SOURCES = ["host_math.cpp", "api.hip", "gauss.hip", "gauss_fused.hip", "blob.hip", "ridge.hip", "select.hip",
-           "tv.hip", "tv_tiled.hip"]
+SOURCES = ["host_math.cpp", "api.hip", "gauss.hip", "blob.hip", "ridge.hip", "select.hip", "tv.hip", "tv_tiled.hip"]
+# (source, object stem, extra flags): the fused Gaussian is compiled once per window half-width
+VARIANTS = [("gauss_fused.hip", "gauss_fused_h%d" % h, ["-DVH_FUSED_H=%d" % h]) for h in range(1, 11)]
+if os.environ.get("VISFD_FUSED_EXTRA_CFGS"):
+    VARIANTS = [(s, o, f + ["-DVH_FUSED_EXTRA_CFGS"]) for s, o, f in VARIANTS]
 HEADERS = ["common.hpp", "eigen3.hpp", os.path.join("..", "..", "include", "visfd_hip.h")]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -31,9 +34,9 @@ def _mtime(p):
     return os.path.getmtime(p) if os.path.exists(p) else 0.0
 
 
-def _compile(src, obj):
+def _compile(src, obj, extra=()):
     t0 = time.time()
-    cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = [HIPCC] + FLAGS + list(extra) + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     return src, r.returncode, r.stdout + r.stderr, time.time() - t0
 
@@ -42,21 +45,28 @@ def build(force=False, jobs=4, verbose=True):
     os.makedirs(OBJDIR, exist_ok=True)
     newest_header = max(_mtime(os.path.join(CSRC, h)) for h in HEADERS)
     todo, objs = [], []
-    for s in SOURCES:
-        obj = os.path.join(OBJDIR, os.path.splitext(s)[0] + ".o")
+    units = [(s, os.path.splitext(s)[0], []) for s in SOURCES] + VARIANTS
+    flagfile = os.path.join(OBJDIR, "flags.txt")
+    flagsig = repr((FLAGS, VARIANTS))
+    if not os.path.exists(flagfile) or open(flagfile).read() != flagsig:
+        force = True
+    for s, stem, extra in units:
+        obj = os.path.join(OBJDIR, stem + ".o")
         objs.append(obj)
         if force or _mtime(obj) < max(_mtime(os.path.join(CSRC, s)), newest_header):
-            todo.append((s, obj))
+            todo.append((s, obj, extra))
     if todo:
         with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:
-            for src, rc, out, dt in ex.map(lambda a: _compile(*a), todo):
+            for (src, rc, out, dt), (_, obj, _e) in zip(ex.map(lambda a: _compile(*a), todo), todo):
                 if verbose:
-                    print("[visfd_amd.build] %-18s %5.1fs %s" % (src, dt, "ok" if rc == 0 else "FAILED"))
+                    print("[visfd_amd.build] %-22s %5.1fs %s" % (os.path.basename(obj), dt, "ok" if rc == 0 else "FAILED"))
                 if rc != 0:
                     sys.stderr.write(out)
                     raise RuntimeError("hipcc failed on " + src)
                 elif out.strip() and verbose:
                     sys.stderr.write(out)
+    with open(flagfile, "w") as f:
+        f.write(flagsig)
     if todo or not os.path.exists(LIB) or _mtime(LIB) < max(_mtime(o) for o in objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -562,7 +562,7 @@ int visfd_hip_threshold_fraction(visfd_hip_ctx* ctx, float* sal, const float* ma
 int visfd_hip_select_histogram_dev(visfd_hip_ctx* ctx, const float* sal, const float* mask, int64_t nvox,
                                    int pass, uint32_t prefix, uint64_t* hist_host, uint64_t* n_unmasked) {
   VH_REQUIRE(ctx && sal && hist_host && nvox > 0, "bad argument");
-  VH_REQUIRE(pass == 0 || pass == 1, "pass must be 0 or 1");
+  VH_REQUIRE(pass >= 0 && pass <= 2, "round must be 0, 1 or 2");
   VH_HIP(hipSetDevice(ctx->device));
   return dev_select_histogram(ctx, sal, mask, nvox, pass, prefix, hist_host, n_unmasked);
 }

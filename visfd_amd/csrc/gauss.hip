@@ -10,6 +10,8 @@
 // The reference's "sparse input" shortcut (filter1d.hpp:59-94) writes exactly 0 when every
 // source sample under the window is zero; the plain sum gives the same +0.0 for finite data, so
 // only the masked Z pass (where the shortcut is keyed on the mask, not the data) restates it.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace vh {
@@ -102,10 +104,40 @@ int fill_taps(Taps* T, const float* t, int h) {
 
 }  // namespace
 
-// declared in gauss_fused.hip
-int dev_gauss_fused(visfd_hip_ctx* ctx, const float* src, float* dst, i64 nx, i64 ny, i64 nz,
-                    const Taps& tx, const Taps& ty, const Taps& tz, const float* Dx, const float* Dy,
-                    const float* Dz, i64 dz_offset, bool normalize, bool* handled);
+// One translation unit per window half-width (gauss_fused.hip compiled with -DVH_FUSED_H=h).
+#define VH_DECL_FUSED(HH)                                                                          \
+  int launch_gauss_fused_h##HH(visfd_hip_ctx* ctx, const float* src, float* dst, i64 nx, i64 ny,   \
+                               i64 nz, const Taps& tx, const Taps& ty, const Taps& tz,            \
+                               const float* Dx, const float* Dy, const float* Dz, i64 dz_offset,  \
+                               bool normalize, int cfg);
+VH_DECL_FUSED(1) VH_DECL_FUSED(2) VH_DECL_FUSED(3) VH_DECL_FUSED(4) VH_DECL_FUSED(5)
+VH_DECL_FUSED(6) VH_DECL_FUSED(7) VH_DECL_FUSED(8) VH_DECL_FUSED(9) VH_DECL_FUSED(10)
+#undef VH_DECL_FUSED
+
+// The single-sweep kernel covers the unmasked case with equal half-widths 1..10 on the three axes
+// (any sigma per axis), even nx, and planes below 2 GiB; everything else takes the 3-pass path.
+static int dev_gauss_fused(visfd_hip_ctx* ctx, const float* src, float* dst, i64 nx, i64 ny, i64 nz,
+                           const Taps& tx, const Taps& ty, const Taps& tz, const float* Dx,
+                           const float* Dy, const float* Dz, i64 dz_offset, bool normalize,
+                           bool* handled) {
+  *handled = false;
+  const int H = tx.h;
+  if (ty.h != H || tz.h != H || H < 1 || H > 10) return VISFD_HIP_OK;
+  if ((nx & 1) || nx * ny >= (1LL << 29) || nz >= (1LL << 31)) return VISFD_HIP_OK;
+  if (src == dst) return VISFD_HIP_OK;  // in place: 3-pass path through scratch volumes
+  const char* force = getenv("VISFD_HIP_GAUSS_3PASS");
+  if (force && force[0] == '1') return VISFD_HIP_OK;
+  int cfg = 0;
+  if (const char* e = getenv("VISFD_HIP_GAUSS_CFG")) cfg = atoi(e);
+  *handled = true;
+  switch (H) {
+#define VH_CASE(HH) case HH: return launch_gauss_fused_h##HH(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, cfg);
+    VH_CASE(1) VH_CASE(2) VH_CASE(3) VH_CASE(4) VH_CASE(5) VH_CASE(6) VH_CASE(7) VH_CASE(8) VH_CASE(9) VH_CASE(10)
+#undef VH_CASE
+  }
+  *handled = false;
+  return VISFD_HIP_OK;
+}
 
 int dev_separable3d(visfd_hip_ctx* ctx, const float* src, float* dst, const float* mask, i64 nx,
                     i64 ny, i64 nz, const float* tx, int hx, const float* ty, int hy,

@@ -11,17 +11,30 @@
 //   * an output tile of TX x TY voxels in the XY plane, marched along Z over a chunk of planes;
 //   * Z pass: each thread owns NC columns of the (TX+2H) x (TY+2H) haloed tile and keeps the last
 //     2H+1 source planes of each column in a REGISTER RING (the march is unrolled 2H+1 times so the
-//     ring is statically indexed); one new plane is fetched per step, x-contiguous across lanes;
+//     ring is statically indexed).  Right after the Z pass the plane needed by the NEXT step is
+//     requested into the slot that just became free, so its HBM latency is covered by the Y and X
+//     passes.  Loads are buffer loads with hardware range checking: columns outside the image use
+//     an out-of-range offset and planes outside the image a zero-length descriptor, both of which
+//     return 0.0f -- no branches, no exec masking;
 //   * the Z-filtered haloed plane goes to LDS; Y pass: two adjacent x per lane (ds_read_b64 down a
 //     column), result rows to LDS; X pass: two adjacent outputs per lane from one ds_read_b64
-//     window, normalise, float2 store (x-contiguous across lanes).
-// Zero extension: samples outside the image are fed as 0.0f, which adds an exact +0.0 to the
-// accumulator (the reference skips those terms, filter1d.hpp:98-99; same bits for finite data).
+//     window, normalise, 8-byte buffer store (x-contiguous across lanes, dropped by the range
+//     check outside the image).
+// Zero extension: a 0.0f sample adds an exact +0.0 to the accumulator, which equals skipping the
+// term as the reference does (filter1d.hpp:98-99) for finite data.
+//
+// This file is compiled once per window half-width (-DVH_FUSED_H=h, see visfd_amd/build.py).
 #include "common.hpp"
+
+#ifndef VH_FUSED_H
+#error "compile with -DVH_FUSED_H=<halfwidth>"
+#endif
 
 namespace vh {
 
 namespace {
+
+constexpr unsigned OOB = 0x7ffffff0u;  // byte offset beyond any descriptor: loads give 0, stores vanish
 
 template <int H, int TX, int TY, int NT>
 struct FusedCfg {
@@ -30,12 +43,13 @@ struct FusedCfg {
   static constexpr int HY = TY + 2 * H;
   static constexpr int NCOL = HX * HY;
   static constexpr int NC = (NCOL + NT - 1) / NT;  // ring columns per thread
-  static constexpr int SX = HX + 2;                // LDS row stride in floats (even, 8-byte rows)
+  static constexpr int SX = HX + 2;                // LDS row stride in floats (even)
   static constexpr int YTASKS = (HX / 2) * TY;     // (x pair, y) outputs of the Y pass
   static constexpr int YROUNDS = (YTASKS + NT - 1) / NT;
   static constexpr int XTASKS = (TX / 2) * TY;
   static constexpr int XROUNDS = (XTASKS + NT - 1) / NT;
-  static constexpr size_t LDS_BYTES = sizeof(float) * (size_t)SX * (HY + TY);
+  static constexpr int SZ_FLOATS = HY * SX + 64;   // + a dump area for padding ring slots
+  static constexpr int SY_FLOATS = TY * SX;
 };
 
 template <int H>
@@ -43,16 +57,22 @@ struct TapsH {
   float t[2 * H + 1];
 };
 
-template <int H, int TX, int TY, int NT, bool NORMALIZE>
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)byte_off, 0, 0));
+}
+
+template <int H, int TX, int TY, int NT, bool NORMALIZE, bool ISO>
 __global__ void __launch_bounds__(NT)
-gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH<H> tz, TapsH<H> ty,
-                   TapsH<H> tx, const float* __restrict__ Dx, const float* __restrict__ Dy,
+gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH<H> tz, TapsH<H> ty_,
+                   TapsH<H> tx_, const float* __restrict__ Dx, const float* __restrict__ Dy,
                    const float* __restrict__ Dz, i64 dz_offset, int nx, int ny, int nz, int zchunk,
-                   int tiles_x, int tiles_y, int nchunks) {
+                   int tiles_x, int tiles_y) {
   typedef FusedCfg<H, TX, TY, NT> C;
   constexpr int W = C::W;
-  __shared__ __attribute__((aligned(16))) float sZ[C::HY * C::SX];
-  __shared__ __attribute__((aligned(16))) float sY[TY * C::SX];
+  __shared__ __attribute__((aligned(16))) float sZ[C::SZ_FLOATS];
+  __shared__ __attribute__((aligned(16))) float sY[C::SY_FLOATS];
+  const TapsH<H>& ty = ISO ? tz : ty_;
+  const TapsH<H>& tx = ISO ? tz : tx_;
 
   // XCD-aware block order: consecutive logical tiles (neighbours in x, then y) share an XCD/L2.
   const unsigned nblk = gridDim.x;
@@ -69,11 +89,12 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
   const int ze = min(zs + zchunk, nz);
   const int tid = threadIdx.x;
   const i64 plane = (i64)nx * ny;
+  const int plane_bytes = (int)(plane * 4);
 
-  // ---- ring columns owned by this thread ---------------------------------------------------
+  // ---- per-thread constants -------------------------------------------------------------------
   float ring[C::NC][W];
-  i64 col_off[C::NC];   // offset of the column inside a plane, or -1 when outside the image
-  int lds_off[C::NC];   // where its Z-filtered value goes in sZ, or -1 for padding slots
+  unsigned col_off[C::NC];  // byte offset of the column inside a plane (OOB outside the image)
+  int lds_off[C::NC];       // where its Z-filtered value goes in sZ (dump area for padding slots)
 #pragma unroll
   for (int c = 0; c < C::NC; c++) {
     const int id = tid + c * NT;
@@ -81,59 +102,80 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
     const int gx = x0 - H + cx, gy = y0 - H + cy;
     const bool slot = id < C::NCOL;
     const bool inside = slot && gx >= 0 && gx < nx && gy >= 0 && gy < ny;
-    col_off[c] = inside ? ((i64)gy * nx + gx) : -1;
-    lds_off[c] = slot ? (cy * C::SX + cx) : -1;
+    col_off[c] = inside ? (unsigned)(gy * nx + gx) * 4u : OOB;
+    lds_off[c] = slot ? (cy * C::SX + cx) : (C::HY * C::SX + (tid & 63));
   }
-  // preload planes zs-H .. zs+H-1 into ring slots 1..W-1 (slot k holds plane zs-H+k-1 ... see below)
+  int y_off[C::YROUNDS];    // LDS float offset of (row y, column pair xp); -1: idle lane
 #pragma unroll
-  for (int k = 0; k < W - 1; k++) {
-    const int z = zs - H + k;
+  for (int r = 0; r < C::YROUNDS; r++) {
+    const int task = tid + r * NT;
+    const int y = task / (C::HX / 2), xp = task - y * (C::HX / 2);
+    y_off[r] = (task < C::YTASKS) ? (y * C::SX + 2 * xp) : -1;
+  }
+  int x_off[C::XROUNDS];
+  unsigned o_off[C::XROUNDS];  // byte offset of the output pair inside a plane (OOB outside)
+  float dxy0[C::XROUNDS], dxy1[C::XROUNDS];
+#pragma unroll
+  for (int r = 0; r < C::XROUNDS; r++) {
+    const int task = tid + r * NT;
+    const int y = task / (TX / 2), xp = task - y * (TX / 2);
+    const int gx = x0 + 2 * xp, gy = y0 + y;
+    const bool ok = (task < C::XTASKS) && gx < nx && gy < ny;  // nx is even: gx+1 < nx too
+    x_off[r] = (task < C::XTASKS) ? (y * C::SX + 2 * xp) : 0;
+    o_off[r] = ok ? (unsigned)(gy * nx + gx) * 4u : OOB;
+    if (NORMALIZE) {
+      const float dy = ok ? Dy[gy] : 1.0f;
+      dxy0[r] = (ok ? Dx[gx] : 1.0f) * dy;       // (Dx*Dy) first, then *Dz (filter3d.hpp:1016-1018)
+      dxy1[r] = (ok ? Dx[gx + 1] : 1.0f) * dy;
+    }
+  }
+
+  // preload planes zs-H .. zs+H into ring slots 1..W-1, 0 (slot (1+m)%W holds plane zs-H+m)
+#pragma unroll
+  for (int m = 0; m < W; m++) {
+    const int z = zs - H + m;
     const bool zin = (z >= 0) && (z < nz);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(src + (zin ? (i64)z * plane : 0)), 0, zin ? plane_bytes : 0, 0x00020000);
 #pragma unroll
-    for (int c = 0; c < C::NC; c++)
-      ring[c][k + 1] = (zin && col_off[c] >= 0) ? src[(i64)z * plane + col_off[c]] : 0.0f;
+    for (int c = 0; c < C::NC; c++) ring[c][(1 + m) % W] = buf_load(rs, col_off[c]);
   }
 
   // ---- march along z, unrolled W times so that ring indices are compile-time ----------------
-  // At unrolled step u (output plane z): plane z+H is written to slot u, and slot (u+1+m) % W
-  // holds plane z-H+m for m = 0..W-2.
+  // At unrolled step u (output plane z): slot (u+1+m) % W holds plane z-H+m, m = 0..W-1
+  // (so the newest plane z+H sits in slot u and the oldest, z-H, in slot (u+1)%W).
   for (int zbase = zs; zbase < ze; zbase += W) {
 #pragma unroll
     for (int u = 0; u < W; u++) {
       const int z = zbase + u;
       if (z < ze) {  // uniform across the workgroup
-        // newest plane
-        {
-          const int zn = z + H;
-          const bool zin = zn < nz;
-#pragma unroll
-          for (int c = 0; c < C::NC; c++)
-            ring[c][u] = (zin && col_off[c] >= 0) ? src[(i64)zn * plane + col_off[c]] : 0.0f;
-        }
-        // Z pass: j ascending <=> plane z-j descending: newest (slot u) first
+        // Z pass: j ascending <=> plane z-j descending: newest first
 #pragma unroll
         for (int c = 0; c < C::NC; c++) {
           float acc = 0.0f;
 #pragma unroll
           for (int jj = 0; jj < W; jj++) {
-            // j = jj - H ; plane z - j = z + H - jj ; m = W-1-jj ; slot = (u+1+m) % W, for jj=0: slot u
-            constexpr int dummy = 0;
-            (void)dummy;
-            const int slot = (jj == 0) ? u : ((u + 1 + (W - 1 - jj)) % W);
-            const float term = tz.t[jj] * ring[c][slot];
+            // j = jj-H; plane z-j = z-H+m with m = W-1-jj
+            const float term = tz.t[jj] * ring[c][(u + 1 + (W - 1 - jj)) % W];
             acc = acc + term;
           }
-          if (lds_off[c] >= 0) sZ[lds_off[c]] = acc;
+          sZ[lds_off[c]] = acc;
+        }
+        // request the plane of the next step (z+1+H) into the slot the oldest plane just vacated
+        {
+          const int zn = z + 1 + H;
+          const bool zin = zn < nz;
+          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+              (void*)(src + (zin ? (i64)zn * plane : 0)), 0, zin ? plane_bytes : 0, 0x00020000);
+#pragma unroll
+          for (int c = 0; c < C::NC; c++) ring[c][(u + 1) % W] = buf_load(rs, col_off[c]);
         }
         __syncthreads();
-        // Y pass: outputs (xp, y): two adjacent x (haloed coords 2xp, 2xp+1), y in [0,TY)
+        // Y pass: two adjacent x per lane; source rows y+2H (j=-H) down to y (j=+H)
 #pragma unroll
         for (int r = 0; r < C::YROUNDS; r++) {
-          const int task = tid + r * NT;
-          if (task < C::YTASKS) {
-            const int y = task / (C::HX / 2);
-            const int xp = task - y * (C::HX / 2);
-            const float* base = &sZ[y * C::SX + 2 * xp];  // haloed row y+H-j, j=-H: row y+2H
+          if (y_off[r] >= 0) {
+            const float* base = &sZ[y_off[r]];
             float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll
             for (int jj = 0; jj < W; jj++) {
@@ -144,126 +186,112 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
               a0 = a0 + p0;
               a1 = a1 + p1;
             }
-            *reinterpret_cast<float2*>(&sY[y * C::SX + 2 * xp]) = make_float2(a0, a1);
+            *reinterpret_cast<float2*>(&sY[y_off[r]]) = make_float2(a0, a1);
           }
         }
         __syncthreads();
-        // X pass: outputs (xp, y): x = 2xp, 2xp+1 in tile coords
+        // X pass: two adjacent outputs per lane; haloed source index x+2H (j=-H) down to x (j=+H)
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(dst + (i64)z * plane), 0, plane_bytes, 0x00020000);
+        float dz = 1.0f;
+        if (NORMALIZE) dz = Dz[z + dz_offset];
 #pragma unroll
         for (int r = 0; r < C::XROUNDS; r++) {
-          const int task = tid + r * NT;
-          if (task < C::XTASKS) {
-            const int y = task / (TX / 2);
-            const int xp = task - y * (TX / 2);
-            const float* base = &sY[y * C::SX + 2 * xp];
-            float v[2 * H + 2];
+          const float* base = &sY[x_off[r]];
+          float v[2 * H + 2];
 #pragma unroll
-            for (int k = 0; k < H + 1; k++) {
-              const float2 q = *reinterpret_cast<const float2*>(base + 2 * k);
-              v[2 * k] = q.x;
-              v[2 * k + 1] = q.y;
-            }
-            float a0 = 0.0f, a1 = 0.0f;
-#pragma unroll
-            for (int jj = 0; jj < W; jj++) {
-              // j = jj-H: haloed index x + H - j = x + 2H - jj
-              const float t = tx.t[jj];
-              const float p0 = t * v[2 * H - jj];
-              const float p1 = t * v[2 * H - jj + 1];
-              a0 = a0 + p0;
-              a1 = a1 + p1;
-            }
-            const int gx = x0 + 2 * xp, gy = y0 + y;
-            if (gy < ny && gx < nx) {
-              if (NORMALIZE) {
-                const float dyz = Dy[gy];
-                const float dz = Dz[z + dz_offset];
-                const float d0 = (Dx[gx] * dyz) * dz;
-                a0 = a0 / d0;
-                if (gx + 1 < nx) {
-                  const float d1 = (Dx[gx + 1] * dyz) * dz;
-                  a1 = a1 / d1;
-                }
-              }
-              float* o = dst + (i64)z * plane + (i64)gy * nx + gx;
-              if (gx + 1 < nx && ((nx & 1) == 0)) {
-                *reinterpret_cast<float2*>(o) = make_float2(a0, a1);
-              } else {
-                o[0] = a0;
-                if (gx + 1 < nx) o[1] = a1;
-              }
-            }
+          for (int k = 0; k < H + 1; k++) {
+            const float2 q = *reinterpret_cast<const float2*>(base + 2 * k);
+            v[2 * k] = q.x;
+            v[2 * k + 1] = q.y;
           }
+          float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+          for (int jj = 0; jj < W; jj++) {
+            const float t = tx.t[jj];
+            const float p0 = t * v[2 * H - jj];
+            const float p1 = t * v[2 * H - jj + 1];
+            a0 = a0 + p0;
+            a1 = a1 + p1;
+          }
+          if (NORMALIZE) {
+            const float d0 = dxy0[r] * dz;
+            const float d1 = dxy1[r] * dz;
+            a0 = a0 / d0;
+            a1 = a1 / d1;
+          }
+          typedef float v2f __attribute__((ext_vector_type(2)));
+          typedef unsigned v2u __attribute__((ext_vector_type(2)));
+          v2f out = {a0, a1};
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, out), ro, (int)o_off[r], 0, 0);
         }
-        // no barrier needed here: the next step's Z pass writes sZ only after every thread has
-        // passed the barrier that follows the Y pass (all sZ reads done), and the next Y pass
-        // writes sY only after the barrier that follows the next Z pass (all sY reads done).
+        // no barrier here: the next Z pass writes sZ only after every thread has passed the barrier
+        // that follows this Y pass (sZ reads done); the next Y pass writes sY only after the barrier
+        // that follows the next Z pass (sY reads done).
       }
     }
   }
 }
 
 template <int H, int TX, int TY, int NT>
-int launch_fused(visfd_hip_ctx* ctx, const float* src, float* dst, i64 nx, i64 ny, i64 nz,
-                 const Taps& tx, const Taps& ty, const Taps& tz, const float* Dx, const float* Dy,
-                 const float* Dz, i64 dz_offset, bool normalize) {
+int launch_cfg(visfd_hip_ctx* ctx, const float* src, float* dst, i64 nx, i64 ny, i64 nz,
+               const Taps& tx, const Taps& ty, const Taps& tz, const float* Dx, const float* Dy,
+               const float* Dz, i64 dz_offset, bool normalize) {
   TapsH<H> a, b, c;
-  for (int k = 0; k < 2 * H + 1; k++) { a.t[k] = tz.t[k]; b.t[k] = ty.t[k]; c.t[k] = tx.t[k]; }
+  bool iso = true;
+  for (int k = 0; k < 2 * H + 1; k++) {
+    a.t[k] = tz.t[k]; b.t[k] = ty.t[k]; c.t[k] = tx.t[k];
+    iso = iso && (std::memcmp(&tz.t[k], &ty.t[k], 4) == 0) && (std::memcmp(&tz.t[k], &tx.t[k], 4) == 0);
+  }
   const int tiles_x = (int)((nx + TX - 1) / TX), tiles_y = (int)((ny + TY - 1) / TY);
-  // z chunks: enough workgroups to fill the chip several times over, but long enough marches
+  // z chunks: enough workgroups to fill the chip several times over, but marches long enough
   // to amortise the 2H-plane ring warm-up
   const i64 tiles = (i64)tiles_x * tiles_y;
-  i64 want_chunks = ((i64)ctx->num_cus * 8 + tiles - 1) / tiles;
+  i64 want_chunks = ((i64)ctx->num_cus * 6 + tiles - 1) / tiles;
   if (want_chunks < 1) want_chunks = 1;
   i64 zchunk = (nz + want_chunks - 1) / want_chunks;
-  const i64 min_chunk = 16 * (2 * H + 1) > 64 ? 64 : 16 * (2 * H + 1);
+  const i64 min_chunk = 12 * H;
   if (zchunk < min_chunk) zchunk = min_chunk;
   if (zchunk > nz) zchunk = nz;
-  i64 nchunks = (nz + zchunk - 1) / zchunk;
-  i64 nblk = tiles * nchunks;
+  const i64 nchunks = (nz + zchunk - 1) / zchunk;
+  const i64 nblk = tiles * nchunks;
   if (nblk > 0x7fffffffLL) return fail(VISFD_HIP_EINVAL, "volume too large for one launch");
   dim3 grid((unsigned)nblk), block(NT);
-  if (normalize)
-    gauss_fused_kernel<H, TX, TY, NT, true><<<grid, block, 0, ctx->stream>>>(
-        src, dst, a, b, c, Dx, Dy, Dz, dz_offset, (int)nx, (int)ny, (int)nz, (int)zchunk, tiles_x,
-        tiles_y, (int)nchunks);
-  else
-    gauss_fused_kernel<H, TX, TY, NT, false><<<grid, block, 0, ctx->stream>>>(
-        src, dst, a, b, c, Dx, Dy, Dz, dz_offset, (int)nx, (int)ny, (int)nz, (int)zchunk, tiles_x,
-        tiles_y, (int)nchunks);
+#define VH_GO(NORM, ISOV)                                                                        \
+  gauss_fused_kernel<H, TX, TY, NT, NORM, ISOV><<<grid, block, 0, ctx->stream>>>(                \
+      src, dst, a, b, c, Dx, Dy, Dz, dz_offset, (int)nx, (int)ny, (int)nz, (int)zchunk, tiles_x, tiles_y)
+  if (normalize) { if (iso) VH_GO(true, true); else VH_GO(true, false); }
+  else           { if (iso) VH_GO(false, true); else VH_GO(false, false); }
+#undef VH_GO
   VH_HIP(hipGetLastError());
   return VISFD_HIP_OK;
 }
 
 }  // namespace
 
-int dev_gauss_fused(visfd_hip_ctx* ctx, const float* src, float* dst, i64 nx, i64 ny, i64 nz,
-                    const Taps& tx, const Taps& ty, const Taps& tz, const float* Dx, const float* Dy,
-                    const float* Dz, i64 dz_offset, bool normalize, bool* handled) {
-  *handled = false;
-  const int H = tx.h;
-  if (ty.h != H || tz.h != H) return VISFD_HIP_OK;          // anisotropic window: 3-pass path
-  if (H < 1 || H > 10) return VISFD_HIP_OK;
-  if (nx >= (1LL << 31) || ny >= (1LL << 31) || nz >= (1LL << 31)) return VISFD_HIP_OK;
-  if (src == dst) return VISFD_HIP_OK;                        // in place: 3-pass path via scratch
-  *handled = true;
-#define VH_FUSED_CASE(HH, TXX, TYY, NTT) \
-  case HH: return launch_fused<HH, TXX, TYY, NTT>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize);
-  switch (H) {
-    VH_FUSED_CASE(1, 64, 16, 256)
-    VH_FUSED_CASE(2, 64, 16, 256)
-    VH_FUSED_CASE(3, 64, 16, 256)
-    VH_FUSED_CASE(4, 64, 16, 256)
-    VH_FUSED_CASE(5, 64, 16, 256)
-    VH_FUSED_CASE(6, 64, 16, 256)
-    VH_FUSED_CASE(7, 64, 16, 512)
-    VH_FUSED_CASE(8, 64, 16, 512)
-    VH_FUSED_CASE(9, 64, 16, 512)
-    VH_FUSED_CASE(10, 64, 16, 512)
-  }
-#undef VH_FUSED_CASE
-  *handled = false;
-  return VISFD_HIP_OK;
+#define VH_CAT2(a, b) a##b
+#define VH_CAT(a, b) VH_CAT2(a, b)
+
+// One entry point per compiled half-width: launch_gauss_fused_h<H>(..., cfg)
+int VH_CAT(launch_gauss_fused_h, VH_FUSED_H)(visfd_hip_ctx* ctx, const float* src, float* dst, i64 nx,
+                                            i64 ny, i64 nz, const Taps& tx, const Taps& ty,
+                                            const Taps& tz, const float* Dx, const float* Dy,
+                                            const float* Dz, i64 dz_offset, bool normalize, int cfg) {
+  constexpr int H = VH_FUSED_H;
+#ifdef VH_FUSED_EXTRA_CFGS   // development: alternative tilings selectable at run time
+  if (cfg == 1) return launch_cfg<H, 64, 16, 512>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize);
+  if (cfg == 2) return launch_cfg<H, 64, 32, 512>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize);
+  if (cfg == 3) return launch_cfg<H, 128, 16, 512>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize);
+  if (cfg == 4) return launch_cfg<H, 128, 32, 1024>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize);
+  if (cfg == 5) return launch_cfg<H, 32, 32, 256>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize);
+  if (cfg == 6) return launch_cfg<H, 64, 32, 1024>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize);
+#endif
+  (void)cfg;
+  // tilings picked from a sweep on MI355X (1024^3, gpurun_out/perf3.log): wider tiles cut the halo
+  // recomputation of the Z and Y passes, which is what bounds this kernel (VALU, not HBM)
+  if (H <= 3) return launch_cfg<H, 128, 16, 512>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize);
+  if (H <= 6) return launch_cfg<H, 128, 32, 1024>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize);
+  return launch_cfg<H, 64, 32, 1024>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize);
 }
 
 }  // namespace vh

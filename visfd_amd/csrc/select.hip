@@ -2,9 +2,11 @@
 // (reference bin/filter_mrc/handlers.cpp:1751-1797).
 //
 // The reference sorts all unmasked saliencies in descending order on one thread and reads entry
-// floor(n*fraction).  Here the same order statistic is found exactly with a two-digit radix select
-// over the order-preserving 32-bit key of the float (2 x 65536-bin histograms, 4 B/voxel/round),
-// which also shards across GPUs: per-rank histograms are summed by the caller.
+// floor(n*fraction).  Here the same order statistic is found exactly with a three-digit radix
+// select (11 + 11 + 10 bits) over the order-preserving 32-bit key of the float: each round is one
+// 4 B/voxel sweep that builds a 2048-bin histogram in LDS per workgroup and merges it with a few
+// global atomics.  Rounds also shard across GPUs: per-rank histograms are summed by the caller
+// (SURVEY.md §8e).
 #include <cmath>
 #include <vector>
 
@@ -15,7 +17,7 @@ namespace vh {
 namespace {
 
 constexpr int BLOCK = 256;
-constexpr int NBINS = 65536;
+constexpr int NBINS = 2048;
 
 __device__ __forceinline__ uint32_t order_key(float f) {
   const uint32_t u = __float_as_uint(f);
@@ -28,32 +30,29 @@ inline float key_to_float(uint32_t k) {
   return f;
 }
 
-// pass 0: digit = key >> 16 over all unmasked voxels.  pass 1: digit = key & 0xffff over voxels
-// whose key >> 16 == prefix.
+// digit layout of the 32-bit key: round 0 = bits 31..21, round 1 = bits 20..10, round 2 = bits 9..0.
+// `prefix` holds the already-selected higher digits (right-aligned); only keys matching it count.
 __global__ void __launch_bounds__(BLOCK)
-histogram_kernel(const float* __restrict__ sal, const float* __restrict__ mask, i64 n, int pass,
+histogram_kernel(const float* __restrict__ sal, const float* __restrict__ mask, i64 n, int round,
                  uint32_t prefix, unsigned long long* __restrict__ hist) {
+  __shared__ unsigned int lh[NBINS];
+  for (int i = threadIdx.x; i < NBINS; i += BLOCK) lh[i] = 0;
+  __syncthreads();
+  const int shift = (round == 0) ? 21 : (round == 1) ? 10 : 0;
+  const uint32_t dmask = (round == 2) ? 0x3ffu : 0x7ffu;
+  const int pshift = (round == 0) ? 32 : (round == 1) ? 21 : 10;
   i64 i = (i64)blockIdx.x * BLOCK + threadIdx.x;
   const i64 step = (i64)gridDim.x * BLOCK;
   for (; i < n; i += step) {
-    bool use = !(mask && mask[i] == 0.0f);
-    uint32_t digit = 0;
-    if (use) {
-      const uint32_t k = order_key(sal[i]);
-      if (pass == 0) digit = k >> 16;
-      else { use = (k >> 16) == prefix; digit = k & 0xffffu; }
-    }
-    // wave-level aggregation of the common "every lane hits the same bin" case
-    const unsigned long long active = __ballot(use);
-    if (active == 0) continue;
-    const int leader = __ffsll((long long)active) - 1;
-    const uint32_t lead_digit = __shfl(digit, leader);
-    const unsigned long long same = __ballot(use && digit == lead_digit);
-    if (same == active) {
-      if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[lead_digit], (unsigned long long)__popcll(active));
-    } else if (use) {
-      atomicAdd(&hist[digit], 1ULL);
-    }
+    if (mask && mask[i] == 0.0f) continue;
+    const uint32_t k = order_key(sal[i]);
+    if (round > 0 && (k >> pshift) != prefix) continue;
+    atomicAdd(&lh[(k >> shift) & dmask], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NBINS; i += BLOCK) {
+    const unsigned int c = lh[i];
+    if (c) atomicAdd(&hist[i], (unsigned long long)c);
   }
 }
 
@@ -71,6 +70,7 @@ apply_threshold_kernel(float* __restrict__ sal, i64 n, float thr) {
 
 int dev_select_histogram(visfd_hip_ctx* ctx, const float* sal, const float* mask, i64 nvox, int pass,
                          uint32_t prefix, uint64_t* hist_host, uint64_t* n_unmasked_host) {
+  // per-workgroup counters are 32-bit: each workgroup sees at most nvox/grid + BLOCK elements
   unsigned long long* hist = nullptr;
   VH_TRY(ws(ctx, WS_HIST, (size_t)NBINS, &hist));
   hipStream_t st = ctx->stream;
@@ -95,7 +95,7 @@ int dev_apply_threshold(visfd_hip_ctx* ctx, float* sal, i64 nvox, float thr) {
   return VISFD_HIP_OK;
 }
 
-// Walk a 65536-bin histogram from the largest key down; returns the bin holding the k-th largest
+// Walk a histogram from the largest key down; returns the bin holding the k-th largest
 // (0-based) element and rewrites k to the rank inside that bin.
 static int pick_bin_descending(const std::vector<uint64_t>& h, uint64_t* k) {
   uint64_t seen = 0;
@@ -116,12 +116,15 @@ int dev_threshold_fraction(visfd_hip_ctx* ctx, float* sal, const float* mask, i6
   uint64_t k = (uint64_t)std::floor(prod);
   if (n_unmasked == 0 || k >= n_unmasked)
     return fail(VISFD_HIP_EINVAL, "threshold fraction selects no voxel (the reference would read past its array)");
-  const int hi = pick_bin_descending(h, &k);
-  if (hi < 0) return fail(VISFD_HIP_EDEVICE, "radix select: inconsistent histogram");
-  VH_TRY(dev_select_histogram(ctx, sal, mask, nvox, 1, (uint32_t)hi, h.data(), nullptr));
-  const int lo = pick_bin_descending(h, &k);
-  if (lo < 0) return fail(VISFD_HIP_EDEVICE, "radix select: inconsistent histogram");
-  const float thr = key_to_float(((uint32_t)hi << 16) | (uint32_t)lo);
+  const int d0 = pick_bin_descending(h, &k);
+  if (d0 < 0) return fail(VISFD_HIP_EDEVICE, "radix select: inconsistent histogram");
+  VH_TRY(dev_select_histogram(ctx, sal, mask, nvox, 1, (uint32_t)d0, h.data(), nullptr));
+  const int d1 = pick_bin_descending(h, &k);
+  if (d1 < 0) return fail(VISFD_HIP_EDEVICE, "radix select: inconsistent histogram");
+  VH_TRY(dev_select_histogram(ctx, sal, mask, nvox, 2, ((uint32_t)d0 << 11) | (uint32_t)d1, h.data(), nullptr));
+  const int d2 = pick_bin_descending(h, &k);
+  if (d2 < 0) return fail(VISFD_HIP_EDEVICE, "radix select: inconsistent histogram");
+  const float thr = key_to_float(((uint32_t)d0 << 21) | ((uint32_t)d1 << 10) | (uint32_t)d2);
   if (thr_out) *thr_out = thr;
   return dev_apply_threshold(ctx, sal, nvox, thr);
 }

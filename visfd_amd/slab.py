@@ -1,0 +1,185 @@
+"""Z-slab decomposition of the hot path across the GPUs of one node.
+
+The reference is single-process (its only parallelism is OpenMP); volumes larger than one GPU --
+or simply more throughput -- are handled here by cutting the volume into slabs of whole XY planes
+along Z, one process and one GPU per slab:
+
+  * every rank stores its owned planes [z0, z1) plus up to `ghost` ghost planes on each INTERIOR
+    face (none at the two true faces of the volume), so that every "outside the image" rule of the
+    reference (zero extension, filter1d.hpp:98-99; Hessian clamp, visfd_utils.hpp:597-610; blob
+    border rule, feature.hpp:245-252) fires only at the true faces;
+  * halos are contiguous blocks of XY planes and travel point-to-point between Z-neighbours only
+    (torch.distributed isend/irecv = RCCL send/recv over one xGMI link per neighbour) -- there is
+    no bulk collective on voxel data;
+  * the only collectives are tiny: three all-reduces of a 2048-bin histogram for the exact global
+    top-fraction threshold (handlers.cpp:1751-1797) and an all-gather of blob lists.
+
+Stage kernels are reached through an `ops` object (visfd_amd.api.Context on a GPU); the arithmetic of
+an owned plane never depends on the decomposition, so slab results equal single-volume results
+bit-for-bit (tests/test_slab_*.py).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import api
+
+
+class SlabLayout:
+    """Which planes a rank owns and stores."""
+
+    def __init__(self, nz_global, rank, world, ghost):
+        self.nz_global, self.rank, self.world, self.ghost = int(nz_global), int(rank), int(world), int(ghost)
+        base, rem = divmod(self.nz_global, self.world)
+        self.z0 = rank * base + min(rank, rem)
+        self.z1 = self.z0 + base + (1 if rank < rem else 0)
+        self.lo = max(0, self.z0 - ghost)           # first stored plane (global index)
+        self.hi = min(self.nz_global, self.z1 + ghost)
+        self.nz_local = self.hi - self.lo
+        self.own0 = self.z0 - self.lo               # owned planes inside the local array
+        self.own1 = self.z1 - self.lo
+        if world > 1 and (self.z1 - self.z0) < ghost:
+            raise ValueError("slabs thinner than the ghost depth are not supported")
+
+    def owned(self, t):
+        """View of the owned planes of a local [nz_local, ny, nx] (or [C, nz_local, ny, nx]) tensor."""
+        return t[..., self.own0:self.own1, :, :]
+
+
+def exchange_halos(t, layout, depth, group=None):
+    """Fill the ghost planes of `t` ([nz_local, ny, nx], contiguous) within `depth` planes of the
+    owned range with the neighbours' owned planes.  Point-to-point with the two Z-neighbours."""
+    L = layout
+    if L.world == 1 or depth == 0:
+        return
+    assert depth <= L.ghost
+    ops = []
+    up, down = L.rank + 1, L.rank - 1
+    if down >= 0:
+        ops.append(dist.P2POp(dist.isend, t[L.own0:L.own0 + depth], down, group))
+        ops.append(dist.P2POp(dist.irecv, t[L.own0 - depth:L.own0], down, group))
+    if up < L.world:
+        ops.append(dist.P2POp(dist.isend, t[L.own1 - depth:L.own1], up, group))
+        ops.append(dist.P2POp(dist.irecv, t[L.own1:L.own1 + depth], up, group))
+    for r in dist.batch_isend_irecv(ops):
+        r.wait()
+
+
+def _pick_descending(hist, k):
+    seen = 0
+    for b in range(len(hist) - 1, -1, -1):
+        c = int(hist[b])
+        if seen + c > k:
+            return b, k - seen
+        seen += c
+    raise RuntimeError("inconsistent histogram")
+
+
+def _key_to_float(key):
+    key = np.uint32(key)
+    u = (key & np.uint32(0x7FFFFFFF)) if (key & np.uint32(0x80000000)) else ~key
+    return float(np.array([u], np.uint32).view(np.float32)[0])
+
+
+def distributed_threshold_fraction(ops, sal_owned, fraction, layout, mask_owned=None, group=None):
+    """Exact global k-th largest saliency over all ranks' owned voxels, then zero everything below
+    it (handlers.cpp:1751-1797).  Three radix rounds; each all-reduces 2048 counters."""
+    prefix, k, thr_key = 0, None, 0
+    shifts = (21, 10, 0)
+    for rnd in range(3):
+        hist, _ = ops.select_histogram_dev(sal_owned, rnd, prefix, mask_owned)
+        h = torch.from_numpy(hist.astype(np.int64))
+        if layout.world > 1:
+            dev = sal_owned.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
+            h = h.to(dev)
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            h = h.cpu()
+        h = h.numpy()
+        if rnd == 0:
+            n = int(h.sum())
+            k = int(math.floor(np.float32(n) * np.float32(fraction)))  # size_t -> float product
+            if n == 0 or k >= n:
+                raise ValueError("threshold fraction selects no voxel")
+        digit, k = _pick_descending(h, k)
+        thr_key |= digit << shifts[rnd]
+        prefix = (prefix << 11) | digit if rnd < 2 else prefix
+    return _key_to_float(thr_key)
+
+
+def membrane_detect_slab(ops, layout, src, sal, dirs, tensor, sigma, tv_sigma_ratio, tv_exponent=4,
+                         best_fraction=0.05, truncate_threshold=0.03, tv_truncate_ratio=math.sqrt(2.0),
+                         minima=True, group=None):
+    """HandleTV (handlers.cpp:1501-1892) on one slab.  `src` holds the owned planes (ghosts are
+    filled here); all tensors have the local shape [nz_local, ny, nx] (dirs: [3, ...], tensor: [6, ...]).
+    Valid results are the owned planes of `sal` (post-voting saliency) and `tensor`."""
+    L = layout
+    order = api.DECREASING_EIVALS if minima else api.INCREASING_EIVALS
+    ratio = api.ratio_from_threshold(truncate_threshold)
+    h_gauss = int(math.floor(np.float32(sigma) * np.float32(ratio)))
+    sigma_tv = float(np.float32(tv_sigma_ratio) * np.float32(sigma))
+    h_tv = int(math.floor(np.float32(sigma_tv) * np.float32(tv_truncate_ratio)))
+    assert L.world == 1 or (h_gauss + 1 <= L.ghost and h_tv <= L.ghost), "ghost depth too small"
+    # 1. source halo deep enough for smoothing + the 19-point stencil
+    exchange_halos(src, L, min(L.ghost, h_gauss + 1), group)
+    # 2. saliency/direction on every stored plane; planes closer than h_gauss+1 to an interior
+    #    array end are garbage, owned planes are exact
+    ops.ridge_saliency_dev(src, sal, dirs, sigma, ratio, order)
+    # 3. global top-fraction threshold over owned voxels
+    thr = distributed_threshold_fraction(ops, L.owned(sal), best_fraction, L, None, group)
+    ops.apply_threshold_dev(L.owned(sal), thr)
+    # 4. (saliency, direction) halo for the voting window
+    exchange_halos(sal, L, min(L.ghost, h_tv), group)
+    for c in range(3):
+        exchange_halos(dirs[c], L, min(L.ghost, h_tv), group)
+    # stored planes beyond the exchanged halo must not vote
+    if L.own0 - h_tv > 0:
+        sal[:L.own0 - h_tv].zero_()
+    if L.own1 + h_tv < L.nz_local:
+        sal[L.own1 + h_tv:].zero_()
+    # 5. votes for the owned planes; 6. score
+    ops.tv_dense_stick_dev(sal, dirs, tensor, sigma_tv, tv_exponent, tv_truncate_ratio, None, None, False,
+                           (L.own0, L.own1))
+    ops.tensor_saliency_dev(tensor, sal, order)
+    return thr
+
+
+def blob_detect_slab(ops, layout, src, sigmas, truncate_threshold=0.03, delta=0.02, minima_threshold=np.inf,
+                     maxima_threshold=-np.inf, use_ratios=False, group=None, cap=1 << 22):
+    """BlobDog (feature.hpp:53-427) on one slab: LoG volumes are computed on the stored planes, the
+    4-D non-max scan keeps candidates of owned planes only, lists are merged on every rank."""
+    L = layout
+    ratio = api.ratio_from_threshold(truncate_threshold)
+    smax = float(np.max(sigmas)) * (1.0 + 0.5 * delta)
+    depth = int(math.floor(ratio * smax)) + 1
+    assert L.world == 1 or depth <= L.ghost, "ghost depth too small for the widest LoG"
+    exchange_halos(src, L, min(L.ghost, depth), group)
+    # thresholds are applied after the merge (ratio mode needs the global best score)
+    mins, maxs = ops.blob_dog_dev(src, sigmas, None, None, delta, ratio, np.inf, -np.inf, False, cap)
+
+    def own(rows):
+        keep = (rows[:, 2] >= L.own0) & (rows[:, 2] < L.own1)
+        rows = rows[keep].copy()
+        rows[:, 2] += np.float32(L.lo)
+        return rows
+
+    mins, maxs = own(mins), own(maxs)
+    if L.world > 1:
+        gathered = [None] * L.world
+        dist.all_gather_object(gathered, (mins, maxs), group=group)
+        mins = np.concatenate([g[0] for g in gathered], 0)
+        maxs = np.concatenate([g[1] for g in gathered], 0)
+    inf = np.float32(np.inf)
+    tmin, tmax = np.float32(minima_threshold), np.float32(maxima_threshold)
+    if use_ratios:  # feature.hpp:369-372 with the global best scores
+        gmin = np.float32(min([1.0] + list(mins[:, 4])))
+        gmax = np.float32(max([-1.0] + list(maxs[:, 4])))
+        tmin = inf if tmin == inf else np.float32(tmin * gmin)
+        tmax = -inf if tmax == -inf else np.float32(tmax * gmax)
+        mins = mins[mins[:, 4] <= tmin]
+        maxs = maxs[maxs[:, 4] >= tmax]
+    else:  # absolute thresholds are strict in the scan (feature.hpp:270-291)
+        mins = mins[mins[:, 4] < tmin]
+        maxs = maxs[maxs[:, 4] > tmax]
+    return mins, maxs
