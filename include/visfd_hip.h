@@ -230,6 +230,28 @@ int visfd_hip_tensor_saliency(visfd_hip_ctx*, const float* tensor, const float* 
 int visfd_hip_tensor_saliency_dev(visfd_hip_ctx*, const float* tensor, const float* mask,
                                   int64_t nvox, int eival_order, float* saliency_inout);
 
+/* ---- a9+a10+a11+a12+a14+a15 in one call: the compute section of HandleTV ------------------------- */
+/* bin/filter_mrc/handlers.cpp:1618-1892 for SURFACE_RIDGE without background subtraction:
+ * CalcHessian (feature.hpp:1203) -> per-voxel eigen/score/direction loop (handlers.cpp:1645-1746) ->
+ * saliency threshold (handlers.cpp:1751-1797: top `best_fraction` of unmasked voxels when
+ * best_fraction >= 0, else the absolute value `threshold_abs`) -> TV3D::TVDenseStick when sigma_tv > 0
+ * (handlers.cpp:1821-1836, normalize=false) -> post-voting score (handlers.cpp:1870-1892).
+ * saliency_out: 1 channel (zero where mask == 0 before voting; voxels with mask == 0 keep that zero).
+ * tensor_out (nullable): 6 channels, interleaved on the host face / planar on the device face; this is
+ * what `-save-progress` writes as <base>_tensor_{0..5}.rec (handlers.cpp:1897-1922).
+ * direction_out (nullable): principal direction, 3 channels. threshold_out (nullable). */
+int visfd_hip_membrane_detect(visfd_hip_ctx*, const float* src, const float* mask,
+                              int64_t nx, int64_t ny, int64_t nz, float sigma, float truncate_ratio,
+                              int eival_order, float best_fraction, float threshold_abs, float sigma_tv,
+                              int tv_exponent, float tv_cutoff_ratio, float* saliency_out,
+                              float* tensor_out, float* direction_out, float* threshold_out);
+int visfd_hip_membrane_detect_dev(visfd_hip_ctx*, const float* src, const float* mask,
+                                  int64_t nx, int64_t ny, int64_t nz, float sigma, float truncate_ratio,
+                                  int eival_order, float best_fraction, float threshold_abs,
+                                  float sigma_tv, int tv_exponent, float tv_cutoff_ratio,
+                                  float* saliency_out, float* tensor_out, float* direction_out,
+                                  float* threshold_out);
+
 /* ---- Z-slab helpers for the separable filter (multi-GPU) -------------------------- */
 /* Same as apply_gauss_dev on a slab: arrays hold planes [z_lo, z_lo+nz_local) of a volume of height
  * nz_global; planes outside the slab are treated as outside the image ONLY at the true faces

@@ -1,0 +1,396 @@
+// visfd_hip.hpp -- the visfd:: template API of the hot path, re-created on top of the C ABI
+// (include/visfd_hip.h, libvisfd_hip.so).  Header-only, C++11, no dependency on the reference.
+//
+// A program written against the reference's headers for this path keeps compiling when it
+// includes this file instead of <visfd.hpp>: the functions below have the reference's names,
+// argument order, argument meaning and error behaviour (they throw visfd::VisfdErr), and take
+// the same `float***` arrays indexed [iz][iy][ix].  The arrays must be CONTIGUOUS, as produced by
+// visfd::Alloc3D (lib/visfd/alloc3d.hpp:25-67) or MrcSimple: &a[0][0][0] is handed to the C ABI.
+//
+// Reference signatures mirrored (file:line under the reference root):
+//   ApplyGauss   lib/visfd/filter3d.hpp:1086-1097, :1161-1173, :1226-1237, :1297-1308
+//                bin/filter_mrc/filter3d_variants.hpp:500-528 (ratio OR threshold)
+//   ApplyDog     lib/visfd/filter3d.hpp:1338-1351          ApplyLog  :1428-1441, :1531-1544
+//   ApplySeparable lib/visfd/filter3d.hpp:686-695  (with GenFilterGauss1D, filter1d.hpp:409)
+//   BlobDog      lib/visfd/feature.hpp:53-77               BlobDogD  :446-470
+//   CalcHessian  lib/visfd/feature.hpp:1203-1219
+//   TV3D         lib/visfd/feature.hpp:1645-1647, TVDenseStick :1711-1724
+//   Alloc3D / Dealloc3D  lib/visfd/alloc3d.hpp:25, :75
+// Only Scalar = float is provided (the hot path and the CLI use float throughout).
+#ifndef VISFD_HIP_HPP
+#define VISFD_HIP_HPP
+
+#include <array>
+#include <cmath>
+#include <cstddef>
+#include <cstdlib>
+#include <exception>
+#include <limits>
+#include <ostream>
+#include <string>
+#include <vector>
+
+#include "visfd_hip.h"
+
+namespace visfd {
+
+// lib/visfd/err_visfd.hpp:15-22
+class VisfdErr : public std::exception {
+  std::string msg;
+ public:
+  VisfdErr(const char* description) : msg(description) {}
+  VisfdErr(std::string description) : msg(description) {}
+  virtual const char* what() const throw() { return msg.c_str(); }
+  virtual ~VisfdErr() throw() {}
+};
+
+namespace hip_detail {
+
+// One process-wide context (device 0 unless VISFD_HIP_DEVICE is set), created on first use.
+inline visfd_hip_ctx* context() {
+  static visfd_hip_ctx* ctx = nullptr;
+  if (!ctx) {
+    int dev = 0;
+    if (const char* e = std::getenv("VISFD_HIP_DEVICE")) dev = std::atoi(e);
+    if (visfd_hip_create(dev, nullptr, &ctx) != VISFD_HIP_OK)
+      throw VisfdErr(std::string("visfd_hip: ") + visfd_hip_last_error());
+  }
+  return ctx;
+}
+inline void check(int rc) {
+  if (rc != VISFD_HIP_OK) throw VisfdErr(std::string("visfd_hip: ") + visfd_hip_last_error());
+}
+template <typename T>
+inline T* flat(T* const* const* a) { return a ? &a[0][0][0] : nullptr; }
+inline const float* flat(float const* const* const* a) { return a ? &a[0][0][0] : nullptr; }
+inline void require_contiguous(float const* const* const* a, const int size[3]) {
+  if (!a) return;
+  const float* base = &a[0][0][0];
+  const size_t nx = size[0], ny = size[1];
+  if (&a[size[2] - 1][size[1] - 1][0] != base + ((size_t)(size[2] - 1) * ny + (size[1] - 1)) * nx)
+    throw VisfdErr("visfd_hip: 3-D arrays must be contiguous (allocate them with Alloc3D)");
+}
+
+}  // namespace hip_detail
+
+// ---- lib/visfd/alloc3d.hpp ------------------------------------------------------------------
+template <typename Entry, typename Integer>
+Entry*** Alloc3D(const Integer size[3]) {
+  const size_t nx = size[0], ny = size[1], nz = size[2];
+  Entry*** a = new Entry**[nz];
+  Entry** rows = new Entry*[nz * ny];
+  Entry* data = new Entry[nz * ny * nx];
+  for (size_t iz = 0; iz < nz; iz++) {
+    a[iz] = rows + iz * ny;
+    for (size_t iy = 0; iy < ny; iy++) a[iz][iy] = data + (iz * ny + iy) * nx;
+  }
+  return a;
+}
+template <typename Entry>
+void Dealloc3D(Entry*** a) {
+  if (a) {
+    delete[] a[0][0];
+    delete[] a[0];
+    delete[] a;
+  }
+}
+
+// ---- lib/visfd/filter1d.hpp:26-390 (the fields the hot path's callers touch) -------------------
+template <typename Scalar, typename Integer>
+class Filter1D {
+ public:
+  std::vector<Scalar> storage;
+  Scalar* afH;        // indexable from -halfwidth .. +halfwidth
+  Integer halfwidth;
+  Integer array_size;
+  Filter1D() : afH(nullptr), halfwidth(-1), array_size(-1) {}
+  explicit Filter1D(Integer h) { Resize(h); }
+  Filter1D(const Filter1D& o) : storage(o.storage), halfwidth(o.halfwidth), array_size(o.array_size) {
+    afH = storage.empty() ? nullptr : storage.data() + halfwidth;
+  }
+  Filter1D& operator=(const Filter1D& o) {
+    storage = o.storage; halfwidth = o.halfwidth; array_size = o.array_size;
+    afH = storage.empty() ? nullptr : storage.data() + halfwidth;
+    return *this;
+  }
+  void Resize(Integer h) {
+    halfwidth = h;
+    array_size = 2 * h + 1;
+    storage.assign((size_t)array_size, (Scalar)-1.0e38);
+    afH = storage.data() + h;
+  }
+};
+
+// lib/visfd/filter1d.hpp:409-460
+inline Filter1D<float, int> GenFilterGauss1D(float sigma, int halfwidth, std::ostream* = nullptr) {
+  Filter1D<float, int> f(halfwidth);
+  hip_detail::check(visfd_hip_gauss_taps(sigma, halfwidth, f.storage.data()));
+  return f;
+}
+
+// ---- lib/visfd/filter3d.hpp:686-695 ---------------------------------------------------------------
+inline float ApplySeparable(int const image_size[3], float const* const* const* aaafSource,
+                            float*** aaafDest, float const* const* const* aaafMask,
+                            Filter1D<float, int> aFilter[3], bool normalize = true,
+                            std::ostream* pReportProgress = nullptr) {
+  hip_detail::require_contiguous(aaafSource, image_size);
+  hip_detail::require_contiguous(aaafDest, image_size);
+  hip_detail::require_contiguous(aaafMask, image_size);
+  if (pReportProgress) *pReportProgress << "  progress: Applying Z, Y, X filters on the GPU" << std::endl;
+  float A = 0;
+  hip_detail::check(visfd_hip_separable3d(
+      hip_detail::context(), hip_detail::flat(aaafSource), hip_detail::flat(aaafDest),
+      hip_detail::flat(aaafMask), image_size[0], image_size[1], image_size[2],
+      aFilter[0].storage.data(), aFilter[0].halfwidth, aFilter[1].storage.data(), aFilter[1].halfwidth,
+      aFilter[2].storage.data(), aFilter[2].halfwidth, normalize ? 1 : 0, &A));
+  return A;
+}
+
+// ---- ApplyGauss: lib/visfd/filter3d.hpp:1086 (sigma[3], halfwidth[3]) --------------------------------
+inline float ApplyGauss(const int image_size[3], float const* const* const* aaafSource, float*** aaafDest,
+                        float const* const* const* aaafMask, float const sigma[3],
+                        const int truncate_halfwidth[3], bool normalize = true,
+                        std::ostream* pReportProgress = nullptr) {
+  hip_detail::require_contiguous(aaafSource, image_size);
+  hip_detail::require_contiguous(aaafDest, image_size);
+  hip_detail::require_contiguous(aaafMask, image_size);
+  if (pReportProgress) *pReportProgress << "  progress: Applying Z, Y, X filters on the GPU" << std::endl;
+  float A = 0;
+  hip_detail::check(visfd_hip_apply_gauss(hip_detail::context(), hip_detail::flat(aaafSource),
+                                          hip_detail::flat(aaafDest), hip_detail::flat(aaafMask),
+                                          image_size[0], image_size[1], image_size[2], sigma,
+                                          truncate_halfwidth, normalize ? 1 : 0, &A));
+  return A;
+}
+// :1161 (sigma, halfwidth)
+inline float ApplyGauss(const int image_size[3], float const* const* const* src, float*** dest,
+                        float const* const* const* mask, float sigma, int truncate_halfwidth,
+                        bool normalize = true, std::ostream* pReportProgress = nullptr) {
+  const float s[3] = {sigma, sigma, sigma};
+  const int hw[3] = {truncate_halfwidth, truncate_halfwidth, truncate_halfwidth};
+  return ApplyGauss(image_size, src, dest, mask, s, hw, normalize, pReportProgress);
+}
+// :1226 (sigma[3], truncate_ratio)
+inline float ApplyGauss(const int image_size[3], float const* const* const* src, float*** dest,
+                        float const* const* const* mask, const float sigma[3], float truncate_ratio = 2.5,
+                        bool normalize = true, std::ostream* pReportProgress = nullptr) {
+  int hw[3];
+  hip_detail::check(visfd_hip_gauss_halfwidths(sigma, truncate_ratio, hw));
+  return ApplyGauss(image_size, src, dest, mask, sigma, hw, normalize, pReportProgress);
+}
+// :1297 (sigma, truncate_ratio).  The reference falls off the end of this overload without a return
+// statement (filter3d.hpp:1309-1319); here it returns the A coefficient like its siblings.
+inline float ApplyGauss(const int image_size[3], float const* const* const* src, float*** dest,
+                        float const* const* const* mask, float sigma, float truncate_ratio = 2.5,
+                        bool normalize = true, std::ostream* pReportProgress = nullptr) {
+  const float s[3] = {sigma, sigma, sigma};
+  return ApplyGauss(image_size, src, dest, mask, s, truncate_ratio, normalize, pReportProgress);
+}
+// bin/filter_mrc/filter3d_variants.hpp:500-528 (ratio, or threshold when ratio <= 0)
+inline float ApplyGauss(const int image_size[3], float const* const* const* src, float*** dest,
+                        float const* const* const* mask, const float sigma[3], float filter_truncate_ratio,
+                        float filter_truncate_threshold, bool normalize = true,
+                        std::ostream* pReportProgress = nullptr) {
+  if (filter_truncate_ratio <= 0) filter_truncate_ratio = visfd_hip_ratio_from_threshold(filter_truncate_threshold);
+  return ApplyGauss(image_size, src, dest, mask, sigma, filter_truncate_ratio, normalize, pReportProgress);
+}
+
+// ---- ApplyDog: lib/visfd/filter3d.hpp:1338-1351 -------------------------------------------------------
+inline void ApplyDog(const int image_size[3], float const* const* const* src, float*** dest,
+                     float const* const* const* mask, float const sigma_a[3], float const sigma_b[3],
+                     const int truncate_halfwidth[3], float* pA = nullptr, float* pB = nullptr,
+                     std::ostream* = nullptr) {
+  hip_detail::require_contiguous(src, image_size);
+  hip_detail::require_contiguous(dest, image_size);
+  hip_detail::require_contiguous(mask, image_size);
+  hip_detail::check(visfd_hip_apply_dog(hip_detail::context(), hip_detail::flat(src), hip_detail::flat(dest),
+                                        hip_detail::flat(mask), image_size[0], image_size[1], image_size[2],
+                                        sigma_a, sigma_b, truncate_halfwidth, pA, pB));
+}
+
+// ---- ApplyLog: lib/visfd/filter3d.hpp:1428-1441 and :1531-1544 ----------------------------------------
+inline void ApplyLog(const int image_size[3], float const* const* const* src, float*** dest,
+                     float const* const* const* mask, const float sigma[3],
+                     float delta_sigma_over_sigma = 0.02, float truncate_ratio = 2.5, float* pA = nullptr,
+                     float* pB = nullptr, std::ostream* = nullptr) {
+  hip_detail::require_contiguous(src, image_size);
+  hip_detail::require_contiguous(dest, image_size);
+  hip_detail::require_contiguous(mask, image_size);
+  hip_detail::check(visfd_hip_apply_log(hip_detail::context(), hip_detail::flat(src), hip_detail::flat(dest),
+                                        hip_detail::flat(mask), image_size[0], image_size[1], image_size[2], sigma,
+                                        delta_sigma_over_sigma, truncate_ratio, pA, pB));
+}
+inline void ApplyLog(const int image_size[3], float const* const* const* src, float*** dest,
+                     float const* const* const* mask, float sigma, float delta_sigma_over_sigma = 0.02,
+                     float truncate_ratio = 2.5, float* pA = nullptr, float* pB = nullptr,
+                     std::ostream* pReportProgress = nullptr) {
+  const float s[3] = {sigma, sigma, sigma};
+  ApplyLog(image_size, src, dest, mask, s, delta_sigma_over_sigma, truncate_ratio, pA, pB, pReportProgress);
+}
+
+// ---- BlobDog: lib/visfd/feature.hpp:53-77 --------------------------------------------------------------
+// The optional preallocated-images argument of the reference (aaaafI) is accepted and ignored: the
+// rolling LoG volumes live in HBM.
+inline void BlobDog(int const image_size[3], float const* const* const* aaafSource,
+                    float const* const* const* aaafMask, const std::vector<float>& blob_sigma,
+                    std::vector<std::array<float, 3> >* pva_minima_crds = nullptr,
+                    std::vector<std::array<float, 3> >* pva_maxima_crds = nullptr,
+                    std::vector<float>* pv_minima_sigma = nullptr, std::vector<float>* pv_maxima_sigma = nullptr,
+                    std::vector<float>* pv_minima_scores = nullptr, std::vector<float>* pv_maxima_scores = nullptr,
+                    const float aspect_ratio[3] = nullptr, float delta_sigma_over_sigma = 0.02,
+                    float truncate_ratio = 2.5,
+                    float minima_threshold = std::numeric_limits<float>::infinity(),
+                    float maxima_threshold = -std::numeric_limits<float>::infinity(),
+                    bool use_threshold_ratios = true, std::ostream* pReportProgress = nullptr,
+                    float**** /*aaaafI*/ = nullptr) {
+  hip_detail::require_contiguous(aaafSource, image_size);
+  hip_detail::require_contiguous(aaafMask, image_size);
+  if (pReportProgress)
+    *pReportProgress << "\n----- Blob detection initiated using " << blob_sigma.size()
+                     << " trial Gaussians -----\n\n";
+  int64_t cap = 1 << 16, nmin = 0, nmax = 0;
+  std::vector<visfd_hip_blob> mins, maxs;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    mins.resize((size_t)cap);
+    maxs.resize((size_t)cap);
+    int rc = visfd_hip_blob_dog(hip_detail::context(), hip_detail::flat(aaafSource), hip_detail::flat(aaafMask),
+                                image_size[0], image_size[1], image_size[2], blob_sigma.data(),
+                                (int)blob_sigma.size(), aspect_ratio, delta_sigma_over_sigma, truncate_ratio,
+                                minima_threshold, maxima_threshold, use_threshold_ratios ? 1 : 0, mins.data(), cap,
+                                &nmin, maxs.data(), cap, &nmax);
+    if (rc == VISFD_HIP_ECAPACITY) { cap = (nmin > nmax ? nmin : nmax); continue; }
+    hip_detail::check(rc);
+    break;
+  }
+  for (int side = 0; side < 2; side++) {
+    const std::vector<visfd_hip_blob>& L = side ? maxs : mins;
+    const int64_t n = side ? nmax : nmin;
+    std::vector<std::array<float, 3> >* crds = side ? pva_maxima_crds : pva_minima_crds;
+    std::vector<float>* sig = side ? pv_maxima_sigma : pv_minima_sigma;
+    std::vector<float>* sc = side ? pv_maxima_scores : pv_minima_scores;
+    for (int64_t i = 0; i < n; i++) {
+      if (crds) {
+        std::array<float, 3> c;
+        c[0] = (float)L[i].ix; c[1] = (float)L[i].iy; c[2] = (float)L[i].iz;
+        crds->push_back(c);
+      }
+      if (sig) sig->push_back(L[i].sigma);
+      if (sc) sc->push_back(L[i].score);
+    }
+  }
+  if (pReportProgress)
+    *pReportProgress << "--- (Found " << nmin << " and " << nmax
+                     << " local minima and maxima, respectively) ---\n" << std::endl;
+}
+
+// ---- BlobDogD: lib/visfd/feature.hpp:446-470 ------------------------------------------------------------
+inline void BlobDogD(int const image_size[3], float const* const* const* aaafSource,
+                     float const* const* const* aaafMask, const std::vector<float>& blob_diameters,
+                     std::vector<std::array<float, 3> >* pva_minima_crds = nullptr,
+                     std::vector<std::array<float, 3> >* pva_maxima_crds = nullptr,
+                     std::vector<float>* pv_minima_diameters = nullptr,
+                     std::vector<float>* pv_maxima_diameters = nullptr,
+                     std::vector<float>* pv_minima_scores = nullptr, std::vector<float>* pv_maxima_scores = nullptr,
+                     const float aspect_ratio[3] = nullptr, float delta_sigma_over_sigma = 0.02,
+                     float truncate_ratio = 2.5,
+                     float minima_threshold = std::numeric_limits<float>::infinity(),
+                     float maxima_threshold = -std::numeric_limits<float>::infinity(),
+                     bool use_threshold_ratios = false, std::ostream* pReportProgress = nullptr,
+                     float**** aaaafI = nullptr) {
+  std::vector<float> blob_sigma(blob_diameters.size()), min_sig, max_sig;
+  hip_detail::check(visfd_hip_blob_diameters_to_sigmas(blob_diameters.data(), (int)blob_diameters.size(),
+                                                       blob_sigma.data()));
+  BlobDog(image_size, aaafSource, aaafMask, blob_sigma, pva_minima_crds, pva_maxima_crds, &min_sig, &max_sig,
+          pv_minima_scores, pv_maxima_scores, aspect_ratio, delta_sigma_over_sigma, truncate_ratio,
+          minima_threshold, maxima_threshold, use_threshold_ratios, pReportProgress, aaaafI);
+  if (pv_minima_diameters) {
+    pv_minima_diameters->resize(min_sig.size());
+    hip_detail::check(visfd_hip_blob_sigmas_to_diameters(min_sig.data(), (int)min_sig.size(),
+                                                         pv_minima_diameters->data()));
+  }
+  if (pv_maxima_diameters) {
+    pv_maxima_diameters->resize(max_sig.size());
+    hip_detail::check(visfd_hip_blob_sigmas_to_diameters(max_sig.data(), (int)max_sig.size(),
+                                                         pv_maxima_diameters->data()));
+  }
+}
+
+// ---- eigenvalue order: lib/visfd/eigen3_simple.hpp:36-43 ------------------------------------------------
+namespace selfadjoint_eigen3 {
+typedef enum eEigenOrderType {
+  INCREASING_EIVALS = VISFD_HIP_INCREASING_EIVALS,
+  DECREASING_EIVALS = VISFD_HIP_DECREASING_EIVALS
+} EigenOrderType;
+}  // namespace selfadjoint_eigen3
+
+// ---- CalcHessian: lib/visfd/feature.hpp:1203-1219 --------------------------------------------------------
+// Containers as HandleTV instantiates them (bin/filter_mrc/handlers.cpp:1547-1565): gradient as
+// array<float,3>***, Hessian as float**** with one pointer per voxel (nullptr where mask == 0).
+inline void CalcHessian(int const image_size[3], float const* const* const* aaafSource,
+                        std::array<float, 3>*** aaaafGradient, float**** aaaafHessian,
+                        float const* const* const* aaafMask, float sigma, float truncate_ratio = 2.5,
+                        std::ostream* pReportProgress = nullptr) {
+  hip_detail::require_contiguous(aaafSource, image_size);
+  hip_detail::require_contiguous(aaafMask, image_size);
+  const size_t n = (size_t)image_size[0] * image_size[1] * image_size[2];
+  std::vector<float> hess(aaaafHessian ? 6 * n : 0);
+  float* grad = aaaafGradient ? &aaaafGradient[0][0][0][0] : nullptr;
+  if (pReportProgress) *pReportProgress << "Calculating the Hessian associated with each voxel\n";
+  hip_detail::check(visfd_hip_calc_hessian(hip_detail::context(), hip_detail::flat(aaafSource), grad,
+                                           aaaafHessian ? hess.data() : nullptr, hip_detail::flat(aaafMask),
+                                           image_size[0], image_size[1], image_size[2], sigma, truncate_ratio));
+  if (aaaafHessian) {
+    size_t v = 0;
+    for (int iz = 0; iz < image_size[2]; iz++)
+      for (int iy = 0; iy < image_size[1]; iy++)
+        for (int ix = 0; ix < image_size[0]; ix++, v++)
+          if (float* h = aaaafHessian[iz][iy][ix])
+            for (int c = 0; c < 6; c++) h[c] = hess[6 * v + c];
+  }
+}
+
+// ---- TV3D: lib/visfd/feature.hpp:1631-1724 (dense stick voting only) --------------------------------------
+template <typename Scalar, typename Integer, typename VectorContainer, typename TensorContainer>
+class TV3D {
+  float sigma;
+  Integer exponent;
+  float cutoff;
+ public:
+  TV3D() : sigma(0), exponent(4), cutoff(2.5f) {}
+  TV3D(Scalar set_sigma, Integer set_exponent, Scalar filter_cutoff_ratio = 2.5)
+      : sigma(set_sigma), exponent(set_exponent), cutoff(filter_cutoff_ratio) {}
+  void SetExponent(Scalar e) { exponent = (Integer)e; }
+  void SetSigma(Scalar s, Scalar filter_cutoff_ratio = 2.5) { sigma = s; cutoff = filter_cutoff_ratio; }
+
+  // aaaafV: array<float,3>*** ; aaaafDest: float**** (pointer per voxel, nullptr = no storage).
+  void TVDenseStick(Integer const image_size[3], Scalar const* const* const* aaafSaliency,
+                    VectorContainer const* const* const* aaaafV, TensorContainer*** aaaafDest,
+                    Scalar const* const* const* aaafMaskSource = nullptr,
+                    Scalar const* const* const* aaafMaskDest = nullptr, bool detect_curves_not_surfaces = false,
+                    bool normalize = true, bool diagonalize_dest = false, std::ostream* pReportProgress = nullptr) {
+    if (normalize || diagonalize_dest)
+      throw VisfdErr("visfd_hip: TVDenseStick supports normalize=false, diagonalize_dest=false "
+                     "(the form filter_mrc uses, handlers.cpp:1826-1836)");
+    if (!aaafSaliency) throw VisfdErr("visfd_hip: TVDenseStick needs an explicit saliency array");
+    int size[3] = {(int)image_size[0], (int)image_size[1], (int)image_size[2]};
+    hip_detail::require_contiguous(aaafSaliency, size);
+    const size_t n = (size_t)size[0] * size[1] * size[2];
+    std::vector<float> ten(6 * n, 0.0f);
+    const float* dir = reinterpret_cast<const float*>(&aaaafV[0][0][0]);
+    if (pReportProgress) *pReportProgress << "---- Begin Tensor Voting (dense, stick) on the GPU ----" << std::endl;
+    hip_detail::check(visfd_hip_tv_dense_stick(hip_detail::context(), hip_detail::flat(aaafSaliency), dir,
+                                               ten.data(), hip_detail::flat(aaafMaskSource),
+                                               hip_detail::flat(aaafMaskDest), size[0], size[1], size[2], sigma,
+                                               (int)exponent, cutoff, detect_curves_not_surfaces ? 1 : 0));
+    size_t v = 0;
+    for (int iz = 0; iz < size[2]; iz++)
+      for (int iy = 0; iy < size[1]; iy++)
+        for (int ix = 0; ix < size[0]; ix++, v++)
+          if (aaaafDest[iz][iy][ix])
+            for (int c = 0; c < 6; c++) aaaafDest[iz][iy][ix][c] = ten[6 * v + c];
+  }
+};
+
+}  // namespace visfd
+
+#endif  // VISFD_HIP_HPP

@@ -1,0 +1,104 @@
+"""The filter_mrc drop-in (visfd_amd/cli/filter_mrc): argument handling on CPU, and on a GPU the
+reference's own command lines with their known answers."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import volgen
+from conftest import GOLDEN, ROOT, assert_bits_equal, assert_close_rel, golden
+
+CLI = os.path.join(ROOT, "visfd_amd", "cli", "filter_mrc")
+
+
+@pytest.fixture(scope="module")
+def cli():
+    if not os.path.exists(CLI):
+        from visfd_amd import build
+        build.build(verbose=False)
+    return CLI
+
+
+def run(cli, *args):
+    return subprocess.run([cli] + [str(a) for a in args], capture_output=True, text=True)
+
+
+def test_cli_rejects_unknown_arguments(cli):
+    r = run(cli, "-in", os.path.join(GOLDEN, "test_blob_detect.rec"), "-frobnicate", 3)
+    assert r.returncode == 1 and "Unrecognized" in r.stderr
+    r = run(cli, "-gauss", 2)
+    assert r.returncode == 1 and "input file" in r.stderr
+    r = run(cli, "-in", "/nonexistent.rec", "-gauss", 2)
+    assert r.returncode == 1 and "Unable to open" in r.stderr
+
+
+def test_cli_fails_loudly_without_gpu(cli):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = run(cli, "-in", os.path.join(GOLDEN, "test_blob_detect.rec"), "-out", "/tmp/_x.rec", "-gauss", 2, "-w", 1)
+    assert r.returncode == 1 and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_config1_gauss(cli, tmp_path):
+    """BASELINE config 1: filter_mrc -gauss 2 -w 1 on tests/test_blob_detect.rec; the reference
+    prints A = 0.00907605 and its output has min/max/mean 33.43096 / 41.48531 / 36.50518."""
+    out = tmp_path / "g.rec"
+    r = run(cli, "-in", os.path.join(GOLDEN, "test_blob_detect.rec"), "-out", out, "-gauss", 2, "-w", 1)
+    assert r.returncode == 0, r.stderr
+    assert "A = 0.00907605" in r.stderr
+    v = volgen.read_mrc(str(out))
+    assert_bits_equal(v, golden("gauss_blobrec")["out"], "CLI gauss output")
+    r = run(cli, "-in", os.path.join(GOLDEN, "test_blob_detect.rec"), "-mask",
+            os.path.join(GOLDEN, "test_blob_detect_mask.rec"), "-out", out, "-gauss", 2, "-w", 1)
+    assert r.returncode == 0, r.stderr
+    assert_bits_equal(volgen.read_mrc(str(out)), golden("gauss_blobrec")["out_masked"], "CLI masked gauss")
+
+
+@pytest.mark.gpu
+def test_cli_blob_reference_command(cli, tmp_path):
+    """tests/test_blob_detection.sh:21 of the reference: 11 minima, best line
+    '235.2 392 313.6 177.915 -140.018'."""
+    out = tmp_path / "blobs.txt"
+    r = run(cli, "-w", 19.6, "-mask", os.path.join(GOLDEN, "test_blob_detect_mask.rec"), "-in",
+            os.path.join(GOLDEN, "test_blob_detect.rec"), "-blob", "minima", out, 160.0, 280.0, 1.01)
+    assert r.returncode == 0, r.stderr
+    lines = open(out).read().strip().split("\n")
+    assert len(lines) == 11
+    assert lines[0] == "235.2 392 313.6 177.915 -140.018"
+    g = golden("blob_rec")["minima"]
+    for line, row in zip(lines, g):
+        x, y, z, d, s = (float(t) for t in line.split())
+        assert abs(s - row[4]) <= 1e-3 * abs(row[4])
+        assert (round(x / 19.6), round(y / 19.6), round(z / 19.6)) == (int(row[0]), int(row[1]), int(row[2]))
+
+
+@pytest.mark.gpu
+def test_cli_membrane_save_progress(cli, tmp_path, oracle):
+    """-membrane minima ... -tv ... -save-progress writes the six vote-tensor channels
+    (handlers.cpp:1897-1922); compared with the oracle run of the same pipeline."""
+    from oracle import pyoracle as po
+    inp = os.path.join(GOLDEN, "test_image_membrane.rec")
+    out = tmp_path / "m.rec"
+    base = tmp_path / "prog"
+    w = 19.2
+    r = run(cli, "-w", w, "-in", inp, "-out", out, "-membrane", "minima", 55, "-tv", 4, "-tv-angle-exponent", 4,
+            "-bin", 1, "-tv-best", 0.1, "-save-progress", base)
+    assert r.returncode == 0, r.stderr
+    mem = volgen.read_mrc(inp)
+    sigma = np.float32(np.float32(55 / np.sqrt(3.0)) / np.float32(w))
+    sigma_tv = np.float32(np.float32(np.float32(4) * np.float32(55 / np.sqrt(3.0))) / np.float32(w))
+    ratio = oracle.ratio_from_threshold(0.03)
+    _, hess = oracle.calc_hessian(mem, sigma, ratio, None, want_grad=False)
+    sal, dirs = oracle.hessian_saliency(hess, po.ORDER_DECREASING)
+    oracle.threshold_fraction(sal, 0.1)
+    ten = oracle.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5)
+    oracle.tensor_saliency(ten, po.ORDER_DECREASING, sal)
+    got = np.stack([volgen.read_mrc("%s_tensor_%d.rec" % (base, c)) for c in range(6)], -1)
+    # device eigen-solver differences can move a few voxels across the saliency threshold: compare
+    # on the scale of the field (1e-4) rather than bit-for-bit here; bit-exact voting with identical
+    # inputs is covered by test_gpu_parity.py
+    assert_close_rel(got, ten, 1e-4, "vote tensor files")
+    assert_close_rel(volgen.read_mrc(str(out)), sal, 1e-4, "output saliency")

@@ -87,6 +87,11 @@ _SIGS = {
     "visfd_hip_tv_dense_stick_slab_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
                                                     C.c_float, C.c_int, C.c_float, C.c_int]),
     "visfd_hip_tv_tables": (C.c_int, [C.c_float, C.c_float, _ip, _fp, _fp]),
+    "visfd_hip_membrane_detect": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, C.c_float, C.c_float, C.c_int, C.c_float,
+                                            C.c_float, C.c_float, C.c_int, C.c_float, _vp, _vp, _vp, _fp]),
+    "visfd_hip_membrane_detect_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, C.c_float, C.c_float, C.c_int,
+                                                C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, _vp, _vp, _vp,
+                                                _fp]),
     "visfd_hip_tensor_saliency": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, _vp]),
     "visfd_hip_tensor_saliency_dev": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, _vp]),
 }
@@ -323,6 +328,20 @@ class Context:
         self._chk(self._L.visfd_hip_tensor_saliency(self._h, _np(tensor), _np(mask), sal_inout.size, int(order),
                                                     _np(sal_inout)))
         return sal_inout
+
+    def membrane_detect(self, src, sigma, ratio, order, best_fraction=0.05, threshold_abs=0.0, sigma_tv=0.0,
+                        tv_exponent=4, tv_cutoff=2.0 ** 0.5, mask=None, want_tensor=True, want_dir=False):
+        """HandleTV's compute section on host arrays -> (saliency, tensor or None, dirs or None, threshold)."""
+        nz, ny, nx = src.shape
+        sal = np.empty_like(src)
+        ten = np.zeros((nz, ny, nx, 6), np.float32) if want_tensor else None
+        dirs = np.zeros((nz, ny, nx, 3), np.float32) if want_dir else None
+        thr = C.c_float()
+        self._chk(self._L.visfd_hip_membrane_detect(self._h, _np(src), _np(mask), nx, ny, nz, float(sigma),
+                                                    float(ratio), int(order), float(best_fraction),
+                                                    float(threshold_abs), float(sigma_tv), int(tv_exponent),
+                                                    float(tv_cutoff), _np(sal), _np(ten), _np(dirs), C.byref(thr)))
+        return sal, ten, dirs, thr.value
 
     # ---------------------------------------------------------------- device face (torch)
     def gauss_dev(self, src, dst, sigma, hw, mask=None, normalize=True):

@@ -75,7 +75,28 @@ def build(force=False, jobs=4, verbose=True):
             raise RuntimeError("link failed")
         if verbose:
             print("[visfd_amd.build] linked", LIB)
+    build_cli(verbose)
     return LIB
+
+
+CLI_SRC = os.path.join(HERE, "cli", "filter_mrc.cpp")
+CLI_BIN = os.path.join(HERE, "cli", "filter_mrc")
+
+
+def build_cli(verbose=True):
+    """The filter_mrc drop-in: plain C++11 host code on top of the C ABI (no HIP in this file)."""
+    deps = [CLI_SRC, os.path.join(ROOT, "include", "visfd_hip.hpp"), os.path.join(ROOT, "include", "visfd_hip.h"), LIB]
+    if os.path.exists(CLI_BIN) and _mtime(CLI_BIN) >= max(_mtime(d) for d in deps):
+        return CLI_BIN
+    cmd = ["g++", "-std=c++11", "-O2", "-Wall", "-o", CLI_BIN, CLI_SRC, "-L" + HERE, "-lvisfd_hip",
+           "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("building filter_mrc failed")
+    if verbose:
+        print("[visfd_amd.build] built", CLI_BIN)
+    return CLI_BIN
 
 
 if __name__ == "__main__":

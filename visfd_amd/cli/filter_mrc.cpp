@@ -1,0 +1,362 @@
+// filter_mrc (MI355X edition) -- the hot-path subset of the reference's filter_mrc command line,
+// running on libvisfd_hip.so through the visfd:: shim (include/visfd_hip.hpp).
+//
+// Supported flags (same spelling, units and defaults as bin/filter_mrc/settings.cpp; all lengths are
+// in PHYSICAL units and are divided by the voxel width, filter_mrc.cpp:297-336):
+//   -in F | -i F        input tomogram (MRC modes 0,1,2,6)
+//   -out F | -o F       output tomogram (always written as mode 2, like mrc_simple.cpp:373)
+//   -mask F             mask tomogram (voxels with 0 are ignored)
+//   -w WIDTH            voxel width (otherwise cellA[0]/nx from the header, handlers.cpp:2429)
+//   -gauss S | -gauss-aniso SX SY SZ              (settings.cpp:1220-1271, HandleGauss)
+//   -dog A B                                        (settings.cpp:1309-1335, HandleDog)
+//   -log S | -log-r R | -log-d D | -log-aniso SX SY SZ | -dog-delta D   (HandleLoGDoG)
+//   -blob|-blob-s|-blob-r|-blob-d TYPE FILE MIN MAX GROWTH             (settings.cpp:1648-1764)
+//   -minima-threshold T | -maxima-threshold T                          (settings.cpp:1915,1934)
+//   -membrane {minima|maxima} THICKNESS | -surface-ridge ...           (settings.cpp:2734-2799)
+//   -tv RATIO | -tv-angle-exponent N | -tv-truncate R | -tv-best F | -detection-threshold T
+//   -save-progress BASE        writes BASE_tensor_{0..5}.rec           (handlers.cpp:1897-1922)
+//   -truncate R | -truncate-threshold T | -normalize-filters no | -bin 1 | -np N (ignored)
+// Anything else is rejected, as the reference rejects unknown arguments (settings.cpp:3340-3365).
+//
+// MRC input/output is written from the MRC2014 layout description (1024-byte header: nx,ny,nz,mode,
+// start[3], m[3], cella[3], cellb[3], mapc/r/s, dmin,dmax,dmean, ispg, nsymbt, ..., "MAP ", machst);
+// signed-byte rule as the reference applies it (mrc_header.cpp:49-75, mrc_simple.cpp:186-192).
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/visfd_hip.hpp"
+
+using namespace visfd;
+using std::cerr;
+using std::string;
+using std::vector;
+
+namespace {
+
+struct Mrc {
+  int32_t nx = 0, ny = 0, nz = 0, mode = 2;
+  float cella[3] = {0, 0, 0};
+  unsigned char raw_header[1024];
+  float*** a = nullptr;  // [iz][iy][ix], contiguous
+  bool loaded = false;
+
+  ~Mrc() { Dealloc3D(a); }
+
+  void alloc(int x, int y, int z) {
+    Dealloc3D(a);
+    nx = x; ny = y; nz = z;
+    int size[3] = {nx, ny, nz};
+    a = Alloc3D<float>(size);
+  }
+  float* data() { return &a[0][0][0]; }
+  size_t nvox() const { return (size_t)nx * ny * nz; }
+
+  void read(const string& path) {
+    std::ifstream f(path.c_str(), std::ios::binary);
+    if (!f) throw VisfdErr("Error: Unable to open \"" + path + "\" for reading.\n");
+    f.read(reinterpret_cast<char*>(raw_header), 1024);
+    if (!f) throw VisfdErr("Error: \"" + path + "\" is too short to be an MRC file.\n");
+    int32_t w[256];
+    std::memcpy(w, raw_header, 1024);
+    float fw[256];
+    std::memcpy(fw, raw_header, 1024);
+    const int x = w[0], y = w[1], z = w[2];
+    mode = w[3];
+    if (x <= 0 || y <= 0 || z <= 0) throw VisfdErr("Error: bad image size in \"" + path + "\"\n");
+    for (int d = 0; d < 3; d++) cella[d] = fw[10 + d];
+    bool signed_bytes = true;
+    if (path.size() > 4 && path.substr(path.size() - 4) == ".rec") signed_bytes = false;
+    if (mode == 0 && w[38] == 1146047817) signed_bytes = (w[39] & 1) != 0;  // IMOD stamp + flag bit 0
+    const int32_t nsymbt = w[23];
+    if (nsymbt > 0) f.seekg(nsymbt, std::ios::cur);
+    alloc(x, y, z);
+    const size_t n = nvox();
+    float* out = data();
+    if (mode == 2) {
+      f.read(reinterpret_cast<char*>(out), (std::streamsize)(n * 4));
+    } else if (mode == 0) {
+      vector<unsigned char> buf(n);
+      f.read(reinterpret_cast<char*>(buf.data()), (std::streamsize)n);
+      for (size_t i = 0; i < n; i++) out[i] = signed_bytes ? (float)(int8_t)buf[i] : (float)buf[i];
+    } else if (mode == 1 || mode == 6) {
+      vector<uint16_t> buf(n);
+      f.read(reinterpret_cast<char*>(buf.data()), (std::streamsize)(n * 2));
+      for (size_t i = 0; i < n; i++) out[i] = (mode == 1) ? (float)(int16_t)buf[i] : (float)buf[i];
+    } else {
+      throw VisfdErr("Error: unsupported MRC mode in \"" + path + "\" (supported: 0, 1, 2, 6)\n");
+    }
+    if (!f) throw VisfdErr("Error: \"" + path + "\" ended before all voxels were read.\n");
+    loaded = true;
+  }
+
+  // header of `like` (cell size, origin, labels) with mode 2 and fresh statistics
+  void write(const string& path, const Mrc& like) {
+    unsigned char h[1024];
+    std::memcpy(h, like.raw_header, 1024);
+    int32_t w[256];
+    std::memcpy(w, h, 1024);
+    float fw[256];
+    std::memcpy(fw, h, 1024);
+    w[0] = nx; w[1] = ny; w[2] = nz; w[3] = 2;
+    w[23] = 0;  // no extended header
+    const size_t n = nvox();
+    const float* p = &a[0][0][0];
+    double sum = 0;
+    float lo = p[0], hi = p[0];
+    for (size_t i = 0; i < n; i++) { sum += p[i]; lo = std::min(lo, p[i]); hi = std::max(hi, p[i]); }
+    std::memcpy(h, w, 96);
+    fw[19] = lo; fw[20] = hi; fw[21] = (float)(sum / (double)n);
+    std::memcpy(h + 76, &fw[19], 12);
+    std::ofstream f(path.c_str(), std::ios::binary);
+    if (!f) throw VisfdErr("Error: Unable to open \"" + path + "\" for writing.\n");
+    f.write(reinterpret_cast<const char*>(h), 1024);
+    f.write(reinterpret_cast<const char*>(p), (std::streamsize)(n * 4));
+  }
+};
+
+struct Settings {
+  string in, out, mask, save_base;
+  float voxel_width = -1;
+  enum { NONE, GAUSS, DOG, LOG, BLOB, SURFACE_RIDGE } type = NONE;
+  float width_a[3] = {0, 0, 0}, width_b[3] = {0, 0, 0}, log_width[3] = {0, 0, 0};
+  float truncate_ratio = -1.0f, truncate_threshold = 0.03f;   // settings.cpp:81,88
+  float delta = 0.02f;                                        // settings.cpp:95
+  bool normalize = true;
+  // blobs
+  vector<float> blob_diameters;
+  string blob_min_file, blob_max_file;
+  float score_lower = -std::numeric_limits<float>::infinity();
+  float score_upper = std::numeric_limits<float>::infinity();
+  // membranes
+  bool ridges_are_maxima = false;
+  float hessian_thr = 0.05f;                                  // settings.cpp:150-151
+  bool hessian_thr_is_fraction = true;
+  float tv_sigma = 0.0f;
+  int tv_exponent = 4;                                        // settings.cpp:154
+  float tv_truncate = std::sqrt(2.0);                         // settings.cpp:155
+};
+
+float num(const vector<string>& v, size_t i, const string& flag) {
+  if (i >= v.size() || v[i].empty()) throw VisfdErr("Error: The " + flag + " argument must be followed by a number.\n");
+  try { return std::stof(v[i]); } catch (...) { throw VisfdErr("Error: The " + flag + " argument must be followed by a number.\n"); }
+}
+
+Settings parse(int argc, char** argv) {
+  Settings s;
+  vector<string> v(argv + 1, argv + argc);
+  for (size_t i = 0; i < v.size();) {
+    const string& f = v[i];
+    auto need = [&](size_t k) { if (i + k >= v.size()) throw VisfdErr("Error: The " + f + " argument needs " + std::to_string(k) + " parameter(s).\n"); };
+    if (f == "-in" || f == "-i") { need(1); s.in = v[i + 1]; i += 2; }
+    else if (f == "-out" || f == "-o") { need(1); s.out = v[i + 1]; i += 2; }
+    else if (f == "-mask") { need(1); s.mask = v[i + 1]; i += 2; }
+    else if (f == "-w") { need(1); s.voxel_width = num(v, i + 1, f); i += 2; }
+    else if (f == "-np") { need(1); i += 2; }  // host threads: not used by the GPU path
+    else if (f == "-bin") {
+      need(1);
+      if (num(v, i + 1, f) != 1.0f) throw VisfdErr("Error: this build supports \"-bin 1\" only (binning is not on the GPU hot path).\n");
+      i += 2;
+    }
+    else if (f == "-gauss") { need(1); s.width_a[0] = s.width_a[1] = s.width_a[2] = num(v, i + 1, f); s.type = Settings::GAUSS; i += 2; }
+    else if (f == "-gauss-aniso") { need(3); for (int d = 0; d < 3; d++) s.width_a[d] = num(v, i + 1 + d, f); s.type = Settings::GAUSS; i += 4; }
+    else if (f == "-dog") {
+      need(2);
+      s.width_a[0] = s.width_a[1] = s.width_a[2] = num(v, i + 1, f);
+      s.width_b[0] = s.width_b[1] = s.width_b[2] = num(v, i + 2, f);
+      s.type = Settings::DOG; i += 3;
+    }
+    else if (f == "-log" || f == "-log-r" || f == "-log-d") {
+      need(1);
+      float m = 1.0f;
+      if (f == "-log-r") m = (float)(1.0 / std::sqrt(3.0));
+      if (f == "-log-d") m = (float)(1.0 / (2.0 * std::sqrt(3.0)));
+      s.log_width[0] = s.log_width[1] = s.log_width[2] = num(v, i + 1, f) * m;
+      s.type = Settings::LOG; i += 2;
+    }
+    else if (f == "-log-aniso") { need(3); for (int d = 0; d < 3; d++) s.log_width[d] = num(v, i + 1 + d, f); s.type = Settings::LOG; i += 4; }
+    else if (f == "-dog-delta") { need(1); s.delta = num(v, i + 1, f); i += 2; }
+    else if (f == "-truncate") { need(1); s.truncate_ratio = num(v, i + 1, f); s.truncate_threshold = -1.0f; i += 2; }
+    else if (f == "-truncate-threshold") { need(1); s.truncate_threshold = num(v, i + 1, f); s.truncate_ratio = -1.0f; i += 2; }
+    else if (f == "-normalize-filters") {
+      need(1);
+      if (v[i + 1] == "no") s.normalize = false;
+      else throw VisfdErr("Error: -normalize-filters accepts \"no\" only (as in the reference, settings.cpp:492-496).\n");
+      i += 2;
+    }
+    else if (f == "-blob" || f == "-blob-sigma" || f == "-blob-s" || f == "-blobs" || f == "-blob-radii" ||
+             f == "-blob-r" || f == "-blobr" || f == "-blob-diameters" || f == "-blob-d") {
+      need(5);
+      const string kind = v[i + 1], base = v[i + 2];
+      if (kind == "minima" || kind == "min") { s.blob_min_file = base; s.blob_max_file = ""; s.score_upper = 0.0f; }
+      else if (kind == "maxima" || kind == "max") { s.blob_max_file = base; s.blob_min_file = ""; s.score_lower = 0.0f; }
+      else if (kind == "all") {
+        s.blob_min_file = base + ".minima.txt"; s.blob_max_file = base + ".maxima.txt";
+        if (s.score_lower == 0.0f) s.score_lower = -std::numeric_limits<float>::infinity();
+        if (s.score_upper == 0.0f) s.score_upper = std::numeric_limits<float>::infinity();
+      } else throw VisfdErr("Error: The 1st parameter to \"" + f + "\" must be \"minima\", \"maxima\" or \"all\".\n");
+      const float wmin = num(v, i + 3, f), wmax = num(v, i + 4, f);
+      float growth = num(v, i + 5, f);
+      if (wmin <= 0 || wmax <= 0 || wmin >= wmax || growth <= 1.0f)
+        throw VisfdErr("Error: " + f + " needs 0 < min < max and a growth ratio > 1.\n");
+      const int N = 1 + (int)std::ceil(std::log(wmax / wmin) / std::log(growth));   // settings.cpp:1719
+      growth = (float)std::pow(wmax / wmin, 1.0 / N);
+      float mult = 1.0f;
+      if (f == "-blob-sigma" || f == "-blob-s") mult = (float)(2.0 * std::sqrt(3.0));
+      if (f == "-blob-radii" || f == "-blob-r" || f == "-blobr") mult = 2.0f;
+      else if (f == "-blob-diameters" || f == "-blob-d") mult = 1.0f;
+      s.blob_diameters.resize((size_t)N);
+      s.blob_diameters[0] = wmin * mult;
+      for (int n = 1; n < N; n++) s.blob_diameters[(size_t)n] = s.blob_diameters[(size_t)n - 1] * growth;
+      s.type = Settings::BLOB; i += 6;
+    }
+    else if (f == "-minima-threshold") { need(1); s.score_upper = num(v, i + 1, f); i += 2; }
+    else if (f == "-maxima-threshold") { need(1); s.score_lower = num(v, i + 1, f); i += 2; }
+    else if (f == "-membrane" || f == "-surface-ridge") {
+      need(2);
+      if (v[i + 1] == "min" || v[i + 1] == "minima") s.ridges_are_maxima = false;
+      else if (v[i + 1] == "max" || v[i + 1] == "maxima") s.ridges_are_maxima = true;
+      else throw VisfdErr("Error: The " + f + " argument must be followed by \"minima\" or \"maxima\" and a width.\n");
+      const float sigma = (float)(num(v, i + 2, f) / std::sqrt(3.0));   // settings.cpp:2774
+      s.width_a[0] = s.width_a[1] = s.width_a[2] = sigma;
+      s.type = Settings::SURFACE_RIDGE; i += 3;
+    }
+    else if (f == "-tv") { need(1); s.tv_sigma = num(v, i + 1, f); i += 2; }
+    else if (f == "-tv-angle-exponent") { need(1); s.tv_exponent = (int)num(v, i + 1, f); i += 2; }
+    else if (f == "-tv-truncate") { need(1); s.tv_truncate = num(v, i + 1, f); i += 2; }
+    else if (f == "-tv-best" || f == "-best") {
+      need(1); s.hessian_thr = num(v, i + 1, f); s.hessian_thr_is_fraction = true;
+      if (!(s.hessian_thr >= 0.0f && s.hessian_thr <= 1.0f)) throw VisfdErr("Error: -tv-best needs a number between 0 and 1.\n");
+      i += 2;
+    }
+    else if (f == "-detection-threshold") { need(1); s.hessian_thr = num(v, i + 1, f); s.hessian_thr_is_fraction = false; i += 2; }
+    else if (f == "-save-progress") { need(1); s.save_base = v[i + 1]; i += 2; }
+    else throw VisfdErr("Error: Unrecognized (or unsupported on the GPU hot path) argument: \"" + f + "\"\n");
+  }
+  if (s.in.empty()) throw VisfdErr("Error: You must specify an input file (-in).\n");
+  if (s.type == Settings::SURFACE_RIDGE) s.tv_sigma *= s.width_a[0];   // settings.cpp:3535-3540
+  return s;
+}
+
+float ratio_of(const Settings& s) {
+  return s.truncate_ratio > 0 ? s.truncate_ratio : visfd_hip_ratio_from_threshold(s.truncate_threshold);
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  try {
+    cerr << "filter_mrc (visfd-mi355x, hot path on libvisfd_hip ABI " << visfd_hip_abi_version() << ")\n";
+    Settings s = parse(argc, argv);
+    Mrc tomo_in, mask, tomo_out;
+    tomo_in.read(s.in);
+    if (!s.mask.empty()) {
+      mask.read(s.mask);
+      if (mask.nx != tomo_in.nx || mask.ny != tomo_in.ny || mask.nz != tomo_in.nz)
+        throw VisfdErr("Error: The size of the mask image does not match the size of the input image.\n");
+    }
+    int size[3] = {tomo_in.nx, tomo_in.ny, tomo_in.nz};
+    float vw[3];
+    if (s.voxel_width > 0) vw[0] = vw[1] = vw[2] = s.voxel_width;
+    else {
+      vw[0] = tomo_in.cella[0] / size[0];  // handlers.cpp:2429-2475: inferred from the header
+      vw[1] = vw[2] = vw[0];
+      if (!(vw[0] > 0)) vw[0] = vw[1] = vw[2] = 1.0f;
+    }
+    cerr << "voxel width = " << vw[0] << "\n";
+    for (int d = 0; d < 3; d++) { s.width_a[d] /= vw[d]; s.width_b[d] /= vw[d]; s.log_width[d] /= vw[d]; }
+    s.tv_sigma /= vw[0];
+    for (size_t k = 0; k < s.blob_diameters.size(); k++) s.blob_diameters[k] /= vw[0];
+
+    tomo_out.alloc(size[0], size[1], size[2]);
+    std::memcpy(tomo_out.data(), tomo_in.data(), tomo_in.nvox() * 4);   // filter_mrc.cpp:398
+    float const* const* const* M = mask.loaded ? mask.a : nullptr;
+    const float ratio = ratio_of(s);
+
+    if (s.type == Settings::GAUSS) {
+      cerr << "filter_type = Gaussian\n";
+      const float A = ApplyGauss(size, tomo_in.a, tomo_out.a, M, s.width_a, s.truncate_ratio, s.truncate_threshold,
+                                 s.normalize, &cerr);
+      cerr << " Filter Used: A discrete Gaussian kernel, approximately equal to\n"
+              " h(x,y,z)   ≈ A*exp(-0.5*((x/σ_x)^2 + (y/σ_y)^2 + (z/σ_z)^2))\n"
+              " ... where  A = " << A << "\n";
+    } else if (s.type == Settings::DOG) {
+      cerr << "filter_type = Difference of Gaussians (DoG)\n";
+      // bin/filter_mrc/filter3d_variants.hpp:542-597: each Gaussian has its own window
+      Mrc tmp;
+      tmp.alloc(size[0], size[1], size[2]);
+      const float A = ApplyGauss(size, tomo_in.a, tomo_out.a, M, s.width_a, s.truncate_ratio, s.truncate_threshold, true);
+      const float B = ApplyGauss(size, tomo_in.a, tmp.a, M, s.width_b, s.truncate_ratio, s.truncate_threshold, true);
+      float* o = tomo_out.data();
+      const float* t = tmp.data();
+      for (size_t i = 0; i < tomo_out.nvox(); i++) o[i] -= t[i];
+      cerr << "  ... where      A = " << A << "\n                 B = " << B << "\n";
+    } else if (s.type == Settings::LOG) {
+      cerr << "filter_type = Laplacian of Gaussians (LoG)\n";
+      float A = 0, B = 0;
+      ApplyLog(size, tomo_in.a, tomo_out.a, M, s.log_width, s.delta, ratio, &A, &B, &cerr);
+      cerr << "  ... where      A = " << A << "\n                 B = " << B << "\n";
+    } else if (s.type == Settings::BLOB) {
+      vector<std::array<float, 3> > cmin, cmax;
+      vector<float> dmin, dmax, smin, smax;
+      BlobDogD(size, tomo_in.a, M, s.blob_diameters, &cmin, &cmax, &dmin, &dmax, &smin, &smax, nullptr, s.delta, ratio,
+               s.score_upper, s.score_lower, false, &cerr);
+      // physical units + sort by score (handlers.cpp:853-909), ties keep list order
+      for (int side = 0; side < 2; side++) {
+        const string& fname = side ? s.blob_max_file : s.blob_min_file;
+        if (fname.empty()) continue;
+        vector<std::array<float, 3> >& c = side ? cmax : cmin;
+        vector<float>& dia = side ? dmax : dmin;
+        vector<float>& sc = side ? smax : smin;
+        vector<size_t> idx(c.size());
+        for (size_t i = 0; i < idx.size(); i++) idx[i] = i;
+        std::stable_sort(idx.begin(), idx.end(), [&](size_t p, size_t q) { return side ? sc[p] > sc[q] : sc[p] < sc[q]; });
+        std::ofstream out(fname.c_str());
+        if (!out) throw VisfdErr("Error: unable to open \"" + fname + "\" for writing.\n");
+        for (size_t k = 0; k < idx.size(); k++) {
+          const size_t i = idx[k];
+          out << c[i][0] * vw[0] << " " << c[i][1] * vw[1] << " " << c[i][2] * vw[2] << " " << dia[i] * vw[0] << " "
+              << sc[i] << "\n";
+        }
+      }
+    } else if (s.type == Settings::SURFACE_RIDGE) {
+      cerr << "filter_type = surface ridge detector\n";
+      const int order = s.ridges_are_maxima ? VISFD_HIP_INCREASING_EIVALS : VISFD_HIP_DECREASING_EIVALS;  // handlers.cpp:1524-1535
+      const size_t n = tomo_in.nvox();
+      vector<float> tensor(s.save_base.empty() || s.tv_sigma <= 0 ? 0 : 6 * n);
+      float thr = 0;
+      hip_detail::check(visfd_hip_membrane_detect(
+          hip_detail::context(), tomo_in.data(), mask.loaded ? mask.data() : nullptr, size[0], size[1], size[2],
+          s.width_a[0], ratio, order, s.hessian_thr_is_fraction ? s.hessian_thr : -1.0f, s.hessian_thr, s.tv_sigma,
+          s.tv_exponent, s.tv_truncate, tomo_out.data(), tensor.empty() ? nullptr : tensor.data(), nullptr, &thr));
+      cerr << "  (saliency threshold = " << thr << ")\n";
+      if (!tensor.empty()) {
+        Mrc t;
+        t.alloc(size[0], size[1], size[2]);
+        for (int c = 0; c < 6; c++) {
+          float* o = t.data();
+          for (size_t i = 0; i < n; i++) o[i] = tensor[6 * i + c];
+          std::ostringstream name;
+          name << s.save_base << "_tensor_" << c << ".rec";
+          cerr << "writing \"" << name.str() << "\"\n";
+          t.write(name.str(), tomo_in);
+        }
+      }
+    }
+    if (!s.out.empty()) {
+      cerr << "writing tomogram (in 32-bit float mode)\n";
+      tomo_out.write(s.out, tomo_in);
+    }
+  } catch (std::exception& e) {
+    cerr << "\n" << e.what() << std::endl;
+    return 1;
+  }
+  return 0;
+}

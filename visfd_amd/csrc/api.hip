@@ -625,6 +625,66 @@ int visfd_hip_tv_dense_stick(visfd_hip_ctx* ctx, const float* sal, const float* 
   return download(ctx, ten, aos6, 6 * n);
 }
 
+// ---- HandleTV compute section ------------------------------------------------------------------
+int visfd_hip_membrane_detect_dev(visfd_hip_ctx* ctx, const float* src, const float* mask, int64_t nx,
+                                  int64_t ny, int64_t nz, float sigma, float ratio, int order,
+                                  float best_fraction, float threshold_abs, float sigma_tv, int exponent,
+                                  float cutoff, float* sal, float* ten, float* dir, float* thr_out) {
+  VH_REQUIRE(ctx && src && sal, "null argument");
+  VH_REQUIRE(order == 0 || order == 1, "unsupported eigenvalue order");
+  VH_REQUIRE(best_fraction <= 1.0f, "fraction must be <= 1");
+  VH_HIP(hipSetDevice(ctx->device));
+  VH_TRY(check_dims(nx, ny, nz));
+  const i64 n = nx * ny * nz;
+  float* d = dir;
+  if (!d) VH_TRY(ws(ctx, WS_TVAUX, (size_t)(3 * n), &d));
+  VH_TRY(visfd_hip_ridge_saliency_dev(ctx, src, mask, nx, ny, nz, sigma, ratio, order, sal, d));
+  float thr = threshold_abs;
+  if (best_fraction >= 0.0f) VH_TRY(dev_threshold_fraction(ctx, sal, mask, n, best_fraction, &thr));
+  else VH_TRY(dev_apply_threshold(ctx, sal, n, thr));
+  if (thr_out) *thr_out = thr;
+  if (sigma_tv > 0.0f) {
+    float* t = ten;
+    if (!t) VH_TRY(ws(ctx, WS_B, (size_t)(6 * n), &t));
+    VH_TRY(dev_tv_dense_stick(ctx, sal, d, t, mask, mask, nx, ny, nz, 0, nz, sigma_tv, exponent, cutoff, false));
+    VH_TRY(dev_tensor_saliency(ctx, t, mask, n, order, sal));
+  }
+  return VISFD_HIP_OK;
+}
+
+int visfd_hip_membrane_detect(visfd_hip_ctx* ctx, const float* src, const float* mask, int64_t nx, int64_t ny,
+                              int64_t nz, float sigma, float ratio, int order, float best_fraction,
+                              float threshold_abs, float sigma_tv, int exponent, float cutoff, float* sal,
+                              float* ten, float* dir, float* thr_out) {
+  VH_REQUIRE(ctx && src && sal, "null argument");
+  VH_HIP(hipSetDevice(ctx->device));
+  VH_TRY(check_dims(nx, ny, nz));
+  const size_t n = (size_t)(nx * ny * nz);
+  float *ds, *dm, *dsal, *pdir, *pten = nullptr, *aos;
+  VH_TRY(upload(ctx, WS_H2D_0, src, n, &ds));
+  VH_TRY(upload(ctx, WS_H2D_1, mask, n, &dm));
+  VH_TRY(ws(ctx, WS_H2D_2, n, &dsal));
+  VH_TRY(ws(ctx, WS_H2D_3, 3 * n, &pdir));
+  if (ten && sigma_tv > 0.0f) {
+    VH_TRY(ws(ctx, WS_H2D_4, 6 * n, &pten));
+    VH_HIP(hipMemsetAsync(pten, 0, sizeof(float) * 6 * n, ctx->stream));
+  }
+  VH_TRY(visfd_hip_membrane_detect_dev(ctx, ds, dm, nx, ny, nz, sigma, ratio, order, best_fraction,
+                                       threshold_abs, sigma_tv, exponent, cutoff, dsal, pten, pdir, thr_out));
+  VH_TRY(download(ctx, sal, dsal, n));
+  if (ten && pten) {
+    VH_TRY(ws(ctx, WS_A, 6 * n, &aos));
+    VH_TRY(dev_planar_to_interleaved(ctx, pten, aos, (i64)n, 6, nullptr));
+    VH_TRY(download(ctx, ten, aos, 6 * n));
+  }
+  if (dir) {
+    VH_TRY(ws(ctx, WS_A, 6 * n, &aos));
+    VH_TRY(dev_planar_to_interleaved(ctx, pdir, aos, (i64)n, 3, nullptr));
+    VH_TRY(download(ctx, dir, aos, 3 * n));
+  }
+  return VISFD_HIP_OK;
+}
+
 // ---- a15 -------------------------------------------------------------------------------------
 int visfd_hip_tensor_saliency_dev(visfd_hip_ctx* ctx, const float* ten, const float* mask, int64_t nvox,
                                   int order, float* sal) {
