@@ -184,15 +184,20 @@ def sigmas_to_diameters(s):
     return d
 
 
+_BLOB_DTYPE = np.dtype([("ix", "<i4"), ("iy", "<i4"), ("iz", "<i4"), ("scale", "<i4"), ("sigma", "<f4"),
+                        ("score", "<f4")])
+
+
 def _blobs_to_rows(arr, n):
     """-> float32 rows x,y,z,sigma,score (the reference's list layout) plus the scale indices."""
+    rec = np.frombuffer(arr, dtype=_BLOB_DTYPE, count=n)
     rows = np.empty((n, 5), np.float32)
-    scale = np.empty(n, np.int32)
-    for i in range(n):
-        b = arr[i]
-        rows[i] = (b.ix, b.iy, b.iz, b.sigma, b.score)
-        scale[i] = b.scale
-    return rows, scale
+    rows[:, 0] = rec["ix"]
+    rows[:, 1] = rec["iy"]
+    rows[:, 2] = rec["iz"]
+    rows[:, 3] = rec["sigma"]
+    rows[:, 4] = rec["score"]
+    return rows, rec["scale"].copy()
 
 
 class Context:
@@ -273,13 +278,14 @@ class Context:
                    use_ratios, cap):
         nz, ny, nx = shape
         sig = np.ascontiguousarray(sigmas, np.float32)
-        amin = (Blob * cap)()
-        amax = (Blob * cap)()
+        amin = np.empty(cap, _BLOB_DTYPE)   # visfd_hip_blob records
+        amax = np.empty(cap, _BLOB_DTYPE)
         nmin, nmax = _i64(), _i64()
         asp = _f3(aspect) if aspect is not None else None
         self._chk(fn(self._h, psrc, pmask, nx, ny, nz, sig.ctypes.data_as(_fp), len(sig), asp, float(delta),
-                     float(ratio), float(minima_threshold), float(maxima_threshold), int(use_ratios), amin, cap,
-                     C.byref(nmin), amax, cap, C.byref(nmax)))
+                     float(ratio), float(minima_threshold), float(maxima_threshold), int(use_ratios),
+                     amin.ctypes.data_as(C.POINTER(Blob)), cap, C.byref(nmin),
+                     amax.ctypes.data_as(C.POINTER(Blob)), cap, C.byref(nmax)))
         return _blobs_to_rows(amin, nmin.value)[0], _blobs_to_rows(amax, nmax.value)[0]
 
     def blob_dog(self, src, sigmas, mask=None, aspect=None, delta=0.02, ratio=2.5, minima_threshold=np.inf,

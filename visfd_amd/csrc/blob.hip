@@ -6,7 +6,18 @@
 // voxel itself is unmasked, its score is negative and passes the (absolute) threshold; maxima are
 // symmetric (feature.hpp:231-304).  Float comparisons are exact, so indices match the reference
 // bit-for-bit whenever the three LoG volumes do.
+//
+// Two kernels:
+//   1. candidates: an HBM sweep of the MIDDLE volume only (4 B/voxel).  A workgroup owns a 64 x 4
+//      column tile and marches along z; each plane goes through an LDS tile with a one-voxel halo,
+//      each thread takes the min and max of its 3x3 neighbourhood, and a three-plane register ring
+//      gives the 3x3x3 box min/max.  A voxel is a candidate when it equals the box min (or max)
+//      and passes the sign/threshold tests -- a non-strict superset of the 26-neighbour rule.
+//   2. verify: one thread per candidate repeats the reference's exact test on all 80 neighbours
+//      (strict comparisons, masks) and appends the survivors.
+// LoG volumes are smooth, so candidates are a small fraction of the voxels and kernel 2 is cheap.
 #include <algorithm>
+#include <limits>
 
 #include "common.hpp"
 
@@ -14,7 +25,11 @@ namespace vh {
 
 namespace {
 
-constexpr int BLOCK = 256;
+constexpr int BLOCK = 512;
+constexpr int TX = 64, TY = 8;          // one voxel column per thread
+constexpr int FLUSH_EVERY = 4;          // planes between flushes of the workgroup's candidate buffer
+constexpr int BUFCAP = FLUSH_EVERY * BLOCK;
+constexpr int LW = TX + 2, LH = TY + 2; // LDS tile with halo
 
 struct Cand {
   int ix, iy, iz;
@@ -23,29 +38,112 @@ struct Cand {
 };
 
 __global__ void __launch_bounds__(BLOCK)
-blob_scan_kernel(const float* __restrict__ lo, const float* __restrict__ mid,
-                 const float* __restrict__ hi, const float* __restrict__ mask, int nx, int ny, int nz,
-                 float min_thr, float max_thr, int want_min, int want_max,
-                 Cand* __restrict__ out, unsigned long long capacity,
-                 unsigned long long* __restrict__ counter) {
-  // interior voxels only: a voxel on a face has an out-of-bounds neighbour (feature.hpp:245-252)
-  const int wx = nx - 2;
-  const int xblocks = (wx + BLOCK - 1) / BLOCK;
+blob_candidates_kernel(const float* __restrict__ mid, const float* __restrict__ mask, int nx, int ny, int nz,
+                       float min_thr, float max_thr, int zchunk, int tiles_x, int tiles_y,
+                       unsigned long long* __restrict__ out, unsigned long long capacity,
+                       unsigned long long* __restrict__ counter) {
+  __shared__ float tile[2][LH * LW];
+  // candidates are collected per workgroup and written out with ONE global atomic per flush
+  __shared__ unsigned long long buf[BUFCAP];
+  __shared__ unsigned int buf_n;
+  __shared__ unsigned long long buf_base;
+  if (threadIdx.x == 0) buf_n = 0;
   unsigned b = blockIdx.x;
-  const int bx = b % xblocks;
-  b /= xblocks;
-  const int iy = 1 + (int)(b % (unsigned)(ny - 2));
-  const int iz = 1 + (int)(b / (unsigned)(ny - 2));
-  const int ix = 1 + bx * BLOCK + (int)threadIdx.x;
-  if (ix > nx - 2) return;
+  const int tile_x = b % tiles_x;
+  b /= tiles_x;
+  const int tile_y = b % tiles_y;
+  const int chunk = b / tiles_y;
+  const int x0 = tile_x * TX, y0 = tile_y * TY;
+  const int zs = max(1, chunk * zchunk), ze = min(nz - 1, (chunk + 1) * zchunk);  // interior planes only
+  if (zs >= ze) return;
+  const int tid = threadIdx.x;
+  const int lx = tid & (TX - 1), ly = tid >> 6;
+  const int gx = x0 + lx, gy = y0 + ly;
   const i64 plane = (i64)nx * ny;
-  const i64 c = (i64)iz * plane + (i64)iy * nx + ix;
-  if (mask && mask[c] == 0.0f) return;
+  const bool interior = gx >= 1 && gx <= nx - 2 && gy >= 1 && gy <= ny - 2;
+
+  // cooperative load of one haloed plane into LDS (values outside the image are irrelevant: they
+  // only influence face voxels, which can never be blobs, feature.hpp:245-252)
+  auto load_plane = [&](int z, float* dst) {
+    for (int i = tid; i < LH * LW; i += BLOCK) {
+      const int r = i / LW, c = i - r * LW;
+      const int sx = x0 - 1 + c, sy = y0 - 1 + r;
+      float v = 0.0f;
+      if (sx >= 0 && sx < nx && sy >= 0 && sy < ny) v = mid[(i64)z * plane + (i64)sy * nx + sx];
+      dst[i] = v;
+    }
+  };
+  // min and max over the 3x3 neighbourhood of (lx, ly) in an LDS plane, plus the centre value
+  auto minmax9 = [&](const float* t, float& mn, float& mx, float& centre) {
+    const float* p0 = t + ly * LW + lx;  // top-left of the 3x3 window (halo offset 1 folded in)
+    float a = p0[0], bb = p0[1], c = p0[2];
+    mn = fminf(fminf(a, bb), c); mx = fmaxf(fmaxf(a, bb), c);
+    a = p0[LW]; bb = p0[LW + 1]; c = p0[LW + 2];
+    centre = bb;
+    mn = fminf(mn, fminf(fminf(a, bb), c)); mx = fmaxf(mx, fmaxf(fmaxf(a, bb), c));
+    a = p0[2 * LW]; bb = p0[2 * LW + 1]; c = p0[2 * LW + 2];
+    mn = fminf(mn, fminf(fminf(a, bb), c)); mx = fmaxf(mx, fmaxf(fmaxf(a, bb), c));
+  };
+
+  float mn_prev, mx_prev, c_prev, mn_cur, mx_cur, c_cur;
+  load_plane(zs - 1, tile[0]);
+  __syncthreads();
+  minmax9(tile[0], mn_prev, mx_prev, c_prev);
+  load_plane(zs, tile[1]);
+  __syncthreads();
+  minmax9(tile[1], mn_cur, mx_cur, c_cur);
+  for (int z = zs; z < ze; z++) {
+    float* nxt = tile[(z - zs) & 1];      // the buffer that held plane z-1: free since the last barrier
+    load_plane(z + 1, nxt);
+    __syncthreads();
+    float mn_nxt, mx_nxt, c_nxt;
+    minmax9(nxt, mn_nxt, mx_nxt, c_nxt);
+    const float e = c_cur;
+    const float bmin = fminf(fminf(mn_prev, mn_cur), mn_nxt);
+    const float bmax = fmaxf(fmaxf(mx_prev, mx_cur), mx_nxt);
+    const bool is_min = (e == bmin) && (e < 0.0f) && (e < min_thr);
+    const bool is_max = (e == bmax) && (e > 0.0f) && (e > max_thr);
+    if (interior && (is_min || is_max)) {
+      const i64 v = (i64)z * plane + (i64)gy * nx + gx;
+      if (!(mask && mask[v] == 0.0f)) buf[atomicAdd(&buf_n, 1u)] = (unsigned long long)v;
+    }
+    mn_prev = mn_cur; mx_prev = mx_cur;
+    mn_cur = mn_nxt; mx_cur = mx_nxt; c_cur = c_nxt;
+    // no second barrier for the tiles: the buffer overwritten in the next step was last read before
+    // this step's barrier, and the one read in this step is only overwritten after the next one's
+    if (((z - zs) % FLUSH_EVERY) == FLUSH_EVERY - 1 || z == ze - 1) {   // uniform
+      __syncthreads();
+      const unsigned int n = buf_n;
+      if (tid == 0 && n) buf_base = atomicAdd(counter, (unsigned long long)n);
+      __syncthreads();
+      if (n) {
+        const unsigned long long base = buf_base;
+        for (unsigned int i = tid; i < n; i += BLOCK)
+          if (base + i < capacity) out[base + i] = buf[i];
+      }
+      __syncthreads();
+      if (tid == 0) buf_n = 0;
+      // the next append happens after the next plane's barrier, which orders this reset before it
+    }
+  }
+}
+
+__global__ void __launch_bounds__(BLOCK)
+blob_verify_kernel(const unsigned long long* __restrict__ cand_idx, unsigned long long n_cand,
+                   const float* __restrict__ lo, const float* __restrict__ mid, const float* __restrict__ hi,
+                   const float* __restrict__ mask, int nx, int ny, int nz, float min_thr, float max_thr,
+                   Cand* __restrict__ out, unsigned long long capacity, unsigned long long* __restrict__ counter) {
+  const unsigned long long t = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (t >= n_cand) return;
+  const i64 c = (i64)cand_idx[t];
+  const i64 plane = (i64)nx * ny;
+  const int iz = (int)(c / plane);
+  const int rem = (int)(c - (i64)iz * plane);
+  const int iy = rem / nx, ix = rem - iy * nx;
   const float e = mid[c];
-  bool is_min = want_min && (e < 0.0f) && (e < min_thr);
-  bool is_max = want_max && (e > 0.0f) && (e > max_thr);
-  if (!is_min && !is_max) return;
-  const float* vol[3] = {mid, lo, hi};  // same-scale neighbours first: they reject most voxels
+  bool is_min = (e < 0.0f) && (e < min_thr);
+  bool is_max = (e > 0.0f) && (e > max_thr);
+  const float* vol[3] = {mid, lo, hi};
   for (int r = 0; r < 3 && (is_min || is_max); r++) {
     const float* v = vol[r];
     for (int jz = -1; jz <= 1; jz++)
@@ -83,28 +181,50 @@ int dev_blob_scan(visfd_hip_ctx* ctx, const float* lo, const float* mid, const f
   if (nx < 3 || ny < 3 || nz < 3) return VISFD_HIP_OK;  // no interior voxels: nothing can be a blob
   if (nx >= (1LL << 31) || ny >= (1LL << 31) || nz >= (1LL << 31))
     return fail(VISFD_HIP_EINVAL, "dimension too large");
+  const float inf = std::numeric_limits<float>::infinity();
+  if (!want_min) min_thr = -inf;   // nothing is < -inf
+  if (!want_max) max_thr = inf;
   hipStream_t st = ctx->stream;
-  unsigned long long* counter = nullptr;
-  VH_TRY(ws(ctx, WS_COUNTER, 1, &counter));
-  size_t capacity = ctx->slot_bytes[WS_CAND] / sizeof(Cand);
-  if (capacity < (1u << 20)) capacity = 1u << 20;
-  const i64 xblocks = (nx - 2 + BLOCK - 1) / BLOCK;
-  const i64 nblocks = xblocks * (ny - 2) * (nz - 2);
+  unsigned long long* counters = nullptr;   // [0]: candidates, [1]: verified
+  VH_TRY(ws(ctx, WS_COUNTER, 2, &counters));
+  const int tiles_x = (int)((nx + TX - 1) / TX), tiles_y = (int)((ny + TY - 1) / TY);
+  const i64 tiles = (i64)tiles_x * tiles_y;
+  i64 want_chunks = ((i64)ctx->num_cus * 16 + tiles - 1) / tiles;
+  if (want_chunks < 1) want_chunks = 1;
+  i64 zchunk = (nz + want_chunks - 1) / want_chunks;
+  if (zchunk < 16) zchunk = 16;
+  const i64 nchunks = (nz + zchunk - 1) / zchunk;
+  const i64 nblocks = tiles * nchunks;
   if (nblocks > 0x7fffffffLL) return fail(VISFD_HIP_EINVAL, "volume too large for one launch");
-  for (int attempt = 0; attempt < 2; attempt++) {
+
+  size_t cap_idx = ctx->slot_bytes[WS_TVAUX] / sizeof(unsigned long long);
+  if (cap_idx < (1u << 22)) cap_idx = 1u << 22;
+  size_t cap_out = ctx->slot_bytes[WS_CAND] / sizeof(Cand);
+  if (cap_out < (1u << 20)) cap_out = 1u << 20;
+  for (int attempt = 0; attempt < 3; attempt++) {
+    unsigned long long* idx = nullptr;
     Cand* cand = nullptr;
-    VH_TRY(ws(ctx, WS_CAND, capacity, &cand));
-    VH_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned long long), st));
-    blob_scan_kernel<<<dim3((unsigned)nblocks), dim3(BLOCK), 0, st>>>(
-        lo, mid, hi, mask, (int)nx, (int)ny, (int)nz, min_thr, max_thr, want_min ? 1 : 0,
-        want_max ? 1 : 0, cand, (unsigned long long)capacity, counter);
+    VH_TRY(ws(ctx, WS_TVAUX, cap_idx, &idx));
+    VH_TRY(ws(ctx, WS_CAND, cap_out, &cand));
+    VH_HIP(hipMemsetAsync(counters, 0, 2 * sizeof(unsigned long long), st));
+    blob_candidates_kernel<<<dim3((unsigned)nblocks), dim3(BLOCK), 0, st>>>(
+        mid, mask, (int)nx, (int)ny, (int)nz, min_thr, max_thr, (int)zchunk, tiles_x, tiles_y, idx,
+        (unsigned long long)cap_idx, counters);
     VH_HIP(hipGetLastError());
-    unsigned long long count = 0;
-    VH_HIP(hipMemcpyAsync(&count, counter, sizeof(count), hipMemcpyDeviceToHost, st));
+    unsigned long long n_cand = 0;
+    VH_HIP(hipMemcpyAsync(&n_cand, counters, sizeof(n_cand), hipMemcpyDeviceToHost, st));
     VH_HIP(hipStreamSynchronize(st));
-    if (count > capacity) {  // rare: grow once to the exact size and rescan
-      capacity = (size_t)count;
-      continue;
+    if (n_cand > cap_idx) { cap_idx = (size_t)n_cand; continue; }   // rare: grow and rescan
+    unsigned long long count = 0;
+    if (n_cand) {
+      const unsigned g = (unsigned)((n_cand + BLOCK - 1) / BLOCK);
+      blob_verify_kernel<<<dim3(g), dim3(BLOCK), 0, st>>>(idx, n_cand, lo, mid, hi, mask, (int)nx, (int)ny,
+                                                         (int)nz, min_thr, max_thr, cand,
+                                                         (unsigned long long)cap_out, counters + 1);
+      VH_HIP(hipGetLastError());
+      VH_HIP(hipMemcpyAsync(&count, counters + 1, sizeof(count), hipMemcpyDeviceToHost, st));
+      VH_HIP(hipStreamSynchronize(st));
+      if (count > cap_out) { cap_out = (size_t)count; continue; }
     }
     std::vector<Cand> h((size_t)count);
     if (count) {

@@ -6,21 +6,25 @@
 // once per workgroup instead of once per receiver:
 //
 //   * a workgroup owns a 16 x 16 x 1 tile of receivers (one per thread; each wave an 8 x 8 patch);
-//   * sender planes are visited from z+h down to z-h (= jz ascending).  For each plane the
-//     workgroup reads the (16+2h)^2 region of saliencies around the tile (next plane prefetched in
-//     registers), and compacts the salient, unmasked senders -- position, saliency, normal, mask
-//     value -- into an LDS list in scan order (ordered block-wide prefix sum, so deterministic);
-//   * the list is consumed from its end in chunks of 64.  Phase A: every lane tests the 64 senders
-//     against its own receiver with integer arithmetic (jx^2+jy^2+jz^2 <= h^2, an exact superset of
-//     the table's spherical support) and records the hits as a 64-bit mask in registers.
-//     Phase B: every lane pops ITS OWN hits in order and accumulates the votes, so lanes are
-//     busy with real votes instead of idling under a sparse exec mask;
-//   * weights and unit displacements come from the |jz| slice of a (h+1)^3 octant table held in
-//     LDS: w(j) depends on (|jx|,|jy|,|jz|) only and rhat(-j) = -rhat(j) exactly.
+//   * sender planes are visited from z+h down to z-h (= jz ascending), in groups of up to G planes
+//     whose |jz| slices of the octant weight table fit in LDS.  For each plane the workgroup reads
+//     the (16+2h)^2 region of saliencies around the tile (buffer loads, next plane prefetched in
+//     registers) and appends the salient, unmasked senders -- packed position, saliency, normal,
+//     mask value -- to an LDS list IN VOTE ORDER (ordered block-wide prefix sum: deterministic);
+//   * when the list is full (or the group ends) it is flushed.  Phase A: every lane tests all
+//     listed senders against its own receiver -- positions broadcast with v_readlane, distance
+//     jx^2+jy^2+jz^2 <= h^2 from one v_dot4_i32_i8 on packed byte offsets, an exact superset of the
+//     table's spherical support -- and writes one 32-bit hit word per 32 senders to its private LDS
+//     column.  Phase B: every lane walks ITS OWN hit words in order and accumulates the votes (next
+//     hit's LDS reads in flight during the current vote), so lanes spend their time on real votes
+//     instead of idling under a sparse exec mask; long lists even out the per-lane hit counts;
+//   * weights and unit displacements come from octant slices in LDS: w(j) depends on
+//     (|jx|,|jy|,|jz|) only and rhat(-j) = -rhat(j) exactly, so signs are re-applied with one
+//     v_and_or per component.
 //
-// Order of accumulation per receiver: jz ascending (plane order), then jy, jx ascending
-// (= list order reversed), exactly the reference's, and each vote is the same chain of float
-// multiplies and adds (no FMA), so tensors are bit-identical to the CPU path for exponent 2 and 4.
+// Order of accumulation per receiver: jz ascending (plane order), then jy, jx ascending, exactly
+// the reference's; each vote is the same chain of float multiplies and adds (no FMA), so tensors
+// are bit-identical to the CPU path for angular exponents 2 and 4.
 #include <vector>
 
 #include "common.hpp"
@@ -33,8 +37,13 @@ constexpr int NT = 256;
 constexpr int TILE = 16;
 constexpr int VPT = 7;               // region voxels per thread per band
 constexpr int BAND_CAP = NT * VPT;   // 1792 region voxels per band
-constexpr int CAP = 512;             // list entries held in LDS at a time (a band may need several passes)
-constexpr int CHUNK = 64;
+#ifndef VH_TV_CAP
+#define VH_TV_CAP 512
+#endif
+constexpr int CAP = VH_TV_CAP;       // list entries held in LDS between flushes
+constexpr int NWORDS = CAP / 32;
+constexpr int SLICE_BYTES = 24 * 1024;  // LDS budget for the octant slices of one plane group
+constexpr int MAX_GROUP = 4;   // more planes per group lengthen the lists but cost LDS (occupancy)
 constexpr unsigned OOB = 0x7ffffff0u;  // byte offset beyond any plane descriptor: reads give 0
 
 __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
@@ -47,6 +56,7 @@ struct TiledParams {
   int h, hp1;            // halfwidth, h+1
   int rw, rh;            // region width/height = TILE + 2h
   int band_rows, nbands;
+  int group;             // planes per group (slices resident in LDS)
   int tiles_x, tiles_y;
   int exponent, curves;
 };
@@ -81,17 +91,22 @@ __device__ __forceinline__ void vote(float T[6], float sal, float fv, float r0, 
   T[2] = T[2] + b2 * m2;
 }
 
+// magnitude m (>= 0) with the sign of the integer j; j == 0 keeps +m (rhat components are +0.0 there)
+__device__ __forceinline__ float with_sign_of(float m, int j) {
+  return __uint_as_float(__float_as_uint(m) | ((unsigned)j & 0x80000000u));
+}
+
 template <bool MASKED_SRC, int MODE>
 __global__ void __launch_bounds__(NT)
 tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, float* __restrict__ ten,
                 const float* __restrict__ mask_src, const float* __restrict__ mask_dst,
                 const float4* __restrict__ octant /* [(h+1)^3] : w, |rx|, |ry|, |rz| */, TiledParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // LDS: sender list of the current pass (structure of arrays) + two |jz| slices of the octant table
-  float4* l_dat = reinterpret_cast<float4*>(smem);                         // sal, n0, n1, n2
-  unsigned* l_pos = reinterpret_cast<unsigned*>(smem + 16 * CAP);          // (ey << 8) | ex
-  float* l_mv = reinterpret_cast<float*>(smem + 20 * CAP);                 // source-mask value
-  float4* slices = reinterpret_cast<float4*>(smem + 24 * CAP);             // 2 x (h+1)^2
+  float4* l_dat = reinterpret_cast<float4*>(smem);                        // sal, n0, n1, n2
+  unsigned* l_pos = reinterpret_cast<unsigned*>(smem + 16 * CAP);         // ex | ey << 8 | ez << 16
+  float* l_mv = reinterpret_cast<float*>(smem + 20 * CAP);                // source-mask value
+  unsigned* hitw = reinterpret_cast<unsigned*>(smem + 24 * CAP);          // [NWORDS][NT] hit words
+  float4* slices = reinterpret_cast<float4*>(smem + 24 * CAP + 4 * NWORDS * NT);  // [group][(h+1)^2]
   __shared__ int wave_tot[2][NT / 64];
 
   const int tid = threadIdx.x;
@@ -107,19 +122,22 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
   const i64 plane = (i64)p.nx * p.ny;
   const i64 nvox = plane * p.nz;
 
-  // receiver of this thread: wave w owns the 8x8 patch (w&1, w>>1)
+  // receiver of this thread: wave w owns the 8x8 patch (w&1, w>>1).  Region-relative coordinates:
+  // the sender region starts at (x0-h, y0-h, rz-h), so the receiver sits at (lx+h, ly+h, h).
   const int lx = (wave & 1) * 8 + (lane & 7), ly = (wave >> 1) * 8 + (lane >> 3);
   const int rx = x0 + lx, ry = y0 + ly;
-  const int rxr = lx + h, ryr = ly + h;   // region-relative receiver coordinates
   const bool r_in = rx < p.nx && ry < p.ny;
   const i64 rc = (i64)rz * plane + (i64)ry * p.nx + rx;
   const bool r_live = r_in && !(mask_dst && mask_dst[r_in ? rc : 0] == 0.0f);
   const int h2 = h * h;
+  // byte-packed receiver position, biased by 128 per byte so that recv_b - pos never borrows
+  const unsigned recv_b = (unsigned)(lx + h + 128) | ((unsigned)(ly + h + 128) << 8) | ((unsigned)(h + 128) << 16);
 
   float T[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 
   const int sz_hi = min(rz + h, p.nz - 1), sz_lo = max(rz - h, 0);
-  const int nsteps = (sz_hi - sz_lo + 1) * p.nbands;
+  const int nplanes = sz_hi - sz_lo + 1;
+  const int nsteps = nplanes * p.nbands;
 
   // region voxels owned by this thread inside a band: VPT consecutive positions, (row << 8) | column
   int rc_[VPT];
@@ -161,19 +179,92 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
     }
   };
 
+  // ---- flush: phase A (tests) + phase B (votes) over list entries [0, n) in vote order ---------
+  // slot_of_plane0: region-relative z (ez) of the group's first plane; slice slot = ez_first - ez
+  auto flush = [&](int n, int ez_first) {
+    const int nwords = (n + 31) >> 5;
+    const int neg_lim = -(h2 + 1);
+    // phase A: one hit word per 32 listed senders; nz collects which words are non-empty
+    unsigned nz = 0u;
+    for (int w = 0; w < nwords; w++) {
+      const int e = (w << 5) + (lane & 31);
+      const unsigned mypos = (e < n) ? l_pos[e] : 0u;
+      unsigned bits = 0u;
+#pragma unroll
+      for (int k = 31; k >= 0; k--) {
+        const unsigned ps = (unsigned)__builtin_amdgcn_readlane((int)mypos, k);
+        const unsigned t = (recv_b - ps) ^ 0x00808080u;          // signed byte offsets jx, jy, jz
+        const int d = __builtin_amdgcn_sdot4((int)t, (int)t, neg_lim, false);  // jx^2+jy^2+jz^2-h^2-1 < 0 <=> hit
+        bits = __builtin_amdgcn_alignbit(bits, (unsigned)d, 31);  // bits = bits << 1 | sign(d)
+      }
+      const int valid = n - (w << 5);
+      if (valid < 32) bits &= (1u << valid) - 1u;
+      if (!r_live) bits = 0u;
+      hitw[w * NT + tid] = bits;
+      nz |= (bits != 0u ? 1u : 0u) << w;
+    }
+    // phase B: every lane walks its own hit words (its LDS column is private: no barrier needed)
+    unsigned cur = 0u;
+    int w = 0;
+    for (;;) {
+      if (cur == 0u) {
+        if (nz == 0u) break;                 // this lane is done
+        w = __ffs((int)nz) - 1;
+        nz &= nz - 1u;
+        cur = hitw[w * NT + tid];
+      }
+      const int bpos = __ffs((int)cur) - 1;
+      cur &= cur - 1u;
+      const int idx = (w << 5) + bpos;
+      const unsigned ps = l_pos[idx];
+      const float4 d = l_dat[idx];
+      const unsigned t = (recv_b - ps) ^ 0x00808080u;
+      const int jx = (int)(signed char)(t & 0xffu);
+      const int jy = (int)(signed char)((t >> 8) & 0xffu);
+      const int jz = (int)(signed char)((t >> 16) & 0xffu);
+      const int ax = jx < 0 ? -jx : jx, ay = jy < 0 ? -jy : jy;
+      const int slot = ez_first - h + jz;                       // ez = h - jz
+      const float4 tw = slices[__mul24(slot, nsl) + __mul24(ay, p.hp1) + ax];
+      float fv = tw.x;
+      if (MASKED_SRC) fv = fv * l_mv[idx];
+      if (fv != 0.0f) {
+        const float r0 = with_sign_of(tw.y, jx);
+        const float r1 = with_sign_of(tw.z, jy);
+        const float r2 = with_sign_of(tw.w, jz);
+        vote<MODE>(T, d.x, fv, r0, r1, r2, d.y, d.z, d.w, p.exponent, p.curves);
+      }
+    }
+  };
+
+  int n_list = 0;         // entries currently in the LDS list
+  int ez_first = 0;       // region-relative z of the first plane of the current group
   if (nsteps > 0) fetch(0, pre);
   for (int step = 0; step < nsteps; step++) {
     const int par = step & 1;
-    const int sz = sz_hi - step / p.nbands;
+    const int pl = step / p.nbands;                         // plane counter, 0 = z+h side
+    const int sz = sz_hi - pl;
     const int band = p.nbands - 1 - (step % p.nbands);
     const int row0 = band * p.band_rows;
-    const int jz = rz - sz;
-    const int az = jz < 0 ? -jz : jz;
-    const float4* slice = slices + ((step / p.nbands) & 1) * nsl;
+    const int rows = min(p.band_rows, p.rh - row0);
+    const int ez = sz - (rz - h);                           // 0..2h
+    const bool new_group = (step % p.nbands == 0) && (pl % p.group == 0);
     float cur[VPT];
 #pragma unroll
     for (int v = 0; v < VPT; v++) cur[v] = pre[v];
     if (step + 1 < nsteps) fetch(step + 1, pre);   // in flight while this band is processed
+
+    if (new_group) {
+      // previous group completely flushed (n_list == 0, barrier at the end of flush block below):
+      // load the |jz| slices of this group's planes
+      ez_first = ez;
+      const int g_planes = min(p.group, nplanes - pl);
+      for (int i = tid; i < g_planes * nsl; i += NT) {
+        const int s = i / nsl, r = i - s * nsl;
+        const int jz = h - (ez_first - s);                  // plane s of the group has ez = ez_first - s
+        const int az = jz < 0 ? -jz : jz;
+        slices[i] = octant[(i64)az * nsl + r];
+      }
+    }
 
     // ---- ordered compaction of the band's salient senders ------------------------------------
     int cnt = 0;
@@ -186,13 +277,7 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
       if (lane >= d) incl += o;
     }
     if (lane == 63) wave_tot[par][wave] = incl;
-    // the |jz| slice of the octant table (when the plane changes); double-buffered like wave_tot so
-    // that waves still consuming the previous step are not disturbed
-    if (step % p.nbands == 0) {
-      float4* dst = slices + ((step / p.nbands) & 1) * nsl;
-      for (int i = tid; i < nsl; i += NT) dst[i] = octant[(i64)az * nsl + i];
-    }
-    __syncthreads();   // (1) every wave has finished consuming the previous step's list
+    __syncthreads();   // (1) wave totals (and new slices) visible
     int base = 0, len = 0;
 #pragma unroll
     for (int w = 0; w < NT / 64; w++) {
@@ -200,103 +285,46 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
       base += (w < wave) ? t : 0;
       len += t;
     }
-    const int first_rank = base + incl - cnt;   // rank of this thread's first sender in the band list
+    // vote order inside a band is DESCENDING position: entry with ascending rank r gets q = len-1-r
+    const int first_q = len - 1 - (base + incl - cnt);     // q of this thread's first sender; next ones q-1, ...
 
-    // The band's list (ranks 0..len-1, ascending position) is walked from its end in passes of at
-    // most CAP entries: one pass unless more than CAP senders of the region are salient.
-    for (int pass_hi = len; pass_hi > 0; pass_hi -= CAP) {
-      const int pass_lo = max(0, pass_hi - CAP);
-      if (pass_hi != len) __syncthreads();  // previous pass fully consumed before the list is rewritten
-      {
-        const int rows = min(p.band_rows, p.rh - row0);
-        const __amdgpu_buffer_rsrc_t rd0 = plane_rsrc(dir, sz);
-        const __amdgpu_buffer_rsrc_t rd1 = plane_rsrc(dir + nvox, sz);
-        const __amdgpu_buffer_rsrc_t rd2 = plane_rsrc(dir + 2 * nvox, sz);
-        int r = first_rank;
+    const __amdgpu_buffer_rsrc_t rd0 = plane_rsrc(dir, sz);
+    const __amdgpu_buffer_rsrc_t rd1 = plane_rsrc(dir + nvox, sz);
+    const __amdgpu_buffer_rsrc_t rd2 = plane_rsrc(dir + 2 * nvox, sz);
+    int done = 0;
+    while (done < len) {   // uniform
+      const int take = min(CAP - n_list, len - done);
+      int q = first_q;
 #pragma unroll
-        for (int v = 0; v < VPT; v++) {
-          if (cur[v] != 0.0f) {
-            if (r >= pass_lo && r < pass_hi) {
-              const unsigned off = voff_of(v, row0, rows);
-              const int slot = r - pass_lo;
-              l_dat[slot] = make_float4(cur[v], buf_load(rd0, off), buf_load(rd1, off), buf_load(rd2, off));
-              l_pos[slot] = ((unsigned)(row0 + (rc_[v] >> 8)) << 8) | (unsigned)(rc_[v] & 0xff);
-              if (MASKED_SRC) l_mv[slot] = buf_load(plane_rsrc(mask_src, sz), off);
-            }
-            r++;
+      for (int v = 0; v < VPT; v++) {
+        if (cur[v] != 0.0f) {
+          if (q >= done && q < done + take) {
+            const unsigned off = voff_of(v, row0, rows);
+            const int slot = n_list + (q - done);
+            l_dat[slot] = make_float4(cur[v], buf_load(rd0, off), buf_load(rd1, off), buf_load(rd2, off));
+            l_pos[slot] = (unsigned)(rc_[v] & 0xff) | ((unsigned)(row0 + (rc_[v] >> 8)) << 8) | ((unsigned)ez << 16);
+            if (MASKED_SRC) l_mv[slot] = buf_load(plane_rsrc(mask_src, sz), off);
           }
+          q--;
         }
       }
-      __syncthreads();   // (2) list visible
-      const int n_pass = pass_hi - pass_lo;   // entries 0..n_pass-1, ascending position
-
-      // ---- consume from the end (descending position = ascending (jy, jx)) -------------------
-      for (int hi = n_pass; hi > 0; hi -= CHUNK) {
-        const int n_c = min(CHUNK, hi);
-        // phase A: lane l fetches the position of chunk entry l; every lane then tests all n_c
-        // senders (broadcast through v_readlane) against its own receiver.  bit k <=> entry hi-1-k.
-        const unsigned mypos = (lane < n_c) ? l_pos[hi - 1 - lane] : 0u;
-        unsigned hits_lo = 0u, hits_hi = 0u;
-        const int lim2 = h2 - jz * jz;   // jx^2 + jy^2 <= h^2 - jz^2
-#pragma unroll 1
-        for (int k0 = 0; k0 < n_c; k0 += 8) {   // wave-uniform trip count; 8 tests per trip
-          unsigned bits = 0u;
-#pragma unroll
-          for (int j = 0; j < 8; j++) {
-            const unsigned ps = (unsigned)__builtin_amdgcn_readlane((int)mypos, k0 + j);  // lanes >= n_c hold 0
-            const int jx = rxr - (int)(ps & 0xffu);
-            const int jy = ryr - (int)(ps >> 8);
-            const int d2 = jx * jx + jy * jy;
-            bits |= (d2 <= lim2) ? (1u << j) : 0u;
-          }
-          // entries beyond n_c (k0+j >= n_c) decode position 0, which may look like a hit: mask them
-          const int valid = n_c - k0;
-          if (valid < 8) bits &= (1u << valid) - 1u;
-          if (k0 < 32) hits_lo |= bits << (k0 & 31); else hits_hi |= bits << (k0 & 31);
-        }
-        unsigned long long hits = r_live ? (((unsigned long long)hits_hi << 32) | hits_lo) : 0ULL;
-        // phase B: every lane drains its own hits in order, loads of the next hit in flight
-        // while the current vote is accumulated
-        float4 d_c, t_c; float mv_c = 1.0f; int jx_c = 0, jy_c = 0;
-        auto load_hit = [&](int k, float4& d, float4& t, float& mvv, int& jx, int& jy) {
-          const int idx = hi - 1 - k;
-          const unsigned ps = l_pos[idx];
-          d = l_dat[idx];
-          if (MASKED_SRC) mvv = l_mv[idx];
-          jx = rxr - (int)(ps & 0xffu);
-          jy = ryr - (int)(ps >> 8);
-          const int ax = jx < 0 ? -jx : jx, ay = jy < 0 ? -jy : jy;
-          t = slice[ay * p.hp1 + ax];
-        };
-        bool have = hits != 0ULL;
-        if (have) {
-          const int k = __ffsll((long long)hits) - 1;
-          hits &= hits - 1;
-          load_hit(k, d_c, t_c, mv_c, jx_c, jy_c);
-        }
-        while (have) {
-          float4 d_n, t_n; float mv_n = 1.0f; int jx_n = 0, jy_n = 0;
-          const bool more = hits != 0ULL;
-          if (more) {
-            const int k = __ffsll((long long)hits) - 1;
-            hits &= hits - 1;
-            load_hit(k, d_n, t_n, mv_n, jx_n, jy_n);
-          }
-          float fv = t_c.x;
-          if (MASKED_SRC) fv = fv * mv_c;
-          if (fv != 0.0f) {
-            const float r0 = jx_c < 0 ? -t_c.y : t_c.y;
-            const float r1 = jy_c < 0 ? -t_c.z : t_c.z;
-            const float r2 = jz < 0 ? -t_c.w : t_c.w;
-            vote<MODE>(T, d_c.x, fv, r0, r1, r2, d_c.y, d_c.z, d_c.w, p.exponent, p.curves);
-          }
-          have = more;
-          d_c = d_n; t_c = t_n; mv_c = mv_n; jx_c = jx_n; jy_c = jy_n;
-        }
+      n_list += take;
+      done += take;
+      if (n_list == CAP) {
+        __syncthreads();   // list complete
+        flush(n_list, ez_first);
+        n_list = 0;
+        __syncthreads();   // everyone done reading before the list is refilled
       }
     }
-    // no barrier here: wave_tot and the slices are double-buffered, and barrier (1) of the next step
-    // orders every wave's consumption of this list before it is rewritten
+    // end of group (or of all planes): flush what is left
+    const bool last_of_group = (band == 0) && (((pl + 1) % p.group == 0) || (pl + 1 == nplanes));
+    if (last_of_group) {
+      __syncthreads();
+      if (n_list > 0) flush(n_list, ez_first);
+      n_list = 0;
+      __syncthreads();     // list and slices free for the next group
+    }
   }
 
   if (r_live) {
@@ -312,7 +340,7 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
                  i64 z_out1, int h, const float* w, const float* rhat, int exponent, bool curves,
                  bool* handled) {
   *handled = false;
-  if (h < 1 || h > 40) return VISFD_HIP_OK;  // octant slice + coordinates packing limits
+  if (h < 1 || h > 40) return VISFD_HIP_OK;  // octant slice + byte-packed coordinates limits
   if (nx * ny >= (1LL << 29)) return VISFD_HIP_OK;  // plane descriptors are 32-bit
   const int hp1 = h + 1, n = 2 * h + 1;
   // octant table: entry (az, ay, ax) = values at j = (+ax, +ay, +az); rhat(-j) = -rhat(j) and w is
@@ -338,13 +366,18 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
   p.band_rows = BAND_CAP / p.rw;
   if (p.band_rows > p.rh) p.band_rows = p.rh;
   p.nbands = (p.rh + p.band_rows - 1) / p.band_rows;
+  const int slice_bytes = (int)sizeof(float4) * hp1 * hp1;
+  p.group = SLICE_BYTES / slice_bytes;
+  if (p.group > MAX_GROUP) p.group = MAX_GROUP;
+  if (p.group < 1) p.group = 1;
+  if (const char* e = getenv("VISFD_HIP_TV_GROUP")) { const int g = atoi(e); if (g >= 1 && g <= p.group) p.group = g; }
   p.tiles_x = (int)((nx + TILE - 1) / TILE);
   p.tiles_y = (int)((ny + TILE - 1) / TILE);
   p.exponent = exponent;
   p.curves = curves ? 1 : 0;
   const i64 nblk = (i64)p.tiles_x * p.tiles_y * (z_out1 - z_out0);
   if (nblk > 0x7fffffffLL) return fail(VISFD_HIP_EINVAL, "volume too large for one launch");
-  const size_t lds = (size_t)24 * CAP + 2 * sizeof(float4) * (size_t)hp1 * hp1;
+  const size_t lds = (size_t)24 * CAP + (size_t)4 * NWORDS * NT + (size_t)p.group * slice_bytes;
   const int mode = (exponent == 4 && !curves) ? 0 : 1;
 #define VH_TV_LAUNCH(MSK, MD)                                                                        \
   do {                                                                                               \
