@@ -229,9 +229,20 @@ def main():
         g_ms = e0.elapsed_time(e1) / reps
         nv = shape[0] * shape[1] * shape[2]
         achieved = 8.0 * nv / (g_ms * 1e-3) / 1e9  # algorithmic 8 B/voxel
+        # HBM bytes per launch from PMC counters: measured offline with rocprofv3 (separate --pmc passes,
+        # tools/pmc_traffic.py) and committed under profiles/; only quoted for the shape it was measured on
+        traffic = None
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_gauss_traffic.json")))
+            if list(tr["shape"]) == [shape[0], shape[1], shape[2]]:
+                traffic = tr["traffic_bytes"]
+        except Exception:
+            pass
         roofline = {"bound": "hbm", "kernel": "gauss_fused_kernel<H=5> (separable 3-D Gaussian, sigma=2)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_gauss_traffic.json)",
+                    "algorithmic_bytes": 8 * nv,
                     "ms_per_launch": round(g_ms, 4), "voxels_per_launch": nv,
                     "note": "exact mul+add arithmetic (no FMA) makes this kernel VALU-bound, see DESIGN.md"}
 
