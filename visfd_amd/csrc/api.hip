@@ -66,7 +66,8 @@ int halfwidths_from_ratio(const float sigma[3], float ratio, int hw[3]) {
 }
 
 int gauss_dev(visfd_hip_ctx* ctx, const float* src, float* dst, const float* mask, i64 nx, i64 ny, i64 nz,
-              const float sigma[3], const int hw[3], bool normalize, SlabInfo slab, float* A_out) {
+              const float sigma[3], const int hw[3], bool normalize, SlabInfo slab, float* A_out,
+              const float* minuend = nullptr, float log_scale = 1.0f, bool* epilogue_done = nullptr) {
   VH_REQUIRE(ctx && src && dst && sigma && hw, "null argument");
   std::vector<float> t[3];
   for (int d = 0; d < 3; d++) {
@@ -76,15 +77,24 @@ int gauss_dev(visfd_hip_ctx* ctx, const float* src, float* dst, const float* mas
     host_gauss_taps(sigma[d], hw[d], t[d].data());
   }
   return dev_separable3d(ctx, src, dst, mask, nx, ny, nz, t[0].data(), hw[0], t[1].data(), hw[1],
-                         t[2].data(), hw[2], normalize, slab, A_out);
+                         t[2].data(), hw[2], normalize, slab, A_out, minuend, log_scale, epilogue_done);
 }
 
-// ApplyDog with a caller-provided temp volume (filter3d.hpp:1338-1402)
+// ApplyDog with a caller-provided temp volume (filter3d.hpp:1338-1402); with do_scale it is the body of
+// ApplyLog (filter3d.hpp:1466-1498).  dst = G_a(src); then the second Gaussian writes
+// (dst - G_b(src)) [* scale] straight into dst when the single-sweep kernel applies, else via tmp.
 int dog_dev(visfd_hip_ctx* ctx, const float* src, float* dst, float* tmp, const float* mask, i64 nx, i64 ny,
             i64 nz, const float sa[3], const float sb[3], const int hw[3], float scale, bool do_scale,
             float* A, float* B) {
   const SlabInfo whole = {0, nz};
   VH_TRY(gauss_dev(ctx, src, dst, mask, nx, ny, nz, sa, hw, true, whole, A));
+  {
+    // the fused epilogue reads and writes the same element of dst in one thread: in-place is safe;
+    // without scaling the multiplier is 1.0f, which is exact
+    bool fused = false;
+    VH_TRY(gauss_dev(ctx, src, dst, mask, nx, ny, nz, sb, hw, true, whole, B, dst, do_scale ? scale : 1.0f, &fused));
+    if (fused) return VISFD_HIP_OK;
+  }
   VH_TRY(gauss_dev(ctx, src, tmp, mask, nx, ny, nz, sb, hw, true, whole, B));
   return dev_sub_scale(ctx, dst, tmp, nx * ny * nz, scale, do_scale);
 }

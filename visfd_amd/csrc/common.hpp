@@ -101,7 +101,10 @@ struct SlabInfo {   // Z-slab placement for multi-GPU runs; whole volume: z_lo=0
 
 int dev_separable3d(visfd_hip_ctx* ctx, const float* src, float* dst, const float* mask, i64 nx,
                     i64 ny, i64 nz, const float* tx, int hx, const float* ty, int hy,
-                    const float* tz, int hz, bool normalize, SlabInfo slab, float* A_out);
+                    const float* tz, int hz, bool normalize, SlabInfo slab, float* A_out,
+                    // optional DoG/LoG epilogue: dst = (minuend - G(src)) * log_scale, fused into the
+                    // single-sweep kernel when it applies (*epilogue_done tells whether it was)
+                    const float* minuend = nullptr, float log_scale = 1.0f, bool* epilogue_done = nullptr);
 // dst = (a - b) * scale  with two roundings (filter3d.hpp:1387-1390,1495-1498); scale==1: no multiply
 int dev_sub_scale(visfd_hip_ctx* ctx, float* a_inout, const float* b, i64 n, float scale, bool do_scale);
 

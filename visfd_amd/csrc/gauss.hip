@@ -109,21 +109,21 @@ int fill_taps(Taps* T, const float* t, int h) {
   int launch_gauss_fused_h##HH(visfd_hip_ctx* ctx, const float* src, float* dst, i64 nx, i64 ny,   \
                                i64 nz, const Taps& tx, const Taps& ty, const Taps& tz,            \
                                const float* Dx, const float* Dy, const float* Dz, i64 dz_offset,  \
-                               bool normalize, int cfg);
+                               bool normalize, int cfg, const float* minuend, float log_scale);
 VH_DECL_FUSED(1) VH_DECL_FUSED(2) VH_DECL_FUSED(3) VH_DECL_FUSED(4) VH_DECL_FUSED(5)
 VH_DECL_FUSED(6) VH_DECL_FUSED(7) VH_DECL_FUSED(8) VH_DECL_FUSED(9) VH_DECL_FUSED(10)
 #undef VH_DECL_FUSED
 
 // The single-sweep kernel covers the unmasked case with equal half-widths 1..10 on the three axes
-// (any sigma per axis), even nx, and planes below 2 GiB; everything else takes the 3-pass path.
+// (any sigma per axis), nx a multiple of 4, and planes below 2 GiB; everything else takes the 3-pass path.
 static int dev_gauss_fused(visfd_hip_ctx* ctx, const float* src, float* dst, i64 nx, i64 ny, i64 nz,
                            const Taps& tx, const Taps& ty, const Taps& tz, const float* Dx,
                            const float* Dy, const float* Dz, i64 dz_offset, bool normalize,
-                           bool* handled) {
+                           const float* minuend, float log_scale, bool* handled) {
   *handled = false;
   const int H = tx.h;
   if (ty.h != H || tz.h != H || H < 1 || H > 10) return VISFD_HIP_OK;
-  if ((nx & 1) || nx * ny >= (1LL << 29) || nz >= (1LL << 31)) return VISFD_HIP_OK;
+  if ((nx & 3) || nx * ny >= (1LL << 29) || nz >= (1LL << 31)) return VISFD_HIP_OK;
   if (src == dst) return VISFD_HIP_OK;  // in place: 3-pass path through scratch volumes
   const char* force = getenv("VISFD_HIP_GAUSS_3PASS");
   if (force && force[0] == '1') return VISFD_HIP_OK;
@@ -131,7 +131,7 @@ static int dev_gauss_fused(visfd_hip_ctx* ctx, const float* src, float* dst, i64
   if (const char* e = getenv("VISFD_HIP_GAUSS_CFG")) cfg = atoi(e);
   *handled = true;
   switch (H) {
-#define VH_CASE(HH) case HH: return launch_gauss_fused_h##HH(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, cfg);
+#define VH_CASE(HH) case HH: return launch_gauss_fused_h##HH(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, cfg, minuend, log_scale);
     VH_CASE(1) VH_CASE(2) VH_CASE(3) VH_CASE(4) VH_CASE(5) VH_CASE(6) VH_CASE(7) VH_CASE(8) VH_CASE(9) VH_CASE(10)
 #undef VH_CASE
   }
@@ -141,7 +141,9 @@ static int dev_gauss_fused(visfd_hip_ctx* ctx, const float* src, float* dst, i64
 
 int dev_separable3d(visfd_hip_ctx* ctx, const float* src, float* dst, const float* mask, i64 nx,
                     i64 ny, i64 nz, const float* tx, int hx, const float* ty, int hy,
-                    const float* tz, int hz, bool normalize, SlabInfo slab, float* A_out) {
+                    const float* tz, int hz, bool normalize, SlabInfo slab, float* A_out,
+                    const float* minuend, float log_scale, bool* epilogue_done) {
+  if (epilogue_done) *epilogue_done = false;
   VH_TRY(check_dims(nx, ny, nz));
   Taps Tx, Ty, Tz;
   VH_TRY(fill_taps(&Tx, tx, hx));
@@ -174,8 +176,17 @@ int dev_separable3d(visfd_hip_ctx* ctx, const float* src, float* dst, const floa
   if (!mask) {
     bool handled = false;
     VH_TRY(dev_gauss_fused(ctx, src, dst, nx, ny, nz, Tx, Ty, Tz, Dx, Dy, Dz, slab.z_lo, normalize,
-                           &handled));
-    if (handled) return VISFD_HIP_OK;
+                           minuend, log_scale, &handled));
+    if (handled) {
+      if (epilogue_done) *epilogue_done = (minuend != nullptr);
+      return VISFD_HIP_OK;
+    }
+  }
+  // the DoG/LoG epilogue exists only in the single-sweep kernel: when it does not apply, nothing is
+  // computed here (dst may alias the minuend) and the caller takes the two-volume route
+  if (minuend) {
+    if (!epilogue_done) return fail(VISFD_HIP_EINVAL, "internal: unfused epilogue request");
+    return VISFD_HIP_OK;
   }
 
   float *A = nullptr, *B = nullptr;

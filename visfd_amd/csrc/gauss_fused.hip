@@ -17,8 +17,8 @@
 //     an out-of-range offset and planes outside the image a zero-length descriptor, both of which
 //     return 0.0f -- no branches, no exec masking;
 //   * the Z-filtered haloed plane goes to LDS; Y pass: two adjacent x per lane (ds_read_b64 down a
-//     column), result rows to LDS; X pass: two adjacent outputs per lane from one ds_read_b64
-//     window, normalise, 8-byte buffer store (x-contiguous across lanes, dropped by the range
+//     column), result rows to LDS; X pass: four adjacent outputs per lane from ds_read_b128
+//     windows, normalise, 16-byte buffer store (x-contiguous across lanes, dropped by the range
 //     check outside the image).
 // Zero extension: a 0.0f sample adds an exact +0.0 to the accumulator, which equals skipping the
 // term as the reference does (filter1d.hpp:98-99) for finite data.
@@ -43,11 +43,18 @@ struct FusedCfg {
   static constexpr int HY = TY + 2 * H;
   static constexpr int NCOL = HX * HY;
   static constexpr int NC = (NCOL + NT - 1) / NT;  // ring columns per thread
-  static constexpr int SX = HX + 2;                // LDS row stride in floats (even)
-  static constexpr int YTASKS = (HX / 2) * TY;     // (x pair, y) outputs of the Y pass
-  static constexpr int YROUNDS = (YTASKS + NT - 1) / NT;
-  static constexpr int XTASKS = (TX / 2) * TY;
-  static constexpr int XROUNDS = (XTASKS + NT - 1) / NT;
+  static constexpr int SX = ((HX + 2 + 3) / 4) * 4; // LDS row stride in floats (16-byte rows)
+  // Y and X passes are WAVE-LOCAL: wave w owns output rows [w*RPW, (w+1)*RPW) of the tile, computes their
+  // Y-filtered rows into sY and then reads only those rows back for the X pass (no workgroup barrier
+  // between the two passes)
+  static constexpr int NW = NT / 64;
+  static constexpr int RPW = TY / NW;              // rows per wave
+  static constexpr int YTASKS = (HX / 2) * RPW;    // per wave: (x pair, row)
+  static constexpr int YROUNDS = (YTASKS + 63) / 64;
+  static constexpr int XV = 4;                     // outputs per lane in the X pass
+  static constexpr int XTASKS = (TX / XV) * RPW;   // per wave
+  static constexpr int XROUNDS = (XTASKS + 63) / 64;
+  static constexpr int XWIN4 = (XV + 2 * H + 3) / 4;  // float4 reads covering the X window
   static constexpr int SZ_FLOATS = HY * SX + 64;   // + a dump area for padding ring slots
   static constexpr int SY_FLOATS = TY * SX;
 };
@@ -66,10 +73,11 @@ __global__ void __launch_bounds__(NT)
 gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH<H> tz, TapsH<H> ty_,
                    TapsH<H> tx_, const float* __restrict__ Dx, const float* __restrict__ Dy,
                    const float* __restrict__ Dz, i64 dz_offset, int nx, int ny, int nz, int zchunk,
-                   int tiles_x, int tiles_y) {
+                   int tiles_x, int tiles_y, const float* __restrict__ minuend, float log_scale) {
   typedef FusedCfg<H, TX, TY, NT> C;
   constexpr int W = C::W;
-  __shared__ __attribute__((aligned(16))) float sZ[C::SZ_FLOATS];
+  static_assert(TY % (NT / 64) == 0, "tile rows must divide evenly among the waves");
+  __shared__ __attribute__((aligned(16))) float sZ2[2][C::SZ_FLOATS];   // double-buffered: see the march loop
   __shared__ __attribute__((aligned(16))) float sY[C::SY_FLOATS];
   const TapsH<H>& ty = ISO ? tz : ty_;
   const TapsH<H>& tx = ISO ? tz : tx_;
@@ -105,28 +113,30 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
     col_off[c] = inside ? (unsigned)(gy * nx + gx) * 4u : OOB;
     lds_off[c] = slot ? (cy * C::SX + cx) : (C::HY * C::SX + (tid & 63));
   }
+  const int lane = tid & 63, wave = tid >> 6;
   int y_off[C::YROUNDS];    // LDS float offset of (row y, column pair xp); -1: idle lane
 #pragma unroll
   for (int r = 0; r < C::YROUNDS; r++) {
-    const int task = tid + r * NT;
-    const int y = task / (C::HX / 2), xp = task - y * (C::HX / 2);
-    y_off[r] = (task < C::YTASKS) ? (y * C::SX + 2 * xp) : -1;
+    const int task = lane + r * 64;
+    const int yy = task / (C::HX / 2), xp = task - yy * (C::HX / 2);
+    y_off[r] = (task < C::YTASKS) ? ((wave * C::RPW + yy) * C::SX + 2 * xp) : -1;
   }
   int x_off[C::XROUNDS];
-  unsigned o_off[C::XROUNDS];  // byte offset of the output pair inside a plane (OOB outside)
-  float dxy0[C::XROUNDS], dxy1[C::XROUNDS];
+  unsigned o_off[C::XROUNDS];  // byte offset of the output quad inside a plane (OOB outside)
+  float dxy[C::XROUNDS][C::XV];
 #pragma unroll
   for (int r = 0; r < C::XROUNDS; r++) {
-    const int task = tid + r * NT;
-    const int y = task / (TX / 2), xp = task - y * (TX / 2);
-    const int gx = x0 + 2 * xp, gy = y0 + y;
-    const bool ok = (task < C::XTASKS) && gx < nx && gy < ny;  // nx is even: gx+1 < nx too
-    x_off[r] = (task < C::XTASKS) ? (y * C::SX + 2 * xp) : 0;
+    const int task = lane + r * 64;
+    const int yy = task / (TX / C::XV), xq = task - yy * (TX / C::XV);
+    const int y = wave * C::RPW + yy;
+    const int gx = x0 + C::XV * xq, gy = y0 + y;
+    const bool ok = (task < C::XTASKS) && gx < nx && gy < ny;  // nx % 4 == 0: the whole quad is inside
+    x_off[r] = (task < C::XTASKS) ? (y * C::SX + C::XV * xq) : 0;
     o_off[r] = ok ? (unsigned)(gy * nx + gx) * 4u : OOB;
     if (NORMALIZE) {
       const float dy = ok ? Dy[gy] : 1.0f;
-      dxy0[r] = (ok ? Dx[gx] : 1.0f) * dy;       // (Dx*Dy) first, then *Dz (filter3d.hpp:1016-1018)
-      dxy1[r] = (ok ? Dx[gx + 1] : 1.0f) * dy;
+#pragma unroll
+      for (int k = 0; k < C::XV; k++) dxy[r][k] = (ok ? Dx[gx + k] : 1.0f) * dy;  // (Dx*Dy) first, then *Dz (filter3d.hpp:1016-1018)
     }
   }
 
@@ -149,6 +159,7 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
     for (int u = 0; u < W; u++) {
       const int z = zbase + u;
       if (z < ze) {  // uniform across the workgroup
+        float* sZ = sZ2[(z - zs) & 1];
         // Z pass: j ascending <=> plane z-j descending: newest first
 #pragma unroll
         for (int c = 0; c < C::NC; c++) {
@@ -159,7 +170,7 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
             const float term = tz.t[jj] * ring[c][(u + 1 + (W - 1 - jj)) % W];
             acc = acc + term;
           }
-          sZ[lds_off[c]] = acc;
+          sZ[lds_off[c]] = acc;   // sZ = sZ2[step parity]
         }
         // request the plane of the next step (z+1+H) into the slot the oldest plane just vacated
         {
@@ -189,45 +200,62 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
             *reinterpret_cast<float2*>(&sY[y_off[r]]) = make_float2(a0, a1);
           }
         }
-        __syncthreads();
-        // X pass: two adjacent outputs per lane; haloed source index x+2H (j=-H) down to x (j=+H)
+        __builtin_amdgcn_wave_barrier();   // same wave wrote these sY rows: LDS ops of a wave execute in order
+        // X pass: four adjacent outputs per lane; haloed source index x+2H (j=-H) down to x (j=+H)
         const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(dst + (i64)z * plane), 0, plane_bytes, 0x00020000);
         float dz = 1.0f;
         if (NORMALIZE) dz = Dz[z + dz_offset];
 #pragma unroll
         for (int r = 0; r < C::XROUNDS; r++) {
-          const float* base = &sY[x_off[r]];
-          float v[2 * H + 2];
+          const float4* base = reinterpret_cast<const float4*>(&sY[x_off[r]]);
+          float v[4 * C::XWIN4];
 #pragma unroll
-          for (int k = 0; k < H + 1; k++) {
-            const float2 q = *reinterpret_cast<const float2*>(base + 2 * k);
-            v[2 * k] = q.x;
-            v[2 * k + 1] = q.y;
+          for (int k = 0; k < C::XWIN4; k++) {
+            const float4 q = base[k];
+            v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
           }
-          float a0 = 0.0f, a1 = 0.0f;
+          float a[C::XV];
+#pragma unroll
+          for (int k = 0; k < C::XV; k++) a[k] = 0.0f;
 #pragma unroll
           for (int jj = 0; jj < W; jj++) {
             const float t = tx.t[jj];
-            const float p0 = t * v[2 * H - jj];
-            const float p1 = t * v[2 * H - jj + 1];
-            a0 = a0 + p0;
-            a1 = a1 + p1;
+#pragma unroll
+            for (int k = 0; k < C::XV; k++) {
+              const float pr = t * v[2 * H - jj + k];
+              a[k] = a[k] + pr;
+            }
           }
           if (NORMALIZE) {
-            const float d0 = dxy0[r] * dz;
-            const float d1 = dxy1[r] * dz;
-            a0 = a0 / d0;
-            a1 = a1 / d1;
+#pragma unroll
+            for (int k = 0; k < C::XV; k++) {
+              const float d = dxy[r][k] * dz;
+              a[k] = a[k] / d;
+            }
           }
-          typedef float v2f __attribute__((ext_vector_type(2)));
-          typedef unsigned v2u __attribute__((ext_vector_type(2)));
-          v2f out = {a0, a1};
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, out), ro, (int)o_off[r], 0, 0);
+          typedef float v4f __attribute__((ext_vector_type(4)));
+          typedef unsigned v4u __attribute__((ext_vector_type(4)));
+          if (minuend) {
+            // DoG/LoG epilogue fused into the second Gaussian: out = (G_a - G_b) * scale with the two
+            // roundings of filter3d.hpp:1387-1390 and :1495-1498 (wave-uniform branch)
+            const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(minuend + (i64)z * plane), 0, plane_bytes, 0x00020000);
+            const v4u mraw = __builtin_amdgcn_raw_buffer_load_b128(rm, (int)o_off[r], 0, 0);
+            const v4f m = __builtin_bit_cast(v4f, mraw);
+#pragma unroll
+            for (int k = 0; k < C::XV; k++) {
+              const float dd = m[k] - a[k];
+              a[k] = dd * log_scale;
+            }
+          }
+          v4f out = {a[0], a[1], a[2], a[3]};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, out), ro, (int)o_off[r], 0, 0);
         }
-        // no barrier here: the next Z pass writes sZ only after every thread has passed the barrier
-        // that follows this Y pass (sZ reads done); the next Y pass writes sY only after the barrier
-        // that follows the next Z pass (sY reads done).
+        // One workgroup barrier per plane: sZ is double-buffered, so a wave may start the next Z pass
+        // (writing the other buffer) while slower waves still read this one; that buffer's readers
+        // (plane z-1) all finished before they arrived at this step's barrier.  sY rows are private
+        // to a wave.
       }
     }
   }
@@ -236,7 +264,7 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
 template <int H, int TX, int TY, int NT>
 int launch_cfg(visfd_hip_ctx* ctx, const float* src, float* dst, i64 nx, i64 ny, i64 nz,
                const Taps& tx, const Taps& ty, const Taps& tz, const float* Dx, const float* Dy,
-               const float* Dz, i64 dz_offset, bool normalize) {
+               const float* Dz, i64 dz_offset, bool normalize, const float* minuend, float log_scale) {
   TapsH<H> a, b, c;
   bool iso = true;
   for (int k = 0; k < 2 * H + 1; k++) {
@@ -259,7 +287,8 @@ int launch_cfg(visfd_hip_ctx* ctx, const float* src, float* dst, i64 nx, i64 ny,
   dim3 grid((unsigned)nblk), block(NT);
 #define VH_GO(NORM, ISOV)                                                                        \
   gauss_fused_kernel<H, TX, TY, NT, NORM, ISOV><<<grid, block, 0, ctx->stream>>>(                \
-      src, dst, a, b, c, Dx, Dy, Dz, dz_offset, (int)nx, (int)ny, (int)nz, (int)zchunk, tiles_x, tiles_y)
+      src, dst, a, b, c, Dx, Dy, Dz, dz_offset, (int)nx, (int)ny, (int)nz, (int)zchunk, tiles_x, tiles_y,  \
+      minuend, log_scale)
   if (normalize) { if (iso) VH_GO(true, true); else VH_GO(true, false); }
   else           { if (iso) VH_GO(false, true); else VH_GO(false, false); }
 #undef VH_GO
@@ -276,22 +305,23 @@ int launch_cfg(visfd_hip_ctx* ctx, const float* src, float* dst, i64 nx, i64 ny,
 int VH_CAT(launch_gauss_fused_h, VH_FUSED_H)(visfd_hip_ctx* ctx, const float* src, float* dst, i64 nx,
                                             i64 ny, i64 nz, const Taps& tx, const Taps& ty,
                                             const Taps& tz, const float* Dx, const float* Dy,
-                                            const float* Dz, i64 dz_offset, bool normalize, int cfg) {
+                                            const float* Dz, i64 dz_offset, bool normalize, int cfg,
+                                            const float* minuend, float log_scale) {
   constexpr int H = VH_FUSED_H;
 #ifdef VH_FUSED_EXTRA_CFGS   // development: alternative tilings selectable at run time
-  if (cfg == 1) return launch_cfg<H, 64, 16, 512>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize);
-  if (cfg == 2) return launch_cfg<H, 64, 32, 512>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize);
-  if (cfg == 3) return launch_cfg<H, 128, 16, 512>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize);
-  if (cfg == 4) return launch_cfg<H, 128, 32, 1024>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize);
-  if (cfg == 5) return launch_cfg<H, 32, 32, 256>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize);
-  if (cfg == 6) return launch_cfg<H, 64, 32, 1024>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize);
+  if (cfg == 1) return launch_cfg<H, 64, 16, 512>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
+  if (cfg == 2) return launch_cfg<H, 64, 32, 512>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
+  if (cfg == 3) return launch_cfg<H, 128, 16, 512>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
+  if (cfg == 4) return launch_cfg<H, 128, 32, 1024>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
+  if (cfg == 5) return launch_cfg<H, 32, 32, 256>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
+  if (cfg == 6) return launch_cfg<H, 64, 32, 1024>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
 #endif
   (void)cfg;
   // tilings picked from a sweep on MI355X (1024^3, gpurun_out/perf3.log): wider tiles cut the halo
   // recomputation of the Z and Y passes, which is what bounds this kernel (VALU, not HBM)
-  if (H <= 3) return launch_cfg<H, 128, 16, 512>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize);
-  if (H <= 6) return launch_cfg<H, 128, 32, 1024>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize);
-  return launch_cfg<H, 64, 32, 1024>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize);
+  if (H <= 3) return launch_cfg<H, 128, 16, 512>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
+  if (H <= 6) return launch_cfg<H, 128, 32, 1024>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
+  return launch_cfg<H, 64, 32, 1024>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
 }
 
 }  // namespace vh
