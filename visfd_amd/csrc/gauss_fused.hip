@@ -319,9 +319,12 @@ int VH_CAT(launch_gauss_fused_h, VH_FUSED_H)(visfd_hip_ctx* ctx, const float* sr
   (void)cfg;
   // tilings picked from a sweep on MI355X (1024^3, gpurun_out/perf3.log): wider tiles cut the halo
   // recomputation of the Z and Y passes, which is what bounds this kernel (VALU, not HBM)
-  if (H <= 3) return launch_cfg<H, 128, 16, 512>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
-  if (H <= 6) return launch_cfg<H, 128, 32, 1024>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
-  return launch_cfg<H, 64, 32, 1024>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
+  if constexpr (H <= 3)
+    return launch_cfg<H, 128, 16, 512>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
+  else if constexpr (H <= 6)
+    return launch_cfg<H, 128, 32, 1024>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
+  else
+    return launch_cfg<H, 64, 32, 1024>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
 }
 
 }  // namespace vh

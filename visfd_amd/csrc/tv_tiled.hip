@@ -18,9 +18,10 @@
 //     column.  Phase B: every lane walks ITS OWN hit words in order and accumulates the votes (next
 //     hit's LDS reads in flight during the current vote), so lanes spend their time on real votes
 //     instead of idling under a sparse exec mask; long lists even out the per-lane hit counts;
-//   * weights and unit displacements come from octant slices in LDS: w(j) depends on
-//     (|jx|,|jy|,|jz|) only and rhat(-j) = -rhat(j) exactly, so signs are re-applied with one
-//     v_and_or per component.
+//   * weights and unit displacements come from LDS copies of the (2h+1)^2 table slices of the
+//     group's planes (w, rhat_x, rhat_y, rhat_z as one float4, signs included).  Because the table
+//     index is linear in the offset j = receiver - sender, the byte address of a vote's table entry
+//     is  R(lane) - E(sender):  one subtraction per vote, E precomputed when the sender is listed.
 //
 // Order of accumulation per receiver: jz ascending (plane order), then jy, jx ascending, exactly
 // the reference's; each vote is the same chain of float multiplies and adds (no FMA), so tensors
@@ -38,11 +39,11 @@ constexpr int TILE = 16;
 constexpr int VPT = 7;               // region voxels per thread per band
 constexpr int BAND_CAP = NT * VPT;   // 1792 region voxels per band
 #ifndef VH_TV_CAP
-#define VH_TV_CAP 512
+#define VH_TV_CAP 256
 #endif
 constexpr int CAP = VH_TV_CAP;       // list entries held in LDS between flushes
 constexpr int NWORDS = CAP / 32;
-constexpr int SLICE_BYTES = 24 * 1024;  // LDS budget for the octant slices of one plane group
+constexpr int SLICE_BYTES = 21 * 1024;  // LDS budget for the table slices of one plane group
 constexpr int MAX_GROUP = 4;   // more planes per group lengthen the lists but cost LDS (occupancy)
 constexpr unsigned OOB = 0x7ffffff0u;  // byte offset beyond any plane descriptor: reads give 0
 
@@ -100,13 +101,15 @@ template <bool MASKED_SRC, int MODE>
 __global__ void __launch_bounds__(NT)
 tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, float* __restrict__ ten,
                 const float* __restrict__ mask_src, const float* __restrict__ mask_dst,
-                const float4* __restrict__ octant /* [(h+1)^3] : w, |rx|, |ry|, |rz| */, TiledParams p) {
+                const float4* __restrict__ table /* [(2h+1)^3] : w, rhat_x, rhat_y, rhat_z at j */,
+                TiledParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4* l_dat = reinterpret_cast<float4*>(smem);                        // sal, n0, n1, n2
   unsigned* l_pos = reinterpret_cast<unsigned*>(smem + 16 * CAP);         // ex | ey << 8 | ez << 16
   float* l_mv = reinterpret_cast<float*>(smem + 20 * CAP);                // source-mask value
-  unsigned* hitw = reinterpret_cast<unsigned*>(smem + 24 * CAP);          // [NWORDS][NT] hit words
-  float4* slices = reinterpret_cast<float4*>(smem + 24 * CAP + 4 * NWORDS * NT);  // [group][(h+1)^2]
+  int* l_e16 = reinterpret_cast<int*>(smem + 24 * CAP);                   // 16 * (ey*S + ex - slot*S*S)
+  unsigned* hitw = reinterpret_cast<unsigned*>(smem + 28 * CAP);          // [NWORDS][NT] hit words
+  unsigned char* slices = smem + 28 * CAP + 4 * NWORDS * NT;              // [group][(2h+1)^2] float4
   __shared__ int wave_tot[2][NT / 64];
 
   const int tid = threadIdx.x;
@@ -118,7 +121,8 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
   const int rz = p.z_out0 + (int)(b / p.tiles_y);
   const int x0 = tile_x * TILE, y0 = tile_y * TILE;
   const int h = p.h;
-  const int nsl = p.hp1 * p.hp1;
+  const int S = 2 * h + 1;       // table row length
+  const int nsl = S * S;         // float4 entries per slice
   const i64 plane = (i64)p.nx * p.ny;
   const i64 nvox = plane * p.nz;
 
@@ -132,6 +136,9 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
   const int h2 = h * h;
   // byte-packed receiver position, biased by 128 per byte so that recv_b - pos never borrows
   const unsigned recv_b = (unsigned)(lx + h + 128) | ((unsigned)(ly + h + 128) << 8) | ((unsigned)(h + 128) << 16);
+
+  // (jy+h)*S + (jx+h) with jx = lx+h-ex, jy = ly+h-ey  =  [(ly+2h)*S + lx+2h] - [ey*S + ex]
+  const int r16 = 16 * ((ly + 2 * h) * S + lx + 2 * h);
 
   float T[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 
@@ -216,23 +223,14 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
       const int bpos = __ffs((int)cur) - 1;
       cur &= cur - 1u;
       const int idx = (w << 5) + bpos;
-      const unsigned ps = l_pos[idx];
       const float4 d = l_dat[idx];
-      const unsigned t = (recv_b - ps) ^ 0x00808080u;
-      const int jx = (int)(signed char)(t & 0xffu);
-      const int jy = (int)(signed char)((t >> 8) & 0xffu);
-      const int jz = (int)(signed char)((t >> 16) & 0xffu);
-      const int ax = jx < 0 ? -jx : jx, ay = jy < 0 ? -jy : jy;
-      const int slot = ez_first - h + jz;                       // ez = h - jz
-      const float4 tw = slices[__mul24(slot, nsl) + __mul24(ay, p.hp1) + ax];
+      // table entry of j = receiver - sender in the sender's plane slice: address R16 - E16
+      const float4 tw = *reinterpret_cast<const float4*>(slices + (r16 - l_e16[idx]));
       float fv = tw.x;
       if (MASKED_SRC) fv = fv * l_mv[idx];
-      if (fv != 0.0f) {
-        const float r0 = with_sign_of(tw.y, jx);
-        const float r1 = with_sign_of(tw.z, jy);
-        const float r2 = with_sign_of(tw.w, jz);
-        vote<MODE>(T, d.x, fv, r0, r1, r2, d.y, d.z, d.w, p.exponent, p.curves);
-      }
+      // A zero weight (taps on the rim of the spherical support, feature.hpp:2276) needs no branch: the
+      // vote is then (+-0)*m*m and adding +-0 leaves the accumulators bit-for-bit unchanged.
+      vote<MODE>(T, d.x, fv, tw.y, tw.z, tw.w, d.y, d.z, d.w, p.exponent, p.curves);
     }
   };
 
@@ -255,14 +253,14 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
 
     if (new_group) {
       // previous group completely flushed (n_list == 0, barrier at the end of flush block below):
-      // load the |jz| slices of this group's planes
+      // copy the table slices of this group's planes (plane s of the group: ez = ez_first - s, jz = h - ez)
       ez_first = ez;
       const int g_planes = min(p.group, nplanes - pl);
+      float4* sl4 = reinterpret_cast<float4*>(slices);
       for (int i = tid; i < g_planes * nsl; i += NT) {
-        const int s = i / nsl, r = i - s * nsl;
-        const int jz = h - (ez_first - s);                  // plane s of the group has ez = ez_first - s
-        const int az = jz < 0 ? -jz : jz;
-        slices[i] = octant[(i64)az * nsl + r];
+        const int sidx = i / nsl, r = i - sidx * nsl;
+        const int jz = h - (ez_first - sidx);
+        sl4[i] = table[(i64)(jz + h) * nsl + r];
       }
     }
 
@@ -302,7 +300,9 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
             const unsigned off = voff_of(v, row0, rows);
             const int slot = n_list + (q - done);
             l_dat[slot] = make_float4(cur[v], buf_load(rd0, off), buf_load(rd1, off), buf_load(rd2, off));
-            l_pos[slot] = (unsigned)(rc_[v] & 0xff) | ((unsigned)(row0 + (rc_[v] >> 8)) << 8) | ((unsigned)ez << 16);
+            const int ex = rc_[v] & 0xff, ey = row0 + (rc_[v] >> 8);
+            l_pos[slot] = (unsigned)ex | ((unsigned)ey << 8) | ((unsigned)ez << 16);
+            l_e16[slot] = 16 * (ey * S + ex - (ez_first - ez) * nsl);
             if (MASKED_SRC) l_mv[slot] = buf_load(plane_rsrc(mask_src, sz), off);
           }
           q--;
@@ -340,22 +340,18 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
                  i64 z_out1, int h, const float* w, const float* rhat, int exponent, bool curves,
                  bool* handled) {
   *handled = false;
-  if (h < 1 || h > 40) return VISFD_HIP_OK;  // octant slice + byte-packed coordinates limits
+  if (h < 1 || h > 40) return VISFD_HIP_OK;  // table slices in LDS + byte-packed coordinates limits
   if (nx * ny >= (1LL << 29)) return VISFD_HIP_OK;  // plane descriptors are 32-bit
   const int hp1 = h + 1, n = 2 * h + 1;
-  // octant table: entry (az, ay, ax) = values at j = (+ax, +ay, +az); rhat(-j) = -rhat(j) and w is
-  // even in every component (filter3d.hpp:569-573, feature.hpp:2473-2478)
-  std::vector<float4> oct((size_t)hp1 * hp1 * hp1);
-  for (int az = 0; az <= h; az++)
-    for (int ay = 0; ay <= h; ay++)
-      for (int ax = 0; ax <= h; ax++) {
-        const size_t k = ((size_t)(az + h) * n + (ay + h)) * n + (ax + h);
-        oct[((size_t)az * hp1 + ay) * hp1 + ax] = make_float4(w[k], rhat[3 * k], rhat[3 * k + 1], rhat[3 * k + 2]);
-      }
-  float4* doct = nullptr;
-  VH_TRY(ws(ctx, WS_TVTAB, oct.size(), &doct));
+  // full signed table, one float4 per offset j (z, y, x order as built by filter3d.hpp:563-578 and
+  // feature.hpp:2470-2478)
+  const size_t m = (size_t)n * n * n;
+  std::vector<float4> tab(m);
+  for (size_t k = 0; k < m; k++) tab[k] = make_float4(w[k], rhat[3 * k], rhat[3 * k + 1], rhat[3 * k + 2]);
+  float4* dtab = nullptr;
+  VH_TRY(ws(ctx, WS_TVTAB, tab.size(), &dtab));
   hipStream_t st = ctx->stream;
-  VH_HIP(hipMemcpyAsync(doct, oct.data(), sizeof(float4) * oct.size(), hipMemcpyHostToDevice, st));
+  VH_HIP(hipMemcpyAsync(dtab, tab.data(), sizeof(float4) * tab.size(), hipMemcpyHostToDevice, st));
   VH_HIP(hipStreamSynchronize(st));
 
   TiledParams p;
@@ -366,7 +362,7 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
   p.band_rows = BAND_CAP / p.rw;
   if (p.band_rows > p.rh) p.band_rows = p.rh;
   p.nbands = (p.rh + p.band_rows - 1) / p.band_rows;
-  const int slice_bytes = (int)sizeof(float4) * hp1 * hp1;
+  const int slice_bytes = (int)sizeof(float4) * n * n;
   p.group = SLICE_BYTES / slice_bytes;
   if (p.group > MAX_GROUP) p.group = MAX_GROUP;
   if (p.group < 1) p.group = 1;
@@ -377,14 +373,15 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
   p.curves = curves ? 1 : 0;
   const i64 nblk = (i64)p.tiles_x * p.tiles_y * (z_out1 - z_out0);
   if (nblk > 0x7fffffffLL) return fail(VISFD_HIP_EINVAL, "volume too large for one launch");
-  const size_t lds = (size_t)24 * CAP + (size_t)4 * NWORDS * NT + (size_t)p.group * slice_bytes;
+  const size_t lds = (size_t)28 * CAP + (size_t)4 * NWORDS * NT + (size_t)p.group * slice_bytes;
+  if (lds > 150 * 1024) return VISFD_HIP_OK;   // window too wide for the LDS slices: baseline kernel
   const int mode = (exponent == 4 && !curves) ? 0 : 1;
 #define VH_TV_LAUNCH(MSK, MD)                                                                        \
   do {                                                                                               \
     VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tv_tiled_kernel<MSK, MD>),             \
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
     tv_tiled_kernel<MSK, MD><<<dim3((unsigned)nblk), dim3(NT), lds, st>>>(sal, dir, ten, mask_src,   \
-                                                                         mask_dst, doct, p);         \
+                                                                         mask_dst, dtab, p);         \
   } while (0)
   if (mask_src) { if (mode == 0) VH_TV_LAUNCH(true, 0); else VH_TV_LAUNCH(true, 1); }
   else          { if (mode == 0) VH_TV_LAUNCH(false, 0); else VH_TV_LAUNCH(false, 1); }
