@@ -137,15 +137,22 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
                              % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one GPU per rank over RCCL; a rehearsal with more ranks than GPUs (one-GPU box) shares cuda:0 and
+    # stages halos through gloo -- that run checks the code path, its number means nothing
+    own_gpu = world == 1 or torch.cuda.device_count() >= world
+    dev_index = local_rank if own_gpu else 0
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if own_gpu:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     stream = torch.cuda.Stream(device=device)  # one real stream shared by torch and the library
     torch.cuda.set_stream(stream)
-    ctx = api.Context(local_rank, stream.cuda_stream)
+    ctx = api.Context(dev_index, stream.cuda_stream)
 
     S = args.size
     nvox_rank = S * S * S
@@ -254,19 +261,22 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "gauss(sigma=2) + blob-dog(12 scales, sigma 2..4) + membrane/TV(sigma=1.732, "
                                    "sigma_tv=8.66, top 5%%) on %dx%dx%d float32" % (S, S, S * world),
-                       "per_gpu_voxels": nvox_rank, "decomposition": "z-slabs, ghost %d" % layout.ghost},
+                       "per_gpu_voxels": nvox_rank, "decomposition": "z-slabs, ghost %d" % layout.ghost,
+                       "halo_transport": "none" if world == 1 else ("rccl" if own_gpu else "gloo-staged (shared GPU rehearsal)")},
             "stages_ms": {"gauss": round(stage_ms[0] / args.steps, 3), "blob_dog": round(stage_ms[1] / args.steps, 3),
                           "membrane_tv": round(stage_ms[2] / args.steps, 3)},
             "results": counts,
             "roofline": roofline,
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:  # the CPU baseline is an N=1 line only
             try:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
             except Exception as e:  # the checker libraries are optional on the GPU box
                 out["cpu_baseline"] = {"value": None, "unit": "Mvoxels/s", "cores": 0, "kind": "unavailable",
                                        "sample": "failed: %s" % e}
         print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

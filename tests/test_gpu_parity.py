@@ -316,3 +316,4 @@ def test_tensor_voting_dense_saliency(ctx, oracle):
     d = np.ascontiguousarray(d, np.float32)
     ten = ctx.tv_dense_stick(sal, d, 3.0, 2, 2.0 ** 0.5)
     assert_bits_equal(ten, oracle.tv_dense_stick(sal, d, 3.0, 2, 2.0 ** 0.5), "dense-saliency tensor")
+

@@ -1,0 +1,99 @@
+"""Z-slab pipeline versus the single-volume pipeline, both on the GPU, bit for bit.
+
+Launch with one process per rank:
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
+        --master-port 29533 tools/slab_check.py
+With at least as many GPUs as ranks every rank takes its own GPU and halos travel over RCCL
+("nccl"); on a one-GPU box the ranks share cuda:0 and halos are staged through gloo.  Every rank
+runs the slab stages; rank 0 additionally runs the whole volume and compares the gathered owned
+planes and the merged blob lists.  Prints "SLAB-OK ..." on success, exits non-zero otherwise.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+
+import volgen  # noqa: E402
+from visfd_amd import api, pipeline, slab  # noqa: E402
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    ngpu = torch.cuda.device_count()
+    own_gpu = ngpu >= world
+    dev_index = local if own_gpu else 0
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if own_gpu:
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group("gloo")
+    shape, sigma, tv_ratio, fraction, ghost = (48, 36, 44), 1.2, 2.0, 0.15, 6
+    blob_sigmas = np.array([1.0, 1.25, 1.55, 1.9], np.float32)
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+    ctx = api.Context(dev_index, stream.cuda_stream)
+    full = torch.from_numpy(volgen.membrane_volume(shape, seed=55))
+
+    L = slab.SlabLayout(shape[0], rank, world, ghost=ghost)
+    lshape = (L.nz_local,) + tuple(shape[1:])
+    src = torch.full(lshape, float("nan"), device=dev)      # ghosts must come from the exchange
+    L.owned(src).copy_(full[L.z0:L.z1])
+    sal = torch.zeros(lshape, device=dev)
+    dirs = torch.zeros((3,) + lshape, device=dev)
+    ten = torch.zeros((6,) + lshape, device=dev)
+    thr = slab.membrane_detect_slab(ctx, L, src, sal, dirs, ten, sigma, tv_ratio, 4, fraction)
+    src2 = torch.full(lshape, float("nan"), device=dev)
+    L.owned(src2).copy_(full[L.z0:L.z1])
+    mins, maxs = slab.blob_detect_slab(ctx, L, src2, blob_sigmas, 0.03, 0.02, -5.0, 5.0, False)
+    ctx.synchronize()
+
+    part = dict(z0=L.z0, z1=L.z1, thr=np.float32(thr), sal=L.owned(sal).cpu().numpy(),
+                ten=L.owned(ten).cpu().numpy(), mins=mins, maxs=maxs)
+    parts = [None] * world
+    dist.all_gather_object(parts, part)
+
+    bad = []
+    if rank == 0:
+        vol = full.to(dev)
+        fsal = torch.zeros(shape, device=dev)
+        fdirs = torch.zeros((3,) + shape, device=dev)
+        ften = torch.zeros((6,) + shape, device=dev)
+        fthr = pipeline.membrane_detect(ctx, vol, fsal, fdirs, ften, sigma, tv_ratio, 4, fraction)
+        fmins, fmaxs = pipeline.blob_detect(ctx, vol, blob_sigmas, 0.03, 0.02, None, -5.0, 5.0, False)
+        ctx.synchronize()
+        fsal, ften = fsal.cpu().numpy(), ften.cpu().numpy()
+        if not np.abs(ften).max() > 0:
+            bad.append("vote tensor is all zero")
+        for p in parts:
+            z0, z1 = p["z0"], p["z1"]
+            if np.float32(p["thr"]) != np.float32(fthr):
+                bad.append("threshold differs on planes %d..%d" % (z0, z1))
+            if not np.array_equal(p["sal"].view(np.uint32), fsal[z0:z1].view(np.uint32)):
+                bad.append("saliency differs on planes %d..%d" % (z0, z1))
+            if not np.array_equal(p["ten"].view(np.uint32), ften[:, z0:z1].view(np.uint32)):
+                bad.append("vote tensor differs on planes %d..%d" % (z0, z1))
+            for name, got, want, asc in (("minima", p["mins"], fmins, True), ("maxima", p["maxs"], fmaxs, False)):
+                a, b = volgen.sort_blobs(got, asc), volgen.sort_blobs(want, asc)
+                if a.shape != b.shape or not np.array_equal(a.view(np.uint32), b.view(np.uint32)):
+                    bad.append("%s differ (%d vs %d)" % (name, len(a), len(b)))
+        if not bad:
+            print("SLAB-OK world=%d backend=%s minima=%d maxima=%d thr=%.6g" %
+                  (world, dist.get_backend(), len(fmins), len(fmaxs), fthr), flush=True)
+        else:
+            print("SLAB-MISMATCH: " + "; ".join(bad), flush=True)
+    flag = [bool(bad)]
+    dist.broadcast_object_list(flag, src=0)
+    ctx.close()
+    dist.destroy_process_group()
+    sys.exit(1 if flag[0] else 0)
+
+
+if __name__ == "__main__":
+    main()

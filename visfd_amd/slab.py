@@ -55,16 +55,31 @@ def exchange_halos(t, layout, depth, group=None):
     if L.world == 1 or depth == 0:
         return
     assert depth <= L.ghost
-    ops = []
     up, down = L.rank + 1, L.rank - 1
+    # RCCL moves device memory directly.  gloo (CPU tests, or several ranks sharing one GPU in a
+    # test) has no device-memory point-to-point, so device tensors are staged through host copies.
+    staged = t.is_cuda and dist.get_backend(group) != "nccl"
+    views = {}
     if down >= 0:
-        ops.append(dist.P2POp(dist.isend, t[L.own0:L.own0 + depth], down, group))
-        ops.append(dist.P2POp(dist.irecv, t[L.own0 - depth:L.own0], down, group))
+        views["send_down"] = t[L.own0:L.own0 + depth]
+        views["recv_down"] = t[L.own0 - depth:L.own0]
     if up < L.world:
-        ops.append(dist.P2POp(dist.isend, t[L.own1 - depth:L.own1], up, group))
-        ops.append(dist.P2POp(dist.irecv, t[L.own1:L.own1 + depth], up, group))
+        views["send_up"] = t[L.own1 - depth:L.own1]
+        views["recv_up"] = t[L.own1:L.own1 + depth]
+    bufs = {k: (v.cpu() if staged else v) for k, v in views.items()}
+    ops = []
+    if down >= 0:
+        ops.append(dist.P2POp(dist.isend, bufs["send_down"], down, group))
+        ops.append(dist.P2POp(dist.irecv, bufs["recv_down"], down, group))
+    if up < L.world:
+        ops.append(dist.P2POp(dist.isend, bufs["send_up"], up, group))
+        ops.append(dist.P2POp(dist.irecv, bufs["recv_up"], up, group))
     for r in dist.batch_isend_irecv(ops):
         r.wait()
+    if staged:
+        for k in ("recv_down", "recv_up"):
+            if k in views:
+                views[k].copy_(bufs[k])
 
 
 def _pick_descending(hist, k):
