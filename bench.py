@@ -122,7 +122,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=1024, help="edge of the per-GPU volume")
-    ap.add_argument("--cpu-sample", type=int, default=128)
+    ap.add_argument("--cpu-sample", type=int, default=192)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 

@@ -43,12 +43,28 @@ constexpr int BAND_CAP = NT * VPT;   // 1792 region voxels per band
 #endif
 constexpr int CAP = VH_TV_CAP;       // list entries held in LDS between flushes
 constexpr int NWORDS = CAP / 32;
+constexpr int ENT_BYTES = 32;        // LDS bytes per list entry
+static_assert(NT * 4 == 32 * ENT_BYTES, "one hit-word row spans as many bytes as 32 list entries");
+constexpr unsigned SENT_BIT = 1u << NWORDS;   // sentinel "word" NWORDS: its only entry is the dummy entry CAP
+constexpr int SENT_WB = NWORDS << 10;
+static_assert(NWORDS < 31, "hit-word mask is 32 bits");
 constexpr int SLICE_BYTES = 21 * 1024;  // LDS budget for the table slices of one plane group
 constexpr int MAX_GROUP = 4;   // more planes per group lengthen the lists but cost LDS (occupancy)
 constexpr unsigned OOB = 0x7ffffff0u;  // byte offset beyond any plane descriptor: reads give 0
 
 __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)byte_off, 0, 0));
+}
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+// LDS (address space 3) pointers as 32-bit integers and back
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+template <typename T>
+__device__ __forceinline__ const __attribute__((address_space(3))) T* lds_ptr(unsigned a) {
+  return (const __attribute__((address_space(3))) T*)(uintptr_t)a;
 }
 
 struct TiledParams {
@@ -58,9 +74,14 @@ struct TiledParams {
   int rw, rh;            // region width/height = TILE + 2h
   int band_rows, nbands;
   int group;             // planes per group (slices resident in LDS)
+  int slice_f4;          // float4 entries of the LDS slice area
   int tiles_x, tiles_y;
   int exponent, curves;
 };
+
+__device__ __forceinline__ void acc(float& t, float x) {
+  asm("v_add_f32 %0, %0, %1" : "+v"(t) : "v"(x));
+}
 
 // MODE 0: surfaces with angular exponent 4 (the CLI default, settings.cpp:154); MODE 1: general.
 template <int MODE>
@@ -84,12 +105,14 @@ __device__ __forceinline__ void vote(float T[6], float sal, float fv, float r0, 
   }
   const float bse = (sal * fv) * dec;
   const float b0 = bse * m0, b1 = bse * m1, b2 = bse * m2;
-  T[0] = T[0] + b0 * m0;
-  T[3] = T[3] + b0 * m1;
-  T[5] = T[5] + b0 * m2;
-  T[1] = T[1] + b1 * m1;
-  T[4] = T[4] + b1 * m2;
-  T[2] = T[2] + b2 * m2;
+  // accumulate in place (tied operands keep the six sums in fixed registers across the vote loop;
+  // v_add_f32 is the same IEEE add the compiler emits for "+")
+  acc(T[0], b0 * m0);
+  acc(T[3], b0 * m1);
+  acc(T[5], b0 * m2);
+  acc(T[1], b1 * m1);
+  acc(T[4], b1 * m2);
+  acc(T[2], b2 * m2);
 }
 
 // magnitude m (>= 0) with the sign of the integer j; j == 0 keeps +m (rhat components are +0.0 there)
@@ -98,19 +121,21 @@ __device__ __forceinline__ float with_sign_of(float m, int j) {
 }
 
 template <bool MASKED_SRC, int MODE>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
 tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, float* __restrict__ ten,
                 const float* __restrict__ mask_src, const float* __restrict__ mask_dst,
                 const float4* __restrict__ table /* [(2h+1)^3] : w, rhat_x, rhat_y, rhat_z at j */,
                 TiledParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float4* l_dat = reinterpret_cast<float4*>(smem);                        // sal, n0, n1, n2
-  unsigned* l_pos = reinterpret_cast<unsigned*>(smem + 16 * CAP);         // ex | ey << 8 | ez << 16
-  float* l_mv = reinterpret_cast<float*>(smem + 20 * CAP);                // source-mask value
-  int* l_e16 = reinterpret_cast<int*>(smem + 24 * CAP);                   // 16 * (ey*S + ex - slot*S*S)
-  unsigned* hitw = reinterpret_cast<unsigned*>(smem + 28 * CAP);          // [NWORDS][NT] hit words
-  unsigned char* slices = smem + 28 * CAP + 4 * NWORDS * NT;              // [group][(2h+1)^2] float4
+  // Static LDS (compile-time addresses fold into the DS instructions' immediate offsets):
+  // list entry e (32 bytes): float4 {sal, n0, n1, n2} | int e16 | float mask value | pad.
+  // Entry CAP is a permanent dummy (zero saliency and normal): lanes that have run out of hits vote
+  // it, which adds +-0 to their accumulators and leaves them bit-for-bit unchanged.
+  __shared__ __attribute__((aligned(16))) unsigned char l_ent[ENT_BYTES * (CAP + 1)];
+  __shared__ __attribute__((aligned(16))) unsigned l_pos[CAP];                 // ex | ey << 8 | ez << 16
+  __shared__ __attribute__((aligned(16))) unsigned char hitw[4 * (NWORDS + 1) * NT];  // [NWORDS + sentinel][NT]
   __shared__ int wave_tot[2][NT / 64];
+  // dynamic LDS: the table slices of the current plane group, [group][(2h+1)^2] float4
+  extern __shared__ __attribute__((aligned(16))) unsigned char slices[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -139,6 +164,11 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
 
   // (jy+h)*S + (jx+h) with jx = lx+h-ex, jy = ly+h-ey  =  [(ly+2h)*S + lx+2h] - [ey*S + ex]
   const int r16 = 16 * ((ly + 2 * h) * S + lx + 2 * h);
+
+  // LDS addresses as integers (see phase B)
+  const unsigned ent_base = lds_addr(l_ent);
+  const unsigned hitw_lane = lds_addr(hitw) + ((unsigned)tid << 2);
+  const unsigned r16s = lds_addr(slices) + (unsigned)r16;
 
   float T[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 
@@ -191,48 +221,104 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
   auto flush = [&](int n, int ez_first) {
     const int nwords = (n + 31) >> 5;
     const int neg_lim = -(h2 + 1);
-    // phase A: one hit word per 32 listed senders; nz collects which words are non-empty
-    unsigned nz = 0u;
+    // phase A: one hit word per 32 listed senders; nz collects which words are non-empty.  Sender
+    // positions come four at a time from uniform-address (broadcast) LDS reads.
+    unsigned nz = SENT_BIT;
+    unsigned nhits = 0u;
     for (int w = 0; w < nwords; w++) {
-      const int e = (w << 5) + (lane & 31);
-      const unsigned mypos = (e < n) ? l_pos[e] : 0u;
+      const uint4* pp = reinterpret_cast<const uint4*>(l_pos + (w << 5));
       unsigned bits = 0u;
+      uint4 q[4];
 #pragma unroll
-      for (int k = 31; k >= 0; k--) {
-        const unsigned ps = (unsigned)__builtin_amdgcn_readlane((int)mypos, k);
-        const unsigned t = (recv_b - ps) ^ 0x00808080u;          // signed byte offsets jx, jy, jz
-        const int d = __builtin_amdgcn_sdot4((int)t, (int)t, neg_lim, false);  // jx^2+jy^2+jz^2-h^2-1 < 0 <=> hit
-        bits = __builtin_amdgcn_alignbit(bits, (unsigned)d, 31);  // bits = bits << 1 | sign(d)
+      for (int k4 = 3; k4 >= 0; k4--) q[k4] = pp[4 + k4];
+#pragma unroll
+      for (int half = 1; half >= 0; half--) {
+        uint4 qn[4];
+        if (half == 1) {
+#pragma unroll
+          for (int k4 = 3; k4 >= 0; k4--) qn[k4] = pp[k4];   // lower half in flight during the upper half's tests
+        }
+#pragma unroll
+        for (int k4 = 3; k4 >= 0; k4--) {
+          // signed byte offsets jx, jy, jz of four senders
+          const unsigned t0 = (recv_b - q[k4].x) ^ 0x00808080u, t1 = (recv_b - q[k4].y) ^ 0x00808080u;
+          const unsigned t2 = (recv_b - q[k4].z) ^ 0x00808080u, t3 = (recv_b - q[k4].w) ^ 0x00808080u;
+          // d = jx^2+jy^2+jz^2-h^2-1 < 0 <=> hit.  Three-operand dot (the limit stays in an SGPR; the
+          // compiler's own choice is the two-operand form plus a v_mov per test).  A dot result may
+          // be read by the VALU three instructions later at the earliest: with four dots issued
+          // back to back, the shift-in chain below (d3, d2, d1, d0) keeps exactly that distance.
+          unsigned d0, d1, d2, d3;
+          asm("v_dot4_i32_i8 %1, %5, %5, %9\n\t"
+              "v_dot4_i32_i8 %2, %6, %6, %9\n\t"
+              "v_dot4_i32_i8 %3, %7, %7, %9\n\t"
+              "v_dot4_i32_i8 %4, %8, %8, %9\n\t"
+              "v_alignbit_b32 %0, %0, %1, 31\n\t"       // bits = bits << 1 | sign(d), four times
+              "v_alignbit_b32 %0, %0, %2, 31\n\t"
+              "v_alignbit_b32 %0, %0, %3, 31\n\t"
+              "v_alignbit_b32 %0, %0, %4, 31"
+              : "+v"(bits), "=&v"(d3), "=&v"(d2), "=&v"(d1), "=&v"(d0)
+              : "v"(t3), "v"(t2), "v"(t1), "v"(t0), "s"(neg_lim));
+        }
+        if (half == 1) {
+#pragma unroll
+          for (int k4 = 0; k4 < 4; k4++) q[k4] = qn[k4];
+        }
       }
       const int valid = n - (w << 5);
       if (valid < 32) bits &= (1u << valid) - 1u;
       if (!r_live) bits = 0u;
-      hitw[w * NT + tid] = bits;
+      *reinterpret_cast<unsigned*>(hitw + (w << 10) + (tid << 2)) = bits;
       nz |= (bits != 0u ? 1u : 0u) << w;
+      nhits += (unsigned)__builtin_popcount(bits);
     }
-    // phase B: every lane walks its own hit words (its LDS column is private: no barrier needed)
+    // phase B: every lane walks its own hit words (its LDS column is private: no barrier needed).
+    // The loop is wave-uniform -- it runs as many times as the busiest lane has hits -- and there is no divergent
+    // control flow around the vote: a lane that has run out of hits keeps refilling from the
+    // sentinel word (row NWORDS, value 1), i.e. keeps voting the dummy entry CAP.
+    // LDS addresses are formed as integers so that the (link-time) base of the dynamic segment is
+    // folded into per-lane constants instead of being re-added on every vote.
     unsigned cur = 0u;
-    int w = 0;
-    for (;;) {
-      if (cur == 0u) {
-        if (nz == 0u) break;                 // this lane is done
-        w = __ffs((int)nz) - 1;
-        nz &= nz - 1u;
-        cur = hitw[w * NT + tid];
+    unsigned wbe = 0u;    // LDS address of the current word's first list entry (= ent_base + 1024 * word)
+    auto refill = [&]() {
+      if (cur == 0u) {                         // next non-empty word, or the sentinel
+        const unsigned wb = (unsigned)__builtin_ctz(nz) << 10;
+        nz = (nz & (nz - 1u)) | SENT_BIT;
+        cur = *lds_ptr<unsigned>(hitw_lane + wb);
+        wbe = ent_base + wb;
       }
-      const int bpos = __ffs((int)cur) - 1;
+    };
+    refill();
+    unsigned mx = nhits;                    // hits of the busiest lane of the wave
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, d));
+    const int niter = __builtin_amdgcn_readfirstlane((int)mx);
+    for (int it = 0; it < niter; it++) {
+      const unsigned ent = ((unsigned)__builtin_ctz(cur) << 5) + wbe;
       cur &= cur - 1u;
-      const int idx = (w << 5) + bpos;
-      const float4 d = l_dat[idx];
+      const f4v d = *lds_ptr<f4v>(ent);
+      const int e16 = *lds_ptr<int>(ent + 16);
       // table entry of j = receiver - sender in the sender's plane slice: address R16 - E16
-      const float4 tw = *reinterpret_cast<const float4*>(slices + (r16 - l_e16[idx]));
+      const f4v tw = *lds_ptr<f4v>(r16s - (unsigned)e16);
       float fv = tw.x;
-      if (MASKED_SRC) fv = fv * l_mv[idx];
+      if (MASKED_SRC) fv = fv * *lds_ptr<float>(ent + 20);
       // A zero weight (taps on the rim of the spherical support, feature.hpp:2276) needs no branch: the
       // vote is then (+-0)*m*m and adding +-0 leaves the accumulators bit-for-bit unchanged.
       vote<MODE>(T, d.x, fv, tw.y, tw.z, tw.w, d.y, d.z, d.w, p.exponent, p.curves);
+      refill();
     }
   };
+
+  // dummy entry: zero saliency/normal; its table address R16 - E16 = 16*((ly+h)*S + lx+h) stays inside
+  // the slice area (sized for it by the host), which is zero-filled once so that it is always finite
+  if (tid == 0) {
+    unsigned char* ent = l_ent + ENT_BYTES * CAP;
+    *reinterpret_cast<float4*>(ent) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    *reinterpret_cast<int*>(ent + 16) = 16 * (h * S + h);
+    *reinterpret_cast<float*>(ent + 20) = 0.0f;
+  }
+  *reinterpret_cast<unsigned*>(hitw + SENT_WB + (tid << 2)) = 1u;   // sentinel row
+  for (int i = tid; i < p.slice_f4; i += NT) reinterpret_cast<float4*>(slices)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  __syncthreads();
 
   int n_list = 0;         // entries currently in the LDS list
   int ez_first = 0;       // region-relative z of the first plane of the current group
@@ -299,11 +385,13 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
           if (q >= done && q < done + take) {
             const unsigned off = voff_of(v, row0, rows);
             const int slot = n_list + (q - done);
-            l_dat[slot] = make_float4(cur[v], buf_load(rd0, off), buf_load(rd1, off), buf_load(rd2, off));
+            unsigned char* ent = l_ent + ENT_BYTES * slot;
+            *reinterpret_cast<float4*>(ent) =
+                make_float4(cur[v], buf_load(rd0, off), buf_load(rd1, off), buf_load(rd2, off));
             const int ex = rc_[v] & 0xff, ey = row0 + (rc_[v] >> 8);
             l_pos[slot] = (unsigned)ex | ((unsigned)ey << 8) | ((unsigned)ez << 16);
-            l_e16[slot] = 16 * (ey * S + ex - (ez_first - ez) * nsl);
-            if (MASKED_SRC) l_mv[slot] = buf_load(plane_rsrc(mask_src, sz), off);
+            *reinterpret_cast<int*>(ent + 16) = 16 * (ey * S + ex - (ez_first - ez) * nsl);
+            if (MASKED_SRC) *reinterpret_cast<float*>(ent + 20) = buf_load(plane_rsrc(mask_src, sz), off);
           }
           q--;
         }
@@ -373,8 +461,14 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
   p.curves = curves ? 1 : 0;
   const i64 nblk = (i64)p.tiles_x * p.tiles_y * (z_out1 - z_out0);
   if (nblk > 0x7fffffffLL) return fail(VISFD_HIP_EINVAL, "volume too large for one launch");
-  const size_t lds = (size_t)28 * CAP + (size_t)4 * NWORDS * NT + (size_t)p.group * slice_bytes;
-  if (lds > 150 * 1024) return VISFD_HIP_OK;   // window too wide for the LDS slices: baseline kernel
+  // slice area: the group's slices, and at least the span the dummy entry's table reads can touch
+  size_t slice_f4 = (size_t)p.group * n * n;
+  const size_t dummy_span = (size_t)(TILE - 1 + h) * n + (TILE - 1 + h) + 1;
+  if (slice_f4 < dummy_span) slice_f4 = dummy_span;
+  p.slice_f4 = (int)slice_f4;
+  const size_t lds = sizeof(float4) * slice_f4;   // dynamic part
+  const size_t lds_static = (size_t)ENT_BYTES * (CAP + 1) + (size_t)4 * CAP + (size_t)4 * (NWORDS + 1) * NT + 64;
+  if (lds + lds_static > 150 * 1024) return VISFD_HIP_OK;   // window too wide for the LDS slices: baseline kernel
   const int mode = (exponent == 4 && !curves) ? 0 : 1;
 #define VH_TV_LAUNCH(MSK, MD)                                                                        \
   do {                                                                                               \
