@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvisfd_hip.so")
+LIB_PATH = os.environ.get("VISFD_HIP_LIB") or os.path.join(_HERE, "libvisfd_hip.so")  # env: tuning variants (tools/build_variant.py)
 
 INCREASING_EIVALS = 0
 DECREASING_EIVALS = 1

@@ -48,8 +48,14 @@ static_assert(NT * 4 == 32 * ENT_BYTES, "one hit-word row spans as many bytes as
 constexpr unsigned SENT_BIT = 1u << NWORDS;   // sentinel "word" NWORDS: its only entry is the dummy entry CAP
 constexpr int SENT_WB = NWORDS << 10;
 static_assert(NWORDS < 31, "hit-word mask is 32 bits");
-constexpr int SLICE_BYTES = 21 * 1024;  // LDS budget for the table slices of one plane group
-constexpr int MAX_GROUP = 4;   // more planes per group lengthen the lists but cost LDS (occupancy)
+#ifndef VH_TV_SLICE_KB
+#define VH_TV_SLICE_KB 21
+#endif
+#ifndef VH_TV_MAX_GROUP
+#define VH_TV_MAX_GROUP 4
+#endif
+constexpr int SLICE_BYTES = VH_TV_SLICE_KB * 1024;  // LDS budget for the table slices of one plane group
+constexpr int MAX_GROUP = VH_TV_MAX_GROUP;   // more planes per group lengthen the lists but cost LDS (occupancy)
 constexpr unsigned OOB = 0x7ffffff0u;  // byte offset beyond any plane descriptor: reads give 0
 
 __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
@@ -131,7 +137,9 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
   // Entry CAP is a permanent dummy (zero saliency and normal): lanes that have run out of hits vote
   // it, which adds +-0 to their accumulators and leaves them bit-for-bit unchanged.
   __shared__ __attribute__((aligned(16))) unsigned char l_ent[ENT_BYTES * (CAP + 1)];
-  __shared__ __attribute__((aligned(16))) unsigned l_pos[CAP];                 // ex | ey << 8 | ez << 16
+  // distance-test operand of the listed senders (see phase A): packed signed bytes
+  // (e'x, e'y, -(|e'|^2 >> 7), |e'|^2 & 127) with e' = sender position relative to the tile centre
+  __shared__ __attribute__((aligned(16))) unsigned l_pos[CAP];
   __shared__ __attribute__((aligned(16))) unsigned char hitw[4 * (NWORDS + 1) * NT];  // [NWORDS + sentinel][NT]
   __shared__ int wave_tot[2][NT / 64];
   // dynamic LDS: the table slices of the current plane group, [group][(2h+1)^2] float4
@@ -159,8 +167,14 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
   const i64 rc = (i64)rz * plane + (i64)ry * p.nx + rx;
   const bool r_live = r_in && !(mask_dst && mask_dst[r_in ? rc : 0] == 0.0f);
   const int h2 = h * h;
-  // byte-packed receiver position, biased by 128 per byte so that recv_b - pos never borrows
-  const unsigned recv_b = (unsigned)(lx + h + 128) | ((unsigned)(ly + h + 128) << 8) | ((unsigned)(h + 128) << 16);
+  // Distance test  |r - e|^2 <= h^2  as ONE dot product per (receiver, sender): with coordinates
+  // relative to the tile centre (r' = (lx-8, ly-8, 0), e' = (ex-h-8, ey-h-8, ez-h)) and
+  // |e'|^2 = 128 q + m,
+  //   |r'-e'|^2 - h^2 - 1  =  (-2r'x, -2r'y, -128, 1) . (e'x, e'y, -q, m)  +  (|r'|^2 - h^2 - 1),
+  // every factor a signed byte (|e'| <= h+8 <= 48, so q <= 54), the last term a per-lane accumulator.
+  const int rpx = lx - 8, rpy = ly - 8;
+  const unsigned recv4 = (unsigned)((-2 * rpx) & 0xff) | ((unsigned)((-2 * rpy) & 0xff) << 8) | (0x80u << 16) | (1u << 24);
+  const int recv_c = rpx * rpx + rpy * rpy - h2 - 1;
 
   // (jy+h)*S + (jx+h) with jx = lx+h-ex, jy = ly+h-ey  =  [(ly+2h)*S + lx+2h] - [ey*S + ex]
   const int r16 = 16 * ((ly + 2 * h) * S + lx + 2 * h);
@@ -220,7 +234,6 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
   // slot_of_plane0: region-relative z (ez) of the group's first plane; slice slot = ez_first - ez
   auto flush = [&](int n, int ez_first) {
     const int nwords = (n + 31) >> 5;
-    const int neg_lim = -(h2 + 1);
     // phase A: one hit word per 32 listed senders; nz collects which words are non-empty.  Sender
     // positions come four at a time from uniform-address (broadcast) LDS reads.
     unsigned nz = SENT_BIT;
@@ -228,41 +241,24 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
     for (int w = 0; w < nwords; w++) {
       const uint4* pp = reinterpret_cast<const uint4*>(l_pos + (w << 5));
       unsigned bits = 0u;
-      uint4 q[4];
 #pragma unroll
-      for (int k4 = 3; k4 >= 0; k4--) q[k4] = pp[4 + k4];
-#pragma unroll
-      for (int half = 1; half >= 0; half--) {
-        uint4 qn[4];
-        if (half == 1) {
-#pragma unroll
-          for (int k4 = 3; k4 >= 0; k4--) qn[k4] = pp[k4];   // lower half in flight during the upper half's tests
-        }
-#pragma unroll
-        for (int k4 = 3; k4 >= 0; k4--) {
-          // signed byte offsets jx, jy, jz of four senders
-          const unsigned t0 = (recv_b - q[k4].x) ^ 0x00808080u, t1 = (recv_b - q[k4].y) ^ 0x00808080u;
-          const unsigned t2 = (recv_b - q[k4].z) ^ 0x00808080u, t3 = (recv_b - q[k4].w) ^ 0x00808080u;
-          // d = jx^2+jy^2+jz^2-h^2-1 < 0 <=> hit.  Three-operand dot (the limit stays in an SGPR; the
-          // compiler's own choice is the two-operand form plus a v_mov per test).  A dot result may
-          // be read by the VALU three instructions later at the earliest: with four dots issued
-          // back to back, the shift-in chain below (d3, d2, d1, d0) keeps exactly that distance.
-          unsigned d0, d1, d2, d3;
-          asm("v_dot4_i32_i8 %1, %5, %5, %9\n\t"
-              "v_dot4_i32_i8 %2, %6, %6, %9\n\t"
-              "v_dot4_i32_i8 %3, %7, %7, %9\n\t"
-              "v_dot4_i32_i8 %4, %8, %8, %9\n\t"
-              "v_alignbit_b32 %0, %0, %1, 31\n\t"       // bits = bits << 1 | sign(d), four times
-              "v_alignbit_b32 %0, %0, %2, 31\n\t"
-              "v_alignbit_b32 %0, %0, %3, 31\n\t"
-              "v_alignbit_b32 %0, %0, %4, 31"
-              : "+v"(bits), "=&v"(d3), "=&v"(d2), "=&v"(d1), "=&v"(d0)
-              : "v"(t3), "v"(t2), "v"(t1), "v"(t0), "s"(neg_lim));
-        }
-        if (half == 1) {
-#pragma unroll
-          for (int k4 = 0; k4 < 4; k4++) q[k4] = qn[k4];
-        }
+      for (int k4 = 7; k4 >= 0; k4--) {
+        const uint4 q = pp[k4];
+        // d = |r-e|^2 - h^2 - 1 < 0 <=> hit; bits = bits << 1 | sign(d).  A dot result may be read by
+        // the VALU three instructions later at the earliest: four dots back to back, then the
+        // shift-in chain in the same order, keep exactly that distance (the compiler does not
+        // see hazards of instructions inside an asm block).
+        unsigned d0, d1, d2, d3;
+        asm("v_dot4_i32_i8 %1, %5, %7, %6\n\t"
+            "v_dot4_i32_i8 %2, %5, %8, %6\n\t"
+            "v_dot4_i32_i8 %3, %5, %9, %6\n\t"
+            "v_dot4_i32_i8 %4, %5, %10, %6\n\t"
+            "v_alignbit_b32 %0, %0, %1, 31\n\t"
+            "v_alignbit_b32 %0, %0, %2, 31\n\t"
+            "v_alignbit_b32 %0, %0, %3, 31\n\t"
+            "v_alignbit_b32 %0, %0, %4, 31"
+            : "+v"(bits), "=&v"(d3), "=&v"(d2), "=&v"(d1), "=&v"(d0)
+            : "v"(recv4), "v"(recv_c), "v"(q.w), "v"(q.z), "v"(q.y), "v"(q.x));
       }
       const int valid = n - (w << 5);
       if (valid < 32) bits &= (1u << valid) - 1u;
@@ -389,7 +385,10 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
             *reinterpret_cast<float4*>(ent) =
                 make_float4(cur[v], buf_load(rd0, off), buf_load(rd1, off), buf_load(rd2, off));
             const int ex = rc_[v] & 0xff, ey = row0 + (rc_[v] >> 8);
-            l_pos[slot] = (unsigned)ex | ((unsigned)ey << 8) | ((unsigned)ez << 16);
+            const int epx = ex - h - 8, epy = ey - h - 8, epz = ez - h;
+            const int e2 = epx * epx + epy * epy + epz * epz;
+            l_pos[slot] = (unsigned)(epx & 0xff) | ((unsigned)(epy & 0xff) << 8) | ((unsigned)((-(e2 >> 7)) & 0xff) << 16) |
+                          ((unsigned)(e2 & 127) << 24);
             *reinterpret_cast<int*>(ent + 16) = 16 * (ey * S + ex - (ez_first - ez) * nsl);
             if (MASKED_SRC) *reinterpret_cast<float*>(ent + 20) = buf_load(plane_rsrc(mask_src, sz), off);
           }
