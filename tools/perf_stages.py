@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--n", type=int, default=512)
     ap.add_argument("--stages", default="copy,gauss")
     ap.add_argument("--h", type=str, default="5")
+    ap.add_argument("--synth", action="store_true", help="use bench.py's synthetic volume (membranes + blobs) instead of noise")
     a = ap.parse_args()
     n = a.n
     dev = torch.device("cuda:0")
@@ -42,7 +43,11 @@ def main():
     torch.cuda.set_stream(stream)
     ctx = api.Context(0, stream.cuda_stream)
     g = torch.Generator(device=dev).manual_seed(1)
-    src = torch.randn((n, n, n), device=dev, generator=g) * 100 + 1000
+    if a.synth:
+        import bench
+        src = bench.synth_volume(torch, ctx, (n, n, n), dev, seed=12345)
+    else:
+        src = torch.randn((n, n, n), device=dev, generator=g) * 100 + 1000
     dst = torch.empty_like(src)
     nvox = n ** 3
     stages = a.stages.split(",")

@@ -14,7 +14,11 @@ stream = torch.cuda.Stream()
 torch.cuda.set_stream(stream)
 ctx = api.Context(0, stream.cuda_stream)
 g = torch.Generator(device=dev).manual_seed(1)
-src = torch.randn((n, n, n), device=dev, generator=g) * 100 + 1000
+if len(sys.argv) > 2 and sys.argv[2] == "synth":
+    import bench
+    src = bench.synth_volume(torch, ctx, (n, n, n), dev, seed=12345)
+else:
+    src = torch.randn((n, n, n), device=dev, generator=g) * 100 + 1000
 sal = torch.empty_like(src)
 dirs = torch.empty((3, n, n, n), device=dev)
 ctx.ridge_saliency_dev(src, sal, dirs, 1.732, 2.6482, 1)

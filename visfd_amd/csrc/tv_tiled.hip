@@ -64,6 +64,10 @@ __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rs, unsigned by
 
 typedef float f4v __attribute__((ext_vector_type(4)));
 
+#ifdef VH_TV_STATS   // development build only (tools/build_variant.py): phase-B utilisation counters
+__device__ unsigned long long g_tv_stats[8];
+#endif
+
 // LDS (address space 3) pointers as 32-bit integers and back
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
@@ -90,14 +94,17 @@ __device__ __forceinline__ void acc(float& t, float x) {
 }
 
 // MODE 0: surfaces with angular exponent 4 (the CLI default, settings.cpp:154); MODE 1: general.
+// The vote of one (sender, receiver) pair in two halves, so that the vote loop can put LDS reads
+// between them: vote_dir gives the magnitude and the voted direction, vote_acc adds the outer product.
 template <int MODE>
-__device__ __forceinline__ void vote(float T[6], float sal, float fv, float r0, float r1, float r2,
-                                     float n0, float n1, float n2, int exponent, int curves) {
+__device__ __forceinline__ void vote_dir(float sal, float fv, float r0, float r1, float r2, float n0, float n1,
+                                         float n2, int exponent, int curves, float& bse, float& m0, float& m1,
+                                         float& m2) {
   const float u = (r0 * n0 + r1 * n1) + r2 * n2;
   const float ux2 = u * 2.0f;
   const float u2 = u * u;
   const float c2 = 1.0f - u2;
-  float dec, m0, m1, m2;
+  float dec;
   if (MODE == 0) {
     dec = c2 * c2;
     m0 = ux2 * r0 - n0; m1 = ux2 * r1 - n1; m2 = ux2 * r2 - n2;
@@ -109,7 +116,10 @@ __device__ __forceinline__ void vote(float T[6], float sal, float fv, float r0, 
     if (curves) { m0 = n0 - ux2 * r0; m1 = n1 - ux2 * r1; m2 = n2 - ux2 * r2; }
     else        { m0 = ux2 * r0 - n0; m1 = ux2 * r1 - n1; m2 = ux2 * r2 - n2; }
   }
-  const float bse = (sal * fv) * dec;
+  bse = (sal * fv) * dec;
+}
+
+__device__ __forceinline__ void vote_acc(float T[6], float bse, float m0, float m1, float m2) {
   const float b0 = bse * m0, b1 = bse * m1, b2 = bse * m2;
   // accumulate in place (tied operands keep the six sums in fixed registers across the vote loop;
   // v_add_f32 is the same IEEE add the compiler emits for "+")
@@ -283,24 +293,70 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
         wbe = ent_base + wb;
       }
     };
-    refill();
+    auto next_ent = [&]() -> unsigned {       // LDS address of the lane's next hit entry (cur != 0 after refill)
+      const unsigned ent = ((unsigned)__builtin_ctz(cur) << 5) + wbe;
+      cur &= cur - 1u;
+      return ent;
+    };
     unsigned mx = nhits;                    // hits of the busiest lane of the wave
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, d));
     const int niter = __builtin_amdgcn_readfirstlane((int)mx);
-    for (int it = 0; it < niter; it++) {
-      const unsigned ent = ((unsigned)__builtin_ctz(cur) << 5) + wbe;
-      cur &= cur - 1u;
-      const f4v d = *lds_ptr<f4v>(ent);
-      const int e16 = *lds_ptr<int>(ent + 16);
-      // table entry of j = receiver - sender in the sender's plane slice: address R16 - E16
-      const f4v tw = *lds_ptr<f4v>(r16s - (unsigned)e16);
+#ifdef VH_TV_STATS
+    {
+      unsigned sum = nhits;
+      for (int d = 32; d >= 1; d >>= 1) sum += (unsigned)__shfl_xor((int)sum, d);
+      if (lane == 0) {
+        atomicAdd(&g_tv_stats[0], (unsigned long long)niter * 64ull);   // lane-iterations of phase B
+        atomicAdd(&g_tv_stats[1], (unsigned long long)sum);             // real votes
+        atomicAdd(&g_tv_stats[2], (unsigned long long)n * 64ull);       // distance tests
+        atomicAdd(&g_tv_stats[3], 1ull);                                // wave-flushes
+        atomicMax(&g_tv_stats[4], (unsigned long long)niter);
+        wave_tot[0][wave] = niter;   // (free between flushes) for the cross-wave figure below
+      }
+    }
+#endif
+    // Software pipeline, unrolled twice (A/B): while vote i is computed, the entry of vote i+1 is
+    // being read, and its table entry is requested half-way through.  An odd count ends with one
+    // extra dummy vote (every lane is at the sentinel by then).
+    f4v dA, dB, twA, twB;
+    int eA, eB;
+    float mvA = 1.0f, mvB = 1.0f;
+    auto read_entry = [&](unsigned ent, f4v& d, int& e16, float& mv) {
+      d = *lds_ptr<f4v>(ent);
+      e16 = *lds_ptr<int>(ent + 16);
+      if (MASKED_SRC) mv = *lds_ptr<float>(ent + 20);
+    };
+    // table entry of j = receiver - sender in the sender's plane slice: address R16 - E16
+    auto read_table = [&](int e16) -> f4v { return *lds_ptr<f4v>(r16s - (unsigned)e16); };
+    // A zero weight (taps on the rim of the spherical support, feature.hpp:2276) needs no branch: the
+    // vote is then (+-0)*m*m and adding +-0 leaves the accumulators bit-for-bit unchanged.
+    auto half1 = [&](const f4v& d, const f4v& tw, float mv, float& bse, float& m0, float& m1, float& m2) {
       float fv = tw.x;
-      if (MASKED_SRC) fv = fv * *lds_ptr<float>(ent + 20);
-      // A zero weight (taps on the rim of the spherical support, feature.hpp:2276) needs no branch: the
-      // vote is then (+-0)*m*m and adding +-0 leaves the accumulators bit-for-bit unchanged.
-      vote<MODE>(T, d.x, fv, tw.y, tw.z, tw.w, d.y, d.z, d.w, p.exponent, p.curves);
+      if (MASKED_SRC) fv = fv * mv;
+      vote_dir<MODE>(d.x, fv, tw.y, tw.z, tw.w, d.y, d.z, d.w, p.exponent, p.curves, bse, m0, m1, m2);
+    };
+    refill();
+    read_entry(next_ent(), dA, eA, mvA);
+    refill();
+    twA = read_table(eA);
+    const int npairs = (niter + 1) >> 1;
+    for (int it = 0; it < npairs; it++) {
+      float bse, m0, m1, m2;
+      read_entry(next_ent(), dB, eB, mvB);
       refill();
+      half1(dA, twA, mvA, bse, m0, m1, m2);
+      __builtin_amdgcn_sched_barrier(0);   // keep the table request between the two halves
+      twB = read_table(eB);
+      __builtin_amdgcn_sched_barrier(0);
+      vote_acc(T, bse, m0, m1, m2);
+      read_entry(next_ent(), dA, eA, mvA);
+      refill();
+      half1(dB, twB, mvB, bse, m0, m1, m2);
+      __builtin_amdgcn_sched_barrier(0);
+      twA = read_table(eA);
+      __builtin_amdgcn_sched_barrier(0);
+      vote_acc(T, bse, m0, m1, m2);
     }
   };
 
@@ -402,15 +458,34 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
         flush(n_list, ez_first);
         n_list = 0;
         __syncthreads();   // everyone done reading before the list is refilled
+#ifdef VH_TV_STATS
+        if (tid == 0) {
+          int mxw = 0, sm = 0;
+          for (int w = 0; w < NT / 64; w++) { mxw = max(mxw, wave_tot[0][w]); sm += wave_tot[0][w]; }
+          atomicAdd(&g_tv_stats[5], (unsigned long long)mxw * (NT / 64));
+          atomicAdd(&g_tv_stats[6], (unsigned long long)sm);
+        }
+        __syncthreads();
+#endif
       }
     }
     // end of group (or of all planes): flush what is left
     const bool last_of_group = (band == 0) && (((pl + 1) % p.group == 0) || (pl + 1 == nplanes));
     if (last_of_group) {
       __syncthreads();
+      const bool had = n_list > 0;
       if (n_list > 0) flush(n_list, ez_first);
       n_list = 0;
       __syncthreads();     // list and slices free for the next group
+#ifdef VH_TV_STATS
+      if (tid == 0 && had) {
+        int mxw = 0, sm = 0;
+        for (int w = 0; w < NT / 64; w++) { mxw = max(mxw, wave_tot[0][w]); sm += wave_tot[0][w]; }
+        atomicAdd(&g_tv_stats[5], (unsigned long long)mxw * (NT / 64));
+        atomicAdd(&g_tv_stats[6], (unsigned long long)sm);
+      }
+      __syncthreads();
+#endif
     }
   }
 
@@ -480,6 +555,18 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
   else          { if (mode == 0) VH_TV_LAUNCH(false, 0); else VH_TV_LAUNCH(false, 1); }
 #undef VH_TV_LAUNCH
   VH_HIP(hipGetLastError());
+#ifdef VH_TV_STATS
+  {
+    unsigned long long st8[8];
+    VH_HIP(hipStreamSynchronize(st));
+    VH_HIP(hipMemcpyFromSymbol(st8, HIP_SYMBOL(g_tv_stats), sizeof(st8)));
+    fprintf(stderr, "[tv stats] lane-iterations %llu votes %llu (util %.3f) tests %llu wave-flushes %llu max-iter %llu; cross-wave util %.3f\n",
+            st8[0], st8[1], st8[0] ? (double)st8[1] / (double)st8[0] : 0.0, st8[2], st8[3], st8[4],
+            st8[5] ? (double)st8[6] / (double)st8[5] : 0.0);
+    unsigned long long z8[8] = {};
+    VH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tv_stats), z8, sizeof(z8)));
+  }
+#endif
   *handled = true;
   return VISFD_HIP_OK;
 }
