@@ -7,17 +7,18 @@
 //
 //   * a workgroup owns a 16 x 16 x 1 tile of receivers (one per thread; each wave an 8 x 8 patch);
 //   * sender planes are visited from z+h down to z-h (= jz ascending), in groups of up to G planes
-//     whose |jz| slices of the octant weight table fit in LDS.  For each plane the workgroup reads
-//     the (16+2h)^2 region of saliencies around the tile (buffer loads, next plane prefetched in
-//     registers) and appends the salient, unmasked senders -- packed position, saliency, normal,
-//     mask value -- to an LDS list IN VOTE ORDER (ordered block-wide prefix sum: deterministic);
+//     whose signed (2h+1)^2 table slices fit in LDS.  For each plane the workgroup reads the
+//     (16+2h)^2 region of saliencies around the tile (buffer loads, next band prefetched in
+//     registers) and appends the salient, unmasked senders -- distance-test operand, saliency,
+//     normal, table offset, mask value -- to an LDS list IN VOTE ORDER (ordered block-wide prefix
+//     sum: deterministic);
 //   * when the list is full (or the group ends) it is flushed.  Phase A: every lane tests all
-//     listed senders against its own receiver -- positions broadcast with v_readlane, distance
-//     jx^2+jy^2+jz^2 <= h^2 from one v_dot4_i32_i8 on packed byte offsets, an exact superset of the
-//     table's spherical support -- and writes one 32-bit hit word per 32 senders to its private LDS
-//     column.  Phase B: every lane walks ITS OWN hit words in order and accumulates the votes (next
-//     hit's LDS reads in flight during the current vote), so lanes spend their time on real votes
-//     instead of idling under a sparse exec mask; long lists even out the per-lane hit counts;
+//     listed senders against its own receiver -- sender operands from uniform-address LDS reads,
+//     jx^2+jy^2+jz^2 <= h^2 as ONE v_dot4_i32_i8 on signed bytes (see the kernel), an exact superset
+//     of the table's spherical support -- and writes one 32-bit hit word per 32 senders to its
+//     private LDS column.  Phase B: every lane walks ITS OWN hit words in order and accumulates the
+//     votes in a counted, branch-free, software-pipelined loop, so lanes spend their time on real
+//     votes instead of idling under a sparse exec mask;
 //   * weights and unit displacements come from LDS copies of the (2h+1)^2 table slices of the
 //     group's planes (w, rhat_x, rhat_y, rhat_z as one float4, signs included).  Because the table
 //     index is linear in the offset j = receiver - sender, the byte address of a vote's table entry
