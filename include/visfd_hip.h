@@ -143,6 +143,36 @@ int visfd_hip_blob_dog_dev(visfd_hip_ctx*, const float* src, const float* mask,
 int visfd_hip_blob_diameters_to_sigmas(const float* diameters, int n, float* sigmas);
 int visfd_hip_blob_sigmas_to_diameters(const float* sigmas, int n, float* diameters);
 
+/* ---- f3: blob list post-processing (host-side; these take no context and touch no device) --------
+ * Lists are three parallel arrays: crds[n][3] (x,y,z in voxels), diameters[n], scores[n]. */
+enum {   /* SortCriteria, lib/visfd/visfd_utils.hpp:49-55 */
+  VISFD_HIP_DO_NOT_SORT = 0,
+  VISFD_HIP_SORT_DECREASING = 1,
+  VISFD_HIP_SORT_INCREASING = 2,
+  VISFD_HIP_SORT_DECREASING_MAGNITUDE = 3,
+  VISFD_HIP_SORT_INCREASING_MAGNITUDE = 4
+};
+/* CalcSphereOverlap, lib/visfd/visfd_utils.hpp:95-118: volume shared by two spheres */
+float visfd_hip_sphere_overlap(float rij, float ri, float rj);
+/* SortBlobs, lib/visfd/feature.hpp:519-616: reorders the three arrays; `permutation` (nullable, n
+ * entries) receives the original index of every new position.  Ties keep the reference's order:
+ * (key, index) ascending, or exactly the reverse of that. */
+int visfd_hip_sort_blobs(float* crds, float* diameters, float* scores, int64_t n, int sort_criteria,
+                         int ascending_order, uint64_t* permutation);
+/* DiscardMaskedBlobs, lib/visfd/feature.hpp:924-969: drops blobs whose centre voxel
+ * floor(x+0.5) has mask == 0; *n is updated.  mask == NULL keeps everything.  A centre outside the
+ * mask image is VISFD_HIP_EINVAL (the reference reads out of bounds). */
+int visfd_hip_discard_masked_blobs(float* crds, float* diameters, float* scores, int64_t* n,
+                                   const float* mask, int64_t nx, int64_t ny, int64_t nz);
+/* DiscardOverlappingBlobs, lib/visfd/feature.hpp:720-913: sorts by `sort_criteria` (best first), then
+ * keeps a blob unless an already-kept blob it meets in the coarse occupancy grid (cell = `scale`
+ * voxels, reference default 6) is closer than (ri+rk)*min_radial_separation_ratio or overlaps more
+ * than the given volume fractions (infinity disables a criterion).  *n is updated. */
+int visfd_hip_discard_overlapping_blobs(float* crds, float* diameters, float* scores, int64_t* n,
+                                        float min_radial_separation_ratio,
+                                        float max_volume_overlap_large, float max_volume_overlap_small,
+                                        int sort_criteria, int scale);
+
 /* ---- a9: CalcHessian, lib/visfd/feature.hpp:1203-1348 ------------------------------------------- */
 /* gradient (nullable): 3 channels; hessian: 6 channels (xx,yy,zz,xy,yz,xz).  Voxels with mask==0
  * are left untouched.  Returns VISFD_HIP_EINVAL if any dimension < 3 (feature.hpp:1260-1264). */

@@ -315,6 +315,85 @@ inline void BlobDogD(int const image_size[3], float const* const* const* aaafSou
   }
 }
 
+// ---- blob list post-processing: lib/visfd/visfd_utils.hpp:49-55,95-118; feature.hpp:519-616,720-969 ------
+typedef enum eSortCriteria {
+  DO_NOT_SORT = VISFD_HIP_DO_NOT_SORT,
+  SORT_DECREASING = VISFD_HIP_SORT_DECREASING,
+  SORT_INCREASING = VISFD_HIP_SORT_INCREASING,
+  SORT_DECREASING_MAGNITUDE = VISFD_HIP_SORT_DECREASING_MAGNITUDE,
+  SORT_INCREASING_MAGNITUDE = VISFD_HIP_SORT_INCREASING_MAGNITUDE
+} SortCriteria;
+
+inline float CalcSphereOverlap(float rij, float Ri, float Rj) { return visfd_hip_sphere_overlap(rij, Ri, Rj); }
+
+namespace hip_detail {
+struct FlatBlobs {   // the three parallel vectors as the flat arrays of the C ABI, and back
+  std::vector<float> c, d, s;
+  FlatBlobs(const std::vector<std::array<float, 3> >& crds, const std::vector<float>& diam,
+            const std::vector<float>& score) : c(3 * crds.size()), d(diam), s(score) {
+    if (diam.size() != crds.size() || score.size() != crds.size())
+      throw VisfdErr("Error: blob coordinate, diameter and score lists differ in length.\n");
+    for (size_t i = 0; i < crds.size(); i++) { c[3 * i] = crds[i][0]; c[3 * i + 1] = crds[i][1]; c[3 * i + 2] = crds[i][2]; }
+  }
+  void store(size_t n, std::vector<std::array<float, 3> >& crds, std::vector<float>& diam, std::vector<float>& score) {
+    crds.resize(n); diam.assign(d.begin(), d.begin() + n); score.assign(s.begin(), s.begin() + n);
+    for (size_t i = 0; i < n; i++) { crds[i][0] = c[3 * i]; crds[i][1] = c[3 * i + 1]; crds[i][2] = c[3 * i + 2]; }
+  }
+};
+}  // namespace hip_detail
+
+inline void SortBlobs(std::vector<std::array<float, 3> >& blob_crds, std::vector<float>& blob_diameters,
+                      std::vector<float>& blob_scores, SortCriteria sort_blob_criteria, bool ascending_order = true,
+                      std::vector<size_t>* pPermutation = nullptr, std::ostream* pReportProgress = nullptr) {
+  hip_detail::FlatBlobs f(blob_crds, blob_diameters, blob_scores);
+  std::vector<uint64_t> perm(blob_crds.size());
+  if (pReportProgress && !blob_crds.empty() && sort_blob_criteria != DO_NOT_SORT)
+    *pReportProgress << "-- Sorting blobs according to their scores... ";
+  hip_detail::check(visfd_hip_sort_blobs(f.c.data(), f.d.data(), f.s.data(), (int64_t)blob_crds.size(),
+                                         (int)sort_blob_criteria, ascending_order ? 1 : 0, perm.data()));
+  f.store(blob_crds.size(), blob_crds, blob_diameters, blob_scores);
+  if (pPermutation && !blob_crds.empty() && sort_blob_criteria != DO_NOT_SORT) pPermutation->assign(perm.begin(), perm.end());
+  if (pReportProgress && !blob_crds.empty() && sort_blob_criteria != DO_NOT_SORT) *pReportProgress << "done --" << std::endl;
+}
+
+// the (ascending_order, ignore_score_sign) form, feature.hpp:519-560
+inline void SortBlobs(std::vector<std::array<float, 3> >& blob_crds, std::vector<float>& blob_diameters,
+                      std::vector<float>& blob_scores, bool ascending_order = true, bool ignore_score_sign = true,
+                      std::vector<size_t>* pPermutation = nullptr, std::ostream* pReportProgress = nullptr) {
+  SortBlobs(blob_crds, blob_diameters, blob_scores, ignore_score_sign ? SORT_DECREASING_MAGNITUDE : SORT_DECREASING,
+            ascending_order, pPermutation, pReportProgress);
+}
+
+// image_size is needed here (the reference indexes the mask unchecked): pass the mask's dimensions
+inline void DiscardMaskedBlobs(std::vector<std::array<float, 3> >& blob_crds, std::vector<float>& blob_diameters,
+                               std::vector<float>& blob_scores, float const* const* const* aaafMask,
+                               int const image_size[3], std::ostream* pReportProgress = nullptr) {
+  if (!aaafMask) return;
+  hip_detail::FlatBlobs f(blob_crds, blob_diameters, blob_scores);
+  int64_t n = (int64_t)blob_crds.size();
+  hip_detail::check(visfd_hip_discard_masked_blobs(f.c.data(), f.d.data(), f.s.data(), &n, &aaafMask[0][0][0],
+                                                   image_size[0], image_size[1], image_size[2]));
+  if (pReportProgress)
+    *pReportProgress << "  discarded " << (blob_crds.size() - (size_t)n) << "  blobs lying outside the mask." << std::endl;
+  f.store((size_t)n, blob_crds, blob_diameters, blob_scores);
+}
+
+inline void DiscardOverlappingBlobs(std::vector<std::array<float, 3> >& blob_crds, std::vector<float>& blob_diameters,
+                                    std::vector<float>& blob_scores, float min_radial_separation_ratio,
+                                    float max_volume_overlap_large = std::numeric_limits<float>::infinity(),
+                                    float max_volume_overlap_small = std::numeric_limits<float>::infinity(),
+                                    SortCriteria sort_blob_criteria = SORT_DECREASING_MAGNITUDE,
+                                    std::ostream* pReportProgress = nullptr, int scale = 6) {
+  hip_detail::FlatBlobs f(blob_crds, blob_diameters, blob_scores);
+  int64_t n = (int64_t)blob_crds.size();
+  if (pReportProgress) *pReportProgress << "  detecting collisions between " << n << " blobs... ";
+  hip_detail::check(visfd_hip_discard_overlapping_blobs(f.c.data(), f.d.data(), f.s.data(), &n,
+                                                        min_radial_separation_ratio, max_volume_overlap_large,
+                                                        max_volume_overlap_small, (int)sort_blob_criteria, scale));
+  f.store((size_t)n, blob_crds, blob_diameters, blob_scores);
+  if (pReportProgress) *pReportProgress << "done.\n";
+}
+
 // ---- eigenvalue order: lib/visfd/eigen3_simple.hpp:36-43 ------------------------------------------------
 namespace selfadjoint_eigen3 {
 typedef enum eEigenOrderType {

@@ -64,6 +64,15 @@ class CpuLib:
                                       C.c_float, C.c_int, C.c_int]),
             "tensor_saliency": (None, [_fp, _fp, C.c_int64, C.c_int, _fp]),
         }
+        if prefix == "vr_":   # blob list post-processing: checked against the reference directly
+            _up = C.POINTER(C.c_uint64)
+            sig.update({
+                "sphere_overlap": (C.c_float, [C.c_float, C.c_float, C.c_float]),
+                "sort_blobs": (None, [_fp, _fp, _fp, C.c_int64, C.c_int, C.c_int, _up]),
+                "discard_masked_blobs": (C.c_int64, [_fp, _fp, _fp, C.c_int64, _fp, C.c_int, C.c_int, C.c_int]),
+                "discard_overlapping_blobs": (C.c_int64, [_fp, _fp, _fp, C.c_int64, C.c_float, C.c_float, C.c_float,
+                                                          C.c_int, C.c_int]),
+            })
         self._fn = {}
         for name, (res, args) in sig.items():
             fn = g(name)
@@ -195,6 +204,36 @@ class CpuLib:
     def tensor_saliency(self, tensor, order, sal_inout, mask=None):
         self._fn["tensor_saliency"](_f(tensor), _f(mask), sal_inout.size, int(order), _f(sal_inout))
         return sal_inout
+
+
+    # ---- blob list post-processing (reference harness only) -------------------------------
+    @staticmethod
+    def _blob_arrays(crds, diameters, scores):
+        return (np.ascontiguousarray(crds, np.float32).reshape(-1, 3).copy(),
+                np.ascontiguousarray(diameters, np.float32).copy(), np.ascontiguousarray(scores, np.float32).copy())
+
+    def sphere_overlap(self, rij, ri, rj):
+        return float(self._fn["sphere_overlap"](rij, ri, rj))
+
+    def sort_blobs(self, crds, diameters, scores, criteria, ascending=True):
+        c, d, s = self._blob_arrays(crds, diameters, scores)
+        perm = np.zeros(len(d), np.uint64)
+        self._fn["sort_blobs"](_f(c), _f(d), _f(s), len(d), int(criteria), int(bool(ascending)),
+                               perm.ctypes.data_as(C.POINTER(C.c_uint64)))
+        return c, d, s, perm
+
+    def discard_masked_blobs(self, crds, diameters, scores, mask):
+        c, d, s = self._blob_arrays(crds, diameters, scores)
+        nz, ny, nx = mask.shape
+        n = self._fn["discard_masked_blobs"](_f(c), _f(d), _f(s), len(d), _f(mask), nx, ny, nz)
+        return c[:n], d[:n], s[:n]
+
+    def discard_overlapping_blobs(self, crds, diameters, scores, min_sep, max_large=np.inf, max_small=np.inf,
+                                  criteria=3, scale=6):
+        c, d, s = self._blob_arrays(crds, diameters, scores)
+        n = self._fn["discard_overlapping_blobs"](_f(c), _f(d), _f(s), len(d), min_sep, max_large, max_small,
+                                                  int(criteria), int(scale))
+        return c[:n], d[:n], s[:n]
 
 
 _PATHS = {

@@ -289,6 +289,57 @@ float vr_threshold_fraction(float* saliency, const float* mask, int64_t n, float
   return thr;
 }
 
-int vr_version() { return 1; }
+// ---- blob list post-processing: the reference's own templates ---------------------
+namespace {
+void lists_from_flat(const float* crds, const float* diam, const float* score, int64_t n,
+                     std::vector<std::array<float, 3> >& c, std::vector<float>& d, std::vector<float>& s) {
+  c.resize(n); d.assign(diam, diam + n); s.assign(score, score + n);
+  for (int64_t i = 0; i < n; i++) c[i] = {crds[3 * i], crds[3 * i + 1], crds[3 * i + 2]};
+}
+int64_t lists_to_flat(const std::vector<std::array<float, 3> >& c, const std::vector<float>& d,
+                      const std::vector<float>& s, float* crds, float* diam, float* score) {
+  for (size_t i = 0; i < c.size(); i++) {
+    crds[3 * i] = c[i][0]; crds[3 * i + 1] = c[i][1]; crds[3 * i + 2] = c[i][2];
+    diam[i] = d[i]; score[i] = s[i];
+  }
+  return (int64_t)c.size();
+}
+}  // namespace
+
+// visfd_utils.hpp:95-118
+float vr_sphere_overlap(float rij, float ri, float rj) { return CalcSphereOverlap(rij, ri, rj); }
+
+// feature.hpp:573-616 (criteria overload); permutation (nullable) receives the new order
+void vr_sort_blobs(float* crds, float* diam, float* score, int64_t n, int criteria, int ascending,
+                   uint64_t* permutation) {
+  std::vector<std::array<float, 3> > c; std::vector<float> d, s;
+  lists_from_flat(crds, diam, score, n, c, d, s);
+  std::vector<size_t> perm;
+  SortBlobs(c, d, s, (SortCriteria)criteria, ascending != 0, &perm, (std::ostream*)nullptr);
+  lists_to_flat(c, d, s, crds, diam, score);
+  if (permutation) for (size_t i = 0; i < perm.size(); i++) permutation[i] = perm[i];
+}
+
+// feature.hpp:924-969
+int64_t vr_discard_masked_blobs(float* crds, float* diam, float* score, int64_t n, const float* mask,
+                                int nx, int ny, int nz) {
+  std::vector<std::array<float, 3> > c; std::vector<float> d, s;
+  lists_from_flat(crds, diam, score, n, c, d, s);
+  View3<const float> vm(mask, nx, ny, nz);
+  DiscardMaskedBlobs(c, d, s, (cf3)vm.p, (std::ostream*)nullptr);
+  return lists_to_flat(c, d, s, crds, diam, score);
+}
+
+// feature.hpp:720-913
+int64_t vr_discard_overlapping_blobs(float* crds, float* diam, float* score, int64_t n, float min_sep,
+                                     float max_large, float max_small, int criteria, int scale) {
+  std::vector<std::array<float, 3> > c; std::vector<float> d, s;
+  lists_from_flat(crds, diam, score, n, c, d, s);
+  DiscardOverlappingBlobs(c, d, s, min_sep, max_large, max_small, (SortCriteria)criteria,
+                          (std::ostream*)nullptr, scale);
+  return lists_to_flat(c, d, s, crds, diam, score);
+}
+
+int vr_version() { return 2; }
 
 }  // extern "C"

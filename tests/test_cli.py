@@ -102,3 +102,27 @@ def test_cli_membrane_save_progress(cli, tmp_path, oracle):
     # inputs is covered by test_gpu_parity.py
     assert_close_rel(got, ten, 1e-4, "vote tensor files")
     assert_close_rel(volgen.read_mrc(str(out)), sal, 1e-4, "output saliency")
+
+
+def test_cli_discard_blobs_reference_scenario(cli, tmp_path):
+    """tests/test_blob_detection.sh:25-29 of the reference: the 11 minima of the -blob step, filtered with
+    `-discard-blobs in out -blob-separation 1.1 -minima-threshold -90`, leave 2 blobs.  Host-side path
+    (no GPU): list file in physical units -> voxels -> score cut -> mask -> greedy overlap removal."""
+    g = golden("blob_rec")
+    w = 19.6
+    src = tmp_path / "test_blobs.txt"
+    with open(src, "w") as f:
+        f.write("# x y z diameter score\n")
+        for row, d in zip(g["minima"], g["minima_diam_vox"]):
+            f.write("%g %g %g %g %g\n" % (row[0] * w, row[1] * w, row[2] * w, d * w, row[4]))
+    out = tmp_path / "test_blobs_sep_1.1_thresh_-90.txt"
+    r = run(cli, "-w", w, "-mask", os.path.join(GOLDEN, "test_blob_detect_mask.rec"), "-in",
+            os.path.join(GOLDEN, "test_blob_detect.rec"), "-discard-blobs", src, out, "-blob-separation", 1.1,
+            "-minima-threshold", -90)
+    assert r.returncode == 0, r.stderr
+    lines = open(out).read().strip().split("\n")
+    assert len(lines) == 2, lines
+    assert lines[0] == "235.2 392 313.6 177.915 -140.018"
+    assert "2 blobs remaining" in r.stderr
+    # same file names twice / missing separation value are usage errors
+    assert run(cli, "-in", os.path.join(GOLDEN, "test_blob_detect.rec"), "-discard-blobs", src, src).returncode == 1

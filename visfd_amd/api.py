@@ -94,6 +94,11 @@ _SIGS = {
                                                 _fp]),
     "visfd_hip_tensor_saliency": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, _vp]),
     "visfd_hip_tensor_saliency_dev": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, _vp]),
+    "visfd_hip_sphere_overlap": (C.c_float, [C.c_float, C.c_float, C.c_float]),
+    "visfd_hip_sort_blobs": (C.c_int, [_fp, _fp, _fp, _i64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
+    "visfd_hip_discard_masked_blobs": (C.c_int, [_fp, _fp, _fp, C.POINTER(_i64), _vp, _i64, _i64, _i64]),
+    "visfd_hip_discard_overlapping_blobs": (C.c_int, [_fp, _fp, _fp, C.POINTER(_i64), C.c_float, C.c_float,
+                                                     C.c_float, C.c_int, C.c_int]),
 }
 
 _lib = None
@@ -182,6 +187,66 @@ def sigmas_to_diameters(s):
     d = np.empty_like(s)
     load_library().visfd_hip_blob_sigmas_to_diameters(s.ctypes.data_as(_fp), len(s), d.ctypes.data_as(_fp))
     return d
+
+
+# ---- blob list post-processing (host-side).  Blob lists are (crds[n,3], diameters[n], scores[n]).
+DO_NOT_SORT, SORT_DECREASING, SORT_INCREASING, SORT_DECREASING_MAGNITUDE, SORT_INCREASING_MAGNITUDE = range(5)
+
+
+def _chk_host(L, rc):
+    if rc:
+        raise VisfdHipError(rc, L.visfd_hip_last_error().decode())
+
+
+def _blob_arrays(crds, diameters, scores):
+    c = np.ascontiguousarray(crds, np.float32).reshape(-1, 3).copy()
+    d = np.ascontiguousarray(diameters, np.float32).copy()
+    s = np.ascontiguousarray(scores, np.float32).copy()
+    assert len(c) == len(d) == len(s), "blob lists differ in length"
+    return c, d, s
+
+
+def _fptr(a):
+    return a.ctypes.data_as(_fp)
+
+
+def sphere_overlap(rij, ri, rj):
+    """CalcSphereOverlap (visfd_utils.hpp:95-118)."""
+    return float(load_library().visfd_hip_sphere_overlap(rij, ri, rj))
+
+
+def sort_blobs(crds, diameters, scores, criteria=SORT_DECREASING_MAGNITUDE, ascending=True):
+    """SortBlobs (feature.hpp:573-616): returns (crds, diameters, scores, permutation)."""
+    L = load_library()
+    c, d, s = _blob_arrays(crds, diameters, scores)
+    perm = np.arange(len(d), dtype=np.uint64)
+    _chk_host(L, L.visfd_hip_sort_blobs(_fptr(c), _fptr(d), _fptr(s), len(d), int(criteria), int(bool(ascending)),
+                                        perm.ctypes.data_as(C.POINTER(C.c_uint64))))
+    return c, d, s, perm
+
+
+def discard_masked_blobs(crds, diameters, scores, mask):
+    """DiscardMaskedBlobs (feature.hpp:924-969); mask: [nz, ny, nx] float32 or None."""
+    L = load_library()
+    c, d, s = _blob_arrays(crds, diameters, scores)
+    n = _i64(len(d))
+    if mask is None:
+        return c, d, s
+    nz, ny, nx = mask.shape
+    _chk_host(L, L.visfd_hip_discard_masked_blobs(_fptr(c), _fptr(d), _fptr(s), C.byref(n), _np(mask), nx, ny, nz))
+    return c[:n.value], d[:n.value], s[:n.value]
+
+
+def discard_overlapping_blobs(crds, diameters, scores, min_radial_separation_ratio, max_volume_overlap_large=np.inf,
+                              max_volume_overlap_small=np.inf, criteria=SORT_DECREASING_MAGNITUDE, scale=6):
+    """DiscardOverlappingBlobs (feature.hpp:720-913): greedy non-max suppression, best blobs first."""
+    L = load_library()
+    c, d, s = _blob_arrays(crds, diameters, scores)
+    n = _i64(len(d))
+    _chk_host(L, L.visfd_hip_discard_overlapping_blobs(_fptr(c), _fptr(d), _fptr(s), C.byref(n),
+                                                       min_radial_separation_ratio, max_volume_overlap_large,
+                                                       max_volume_overlap_small, int(criteria), int(scale)))
+    return c[:n.value], d[:n.value], s[:n.value]
 
 
 _BLOB_DTYPE = np.dtype([("ix", "<i4"), ("iy", "<i4"), ("iz", "<i4"), ("scale", "<i4"), ("sigma", "<f4"),

@@ -125,7 +125,7 @@ struct Mrc {
 struct Settings {
   string in, out, mask, save_base;
   float voxel_width = -1;
-  enum { NONE, GAUSS, DOG, LOG, BLOB, SURFACE_RIDGE } type = NONE;
+  enum { NONE, GAUSS, DOG, LOG, BLOB, BLOB_NONMAX, SURFACE_RIDGE } type = NONE;
   float width_a[3] = {0, 0, 0}, width_b[3] = {0, 0, 0}, log_width[3] = {0, 0, 0};
   float truncate_ratio = -1.0f, truncate_threshold = 0.03f;   // settings.cpp:81,88
   float delta = 0.02f;                                        // settings.cpp:95
@@ -135,6 +135,12 @@ struct Settings {
   string blob_min_file, blob_max_file;
   float score_lower = -std::numeric_limits<float>::infinity();
   float score_upper = std::numeric_limits<float>::infinity();
+  // blob list post-processing (-discard-blobs)
+  vector<string> in_crds_files;
+  string out_crds_file;
+  float nonmax_min_radial_separation_ratio = 0.0f;            // settings.cpp:137
+  float nonmax_max_overlap_large = std::numeric_limits<float>::infinity();
+  float nonmax_max_overlap_small = std::numeric_limits<float>::infinity();
   // membranes
   bool ridges_are_maxima = false;
   float hessian_thr = 0.05f;                                  // settings.cpp:150-151
@@ -217,6 +223,21 @@ Settings parse(int argc, char** argv) {
       for (int n = 1; n < N; n++) s.blob_diameters[(size_t)n] = s.blob_diameters[(size_t)n - 1] * growth;
       s.type = Settings::BLOB; i += 6;
     }
+    else if (f == "-discard-blobs" || f == "-blob-nonmax" || f == "-blobs-nonmax") {   // settings.cpp:1769-1787
+      need(2);
+      if (v[i + 1].empty() || v[i + 1][0] == '-' || v[i + 2].empty() || v[i + 2][0] == '-' || v[i + 1] == v[i + 2])
+        throw VisfdErr("Error: The " + f + " argument must be followed by two different file names\n");
+      s.in_crds_files.push_back(v[i + 1]);
+      s.out_crds_file = v[i + 2];
+      s.type = Settings::BLOB_NONMAX;
+      i += 3;
+    }
+    else if (f == "-radial-separation" || f == "-blob-separation" || f == "-blob-r-separation" ||
+             f == "-blobr-separation" || f == "-spheres-nonmax-separation-radius") {   // settings.cpp:1603-1624
+      need(1); s.nonmax_min_radial_separation_ratio = num(v, i + 1, f); i += 2;
+    }
+    else if (f == "-max-volume-overlap") { need(1); s.nonmax_max_overlap_large = num(v, i + 1, f); i += 2; }        // settings.cpp:1540
+    else if (f == "-max-volume-overlap-small") { need(1); s.nonmax_max_overlap_small = num(v, i + 1, f); i += 2; }  // settings.cpp:1561
     else if (f == "-minima-threshold") { need(1); s.score_upper = num(v, i + 1, f); i += 2; }
     else if (f == "-maxima-threshold") { need(1); s.score_lower = num(v, i + 1, f); i += 2; }
     else if (f == "-membrane" || f == "-surface-ridge") {
@@ -243,6 +264,98 @@ Settings parse(int argc, char** argv) {
   if (s.in.empty()) throw VisfdErr("Error: You must specify an input file (-in).\n");
   if (s.type == Settings::SURFACE_RIDGE) s.tv_sigma *= s.width_a[0];   // settings.cpp:3535-3540
   return s;
+}
+
+// Blob list file (bin/filter_mrc/file_io.hpp:413-493): 3-5 numbers per line (x y z [diameter [score]]), '#'
+// starts a comment; coordinates written IMOD-style in parentheses mean "units of voxels".  Returns that flag.
+bool read_blob_file(const string& path, vector<std::array<float, 3> >& crds, vector<float>& diameters,
+                    vector<float>& scores) {
+  std::ifstream f(path.c_str());
+  if (!f) throw VisfdErr("Error: unable to open \"" + path + "\" for reading.\n");
+  bool parens = false;
+  string line;
+  size_t i_line = 0;
+  while (std::getline(f, line)) {
+    const size_t hash = line.find('#');
+    if (hash != string::npos) line.erase(hash);
+    for (size_t k = 0; k < line.size(); k++) {
+      if (line[k] == '(' || line[k] == ')') { parens = true; line[k] = ' '; }
+      else if (line[k] == ',') line[k] = ' ';
+    }
+    std::istringstream in(line);
+    vector<float> nums;
+    string tok;
+    while (in >> tok) {
+      try { nums.push_back(std::stof(tok)); } catch (...) { /* words such as "Pixel" or "=" are skipped */ }
+    }
+    if (nums.empty()) continue;
+    if (nums.size() < 3 || nums.size() > 5) {
+      std::ostringstream msg;
+      msg << "Error: Error on line " << i_line + 1 << " of file \"" << path << "\"\n"
+          << "       Each line should contain either 3-5 numbers, or 0 numbers (blank).\n";
+      throw VisfdErr(msg.str());
+    }
+    std::array<float, 3> c = {{nums[0], nums[1], nums[2]}};
+    crds.push_back(c);
+    float d = nums.size() > 3 ? nums[3] : -1.0f;
+    if (d < 0) d = -1.0f;
+    diameters.push_back(d);
+    scores.push_back(nums.size() > 4 ? nums[4] : 1.0f);   // default score = sphere_decals_foreground (settings.cpp: 1)
+    i_line++;
+  }
+  return parens;
+}
+
+// HandleBlobsNonmaxSuppression, bin/filter_mrc/handlers.cpp:421-617 (without the supervised-learning tail)
+void handle_blob_nonmax(const Settings& s, const float vw[3], float const* const* const* mask, const int size[3]) {
+  const float w = vw[0];
+  const float inf = std::numeric_limits<float>::infinity();
+  vector<std::array<float, 3> > crds;
+  vector<float> diameters, scores;
+  for (size_t I = 0; I < s.in_crds_files.size(); I++) {
+    vector<std::array<float, 3> > c;
+    vector<float> d, sc;
+    const bool in_voxels = read_blob_file(s.in_crds_files[I], c, d, sc);
+    if (!in_voxels && w > 0.0f)
+      for (size_t i = 0; i < c.size(); i++) {
+        for (int k = 0; k < 3; k++) c[i][k] = (float)std::floor((c[i][k] / w) + 0.5);   // handlers.cpp:458
+        if (d[i] != -1.0f) d[i] /= w;
+      }
+    crds.insert(crds.end(), c.begin(), c.end());
+    diameters.insert(diameters.end(), d.begin(), d.end());
+    scores.insert(scores.end(), sc.begin(), sc.end());
+  }
+  cerr << " --- discarding blobs in files ---\n\n";
+  if (s.score_lower != -inf || s.score_upper != inf) {   // handlers.cpp:503-545
+    vector<std::array<float, 3> > c;
+    vector<float> d, sc;
+    for (size_t i = 0; i < crds.size(); i++)
+      if (scores[i] >= s.score_lower && scores[i] <= s.score_upper) {
+        c.push_back(crds[i]); d.push_back(diameters[i]); sc.push_back(scores[i]);
+      }
+    crds.swap(c); diameters.swap(d); scores.swap(sc);
+  }
+  if (!crds.empty() && mask) {
+    cerr << "  discarding blobs outside the mask" << std::endl;
+    DiscardMaskedBlobs(crds, diameters, scores, mask, size);
+  }
+  if (s.nonmax_min_radial_separation_ratio > 0 || s.nonmax_max_overlap_large != inf || s.nonmax_max_overlap_small != inf) {
+    if (w <= 0.0f)
+      throw VisfdErr("Error: Checking for overlapping blobs requires that you either specify the\n"
+                     "       voxel width (using the \"-w\" argument).\n");
+    cerr << "  discarding overlapping blobs" << std::endl;
+    DiscardOverlappingBlobs(crds, diameters, scores, s.nonmax_min_radial_separation_ratio, s.nonmax_max_overlap_large,
+                            s.nonmax_max_overlap_small, SORT_DECREASING_MAGNITUDE, &cerr);
+  }
+  cerr << " " << crds.size() << " blobs remaining" << std::endl;
+  if (!s.out_crds_file.empty()) {
+    const double wp = w > 0.0f ? (double)w : 1.0;
+    std::ofstream out(s.out_crds_file.c_str());
+    if (!out) throw VisfdErr("Error: unable to open \"" + s.out_crds_file + "\" for writing.\n");
+    for (size_t i = 0; i < crds.size(); i++)
+      out << crds[i][0] * wp << " " << crds[i][1] * wp << " " << crds[i][2] * wp << " " << diameters[i] * wp << " "
+          << scores[i] << std::endl;
+  }
 }
 
 float ratio_of(const Settings& s) {
@@ -326,6 +439,8 @@ int main(int argc, char** argv) {
               << sc[i] << "\n";
         }
       }
+    } else if (s.type == Settings::BLOB_NONMAX) {
+      handle_blob_nonmax(s, vw, M, size);
     } else if (s.type == Settings::SURFACE_RIDGE) {
       cerr << "filter_type = surface ridge detector\n";
       const int order = s.ridges_are_maxima ? VISFD_HIP_INCREASING_EIVALS : VISFD_HIP_DECREASING_EIVALS;  // handlers.cpp:1524-1535

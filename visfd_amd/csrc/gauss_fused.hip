@@ -36,7 +36,7 @@ namespace {
 
 constexpr unsigned OOB = 0x7ffffff0u;  // byte offset beyond any descriptor: loads give 0, stores vanish
 
-template <int H, int TX, int TY, int NT>
+template <int H, int TX, int TY, int NT, int XV_, int YV_>
 struct FusedCfg {
   static constexpr int W = 2 * H + 1;
   static constexpr int HX = TX + 2 * H;           // haloed tile width (even: TX even)
@@ -49,12 +49,16 @@ struct FusedCfg {
   // between the two passes)
   static constexpr int NW = NT / 64;
   static constexpr int RPW = TY / NW;              // rows per wave
-  static constexpr int YTASKS = (HX / 2) * RPW;    // per wave: (x pair, row)
+  static constexpr int YV = YV_;                   // adjacent x per lane in the Y pass (1 or 2)
+  static constexpr int YTASKS = (HX / YV) * RPW;   // per wave: (x group, row)
   static constexpr int YROUNDS = (YTASKS + 63) / 64;
-  static constexpr int XV = 4;                     // outputs per lane in the X pass
+  static constexpr int XV = XV_;                   // outputs per lane in the X pass (2 or 4)
   static constexpr int XTASKS = (TX / XV) * RPW;   // per wave
   static constexpr int XROUNDS = (XTASKS + 63) / 64;
-  static constexpr int XWIN4 = (XV + 2 * H + 3) / 4;  // float4 reads covering the X window
+  static constexpr int XWINV = (XV + 2 * H + XV - 1) / XV;  // XV-wide vector reads covering the X window
+  static_assert(XV == 2 || XV == 4, "X pass vector width");
+  static_assert(YV == 1 || YV == 2, "Y pass vector width");
+  static_assert(HX % YV == 0 && TX % XV == 0, "tile width must be a multiple of the vector widths");
   static constexpr int SZ_FLOATS = HY * SX + 64;   // + a dump area for padding ring slots
   static constexpr int SY_FLOATS = TY * SX;
 };
@@ -68,13 +72,13 @@ __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rs, unsigned by
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)byte_off, 0, 0));
 }
 
-template <int H, int TX, int TY, int NT, bool NORMALIZE, bool ISO>
+template <int H, int TX, int TY, int NT, int XV_, int YV_, bool NORMALIZE, bool ISO>
 __global__ void __launch_bounds__(NT)
 gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH<H> tz, TapsH<H> ty_,
                    TapsH<H> tx_, const float* __restrict__ Dx, const float* __restrict__ Dy,
                    const float* __restrict__ Dz, i64 dz_offset, int nx, int ny, int nz, int zchunk,
                    int tiles_x, int tiles_y, const float* __restrict__ minuend, float log_scale) {
-  typedef FusedCfg<H, TX, TY, NT> C;
+  typedef FusedCfg<H, TX, TY, NT, XV_, YV_> C;
   constexpr int W = C::W;
   static_assert(TY % (NT / 64) == 0, "tile rows must divide evenly among the waves");
   __shared__ __attribute__((aligned(16))) float sZ2[2][C::SZ_FLOATS];   // double-buffered: see the march loop
@@ -118,8 +122,8 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
 #pragma unroll
   for (int r = 0; r < C::YROUNDS; r++) {
     const int task = lane + r * 64;
-    const int yy = task / (C::HX / 2), xp = task - yy * (C::HX / 2);
-    y_off[r] = (task < C::YTASKS) ? ((wave * C::RPW + yy) * C::SX + 2 * xp) : -1;
+    const int yy = task / (C::HX / C::YV), xp = task - yy * (C::HX / C::YV);
+    y_off[r] = (task < C::YTASKS) ? ((wave * C::RPW + yy) * C::SX + C::YV * xp) : -1;
   }
   int x_off[C::XROUNDS];
   unsigned o_off[C::XROUNDS];  // byte offset of the output quad inside a plane (OOB outside)
@@ -187,17 +191,27 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
         for (int r = 0; r < C::YROUNDS; r++) {
           if (y_off[r] >= 0) {
             const float* base = &sZ[y_off[r]];
-            float a0 = 0.0f, a1 = 0.0f;
+            if (C::YV == 2) {
+              float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll
-            for (int jj = 0; jj < W; jj++) {
-              const float2 v = *reinterpret_cast<const float2*>(base + (2 * H - jj) * C::SX);
-              const float t = ty.t[jj];
-              const float p0 = t * v.x;
-              const float p1 = t * v.y;
-              a0 = a0 + p0;
-              a1 = a1 + p1;
+              for (int jj = 0; jj < W; jj++) {
+                const float2 v = *reinterpret_cast<const float2*>(base + (2 * H - jj) * C::SX);
+                const float t = ty.t[jj];
+                const float p0 = t * v.x;
+                const float p1 = t * v.y;
+                a0 = a0 + p0;
+                a1 = a1 + p1;
+              }
+              *reinterpret_cast<float2*>(&sY[y_off[r]]) = make_float2(a0, a1);
+            } else {
+              float a0 = 0.0f;
+#pragma unroll
+              for (int jj = 0; jj < W; jj++) {
+                const float p0 = ty.t[jj] * base[(2 * H - jj) * C::SX];
+                a0 = a0 + p0;
+              }
+              sY[y_off[r]] = a0;
             }
-            *reinterpret_cast<float2*>(&sY[y_off[r]]) = make_float2(a0, a1);
           }
         }
         __builtin_amdgcn_wave_barrier();   // same wave wrote these sY rows: LDS ops of a wave execute in order
@@ -208,12 +222,21 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
         if (NORMALIZE) dz = Dz[z + dz_offset];
 #pragma unroll
         for (int r = 0; r < C::XROUNDS; r++) {
-          const float4* base = reinterpret_cast<const float4*>(&sY[x_off[r]]);
-          float v[4 * C::XWIN4];
+          float v[C::XV * C::XWINV];
+          if (C::XV == 4) {
+            const float4* base = reinterpret_cast<const float4*>(&sY[x_off[r]]);
 #pragma unroll
-          for (int k = 0; k < C::XWIN4; k++) {
-            const float4 q = base[k];
-            v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+            for (int k = 0; k < C::XWINV; k++) {
+              const float4 q = base[k];
+              v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+            }
+          } else {
+            const float2* base = reinterpret_cast<const float2*>(&sY[x_off[r]]);
+#pragma unroll
+            for (int k = 0; k < C::XWINV; k++) {
+              const float2 q = base[k];
+              v[2 * k] = q.x; v[2 * k + 1] = q.y;
+            }
           }
           float a[C::XV];
 #pragma unroll
@@ -236,21 +259,35 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
           }
           typedef float v4f __attribute__((ext_vector_type(4)));
           typedef unsigned v4u __attribute__((ext_vector_type(4)));
+          typedef float v2f __attribute__((ext_vector_type(2)));
+          typedef unsigned v2u __attribute__((ext_vector_type(2)));
           if (minuend) {
             // DoG/LoG epilogue fused into the second Gaussian: out = (G_a - G_b) * scale with the two
             // roundings of filter3d.hpp:1387-1390 and :1495-1498 (wave-uniform branch)
             const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(minuend + (i64)z * plane), 0, plane_bytes, 0x00020000);
-            const v4u mraw = __builtin_amdgcn_raw_buffer_load_b128(rm, (int)o_off[r], 0, 0);
-            const v4f m = __builtin_bit_cast(v4f, mraw);
+            float m[C::XV];
+            if (C::XV == 4) {
+              const v4f mv = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rm, (int)o_off[r], 0, 0));
+#pragma unroll
+              for (int k = 0; k < 4; k++) m[k] = mv[k];
+            } else {
+              const v2f mv = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rm, (int)o_off[r], 0, 0));
+              m[0] = mv[0]; m[1] = mv[1];
+            }
 #pragma unroll
             for (int k = 0; k < C::XV; k++) {
               const float dd = m[k] - a[k];
               a[k] = dd * log_scale;
             }
           }
-          v4f out = {a[0], a[1], a[2], a[3]};
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, out), ro, (int)o_off[r], 0, 0);
+          if (C::XV == 4) {
+            v4f out = {a[0], a[1], a[2], a[3]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, out), ro, (int)o_off[r], 0, 0);
+          } else {
+            v2f out = {a[0], a[1]};
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, out), ro, (int)o_off[r], 0, 0);
+          }
         }
         // One workgroup barrier per plane: sZ is double-buffered, so a wave may start the next Z pass
         // (writing the other buffer) while slower waves still read this one; that buffer's readers
@@ -261,7 +298,7 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
   }
 }
 
-template <int H, int TX, int TY, int NT>
+template <int H, int TX, int TY, int NT, int XV = 4, int YV = 2>
 int launch_cfg(visfd_hip_ctx* ctx, const float* src, float* dst, i64 nx, i64 ny, i64 nz,
                const Taps& tx, const Taps& ty, const Taps& tz, const float* Dx, const float* Dy,
                const float* Dz, i64 dz_offset, bool normalize, const float* minuend, float log_scale) {
@@ -286,7 +323,7 @@ int launch_cfg(visfd_hip_ctx* ctx, const float* src, float* dst, i64 nx, i64 ny,
   if (nblk > 0x7fffffffLL) return fail(VISFD_HIP_EINVAL, "volume too large for one launch");
   dim3 grid((unsigned)nblk), block(NT);
 #define VH_GO(NORM, ISOV)                                                                        \
-  gauss_fused_kernel<H, TX, TY, NT, NORM, ISOV><<<grid, block, 0, ctx->stream>>>(                \
+  gauss_fused_kernel<H, TX, TY, NT, XV, YV, NORM, ISOV><<<grid, block, 0, ctx->stream>>>(                \
       src, dst, a, b, c, Dx, Dy, Dz, dz_offset, (int)nx, (int)ny, (int)nz, (int)zchunk, tiles_x, tiles_y,  \
       minuend, log_scale)
   if (normalize) { if (iso) VH_GO(true, true); else VH_GO(true, false); }
@@ -309,12 +346,12 @@ int VH_CAT(launch_gauss_fused_h, VH_FUSED_H)(visfd_hip_ctx* ctx, const float* sr
                                             const float* minuend, float log_scale) {
   constexpr int H = VH_FUSED_H;
 #ifdef VH_FUSED_EXTRA_CFGS   // development: alternative tilings selectable at run time
-  if (cfg == 1) return launch_cfg<H, 64, 16, 512>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
-  if (cfg == 2) return launch_cfg<H, 64, 32, 512>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
-  if (cfg == 3) return launch_cfg<H, 128, 16, 512>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
-  if (cfg == 4) return launch_cfg<H, 128, 32, 1024>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
-  if (cfg == 5) return launch_cfg<H, 32, 32, 256>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
-  if (cfg == 6) return launch_cfg<H, 64, 32, 1024>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
+  if (cfg == 7) return launch_cfg<H, 64, 32, 1024, 2, 2>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
+  if (cfg == 8) return launch_cfg<H, 64, 32, 1024, 2, 1>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
+  if (cfg == 9) return launch_cfg<H, 128, 32, 1024, 4, 1>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
+  if (cfg == 10) return launch_cfg<H, 64, 32, 512, 4, 2>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
+  if (cfg == 11) return launch_cfg<H, 64, 32, 512, 4, 1>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
+  if (cfg == 12) return launch_cfg<H, 96, 32, 512, 4, 1>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
 #endif
   (void)cfg;
   // tilings picked from a sweep on MI355X (1024^3, gpurun_out/perf3.log): wider tiles cut the halo
