@@ -173,6 +173,21 @@ int visfd_hip_discard_overlapping_blobs(float* crds, float* diameters, float* sc
                                         float max_volume_overlap_large, float max_volume_overlap_small,
                                         int sort_criteria, int scale);
 
+/* ---- f4: BinArray3D / UnbinArray3D, lib/visfd/resample.hpp:53-166 -------------------------------------
+ * Sizes are {nx, ny, nz}.  bin[d] = floor(size_big[d] / size_small[d]); `offset` (nullable) shifts the
+ * binning window and must satisfy 0 <= offset[d] < bin[d] (VISFD_HIP_EINVAL otherwise, where the
+ * reference throws; also when the shifted window would leave the source, which the reference only
+ * asserts).  Bin: dst = float sum over the bin in z,y,x order / bin volume; source voxels
+ * beyond size_dst*bin are dropped.  Unbin: dst[I] = src[clamp((I - offset) / bin)]. */
+int visfd_hip_bin_array3d(visfd_hip_ctx*, const float* src, const int64_t size_src[3], float* dst,
+                          const int64_t size_dst[3], const int* offset);
+int visfd_hip_bin_array3d_dev(visfd_hip_ctx*, const float* src, const int64_t size_src[3], float* dst,
+                              const int64_t size_dst[3], const int* offset);
+int visfd_hip_unbin_array3d(visfd_hip_ctx*, const float* src, const int64_t size_src[3], float* dst,
+                            const int64_t size_dst[3], const int* offset);
+int visfd_hip_unbin_array3d_dev(visfd_hip_ctx*, const float* src, const int64_t size_src[3], float* dst,
+                                const int64_t size_dst[3], const int* offset);
+
 /* ---- a9: CalcHessian, lib/visfd/feature.hpp:1203-1348 ------------------------------------------- */
 /* gradient (nullable): 3 channels; hessian: 6 channels (xx,yy,zz,xy,yz,xz).  Voxels with mask==0
  * are left untouched.  Returns VISFD_HIP_EINVAL if any dimension < 3 (feature.hpp:1260-1264). */

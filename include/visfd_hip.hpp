@@ -315,6 +315,24 @@ inline void BlobDogD(int const image_size[3], float const* const* const* aaafSou
   }
 }
 
+// ---- BinArray3D / UnbinArray3D: lib/visfd/resample.hpp:53-58, :120-124 ---------------------------------
+inline void BinArray3D(int const size_source[3], int const size_dest[3], float const* const* const* aaafSource,
+                       float*** aaafDest, int const* offset = nullptr) {
+  hip_detail::require_contiguous(aaafSource, size_source);
+  hip_detail::require_contiguous(aaafDest, size_dest);
+  const int64_t ss[3] = {size_source[0], size_source[1], size_source[2]}, ds[3] = {size_dest[0], size_dest[1], size_dest[2]};
+  hip_detail::check(visfd_hip_bin_array3d(hip_detail::context(), hip_detail::flat(aaafSource), ss,
+                                          hip_detail::flat(aaafDest), ds, offset));
+}
+inline void UnbinArray3D(int const size_source[3], int const size_dest[3], float const* const* const* aaafSource,
+                         float*** aaafDest, int const* offset = nullptr) {
+  hip_detail::require_contiguous(aaafSource, size_source);
+  hip_detail::require_contiguous(aaafDest, size_dest);
+  const int64_t ss[3] = {size_source[0], size_source[1], size_source[2]}, ds[3] = {size_dest[0], size_dest[1], size_dest[2]};
+  hip_detail::check(visfd_hip_unbin_array3d(hip_detail::context(), hip_detail::flat(aaafSource), ss,
+                                            hip_detail::flat(aaafDest), ds, offset));
+}
+
 // ---- blob list post-processing: lib/visfd/visfd_utils.hpp:49-55,95-118; feature.hpp:519-616,720-969 ------
 typedef enum eSortCriteria {
   DO_NOT_SORT = VISFD_HIP_DO_NOT_SORT,

@@ -63,6 +63,8 @@ class CpuLib:
             "tv_dense_stick": (None, [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
                                       C.c_float, C.c_int, C.c_int]),
             "tensor_saliency": (None, [_fp, _fp, C.c_int64, C.c_int, _fp]),
+            "bin_array3d": (C.c_int, [_fp, _ip, _fp, _ip, _ip]),
+            "unbin_array3d": (C.c_int, [_fp, _ip, _fp, _ip, _ip]),
         }
         if prefix == "vr_":   # blob list post-processing: checked against the reference directly
             _up = C.POINTER(C.c_uint64)
@@ -205,6 +207,21 @@ class CpuLib:
         self._fn["tensor_saliency"](_f(tensor), _f(mask), sal_inout.size, int(order), _f(sal_inout))
         return sal_inout
 
+
+    # ---- binning (resample.hpp:53-166); shapes are numpy [nz, ny, nx] ----------------------
+    def _resample(self, name, src, dst_shape, offset):
+        dst = np.empty(dst_shape, np.float32)
+        ssz, dsz = _i3(src.shape[::-1]), _i3(tuple(dst_shape)[::-1])
+        off = _i3(offset) if offset is not None else None
+        if self._fn[name](_f(src), ssz, _f(dst), dsz, off):
+            raise ValueError("bin offset out of range")
+        return dst
+
+    def bin_array3d(self, src, dst_shape, offset=None):
+        return self._resample("bin_array3d", src, dst_shape, offset)
+
+    def unbin_array3d(self, src, dst_shape, offset=None):
+        return self._resample("unbin_array3d", src, dst_shape, offset)
 
     # ---- blob list post-processing (reference harness only) -------------------------------
     @staticmethod

@@ -340,6 +340,20 @@ int64_t vr_discard_overlapping_blobs(float* crds, float* diam, float* score, int
   return lists_to_flat(c, d, s, crds, diam, score);
 }
 
-int vr_version() { return 2; }
+// ---- binning: resample.hpp:53-166 --------------------------------------------------------------
+int vr_bin_array3d(const float* src, const int* ssz, float* dst, const int* dsz, const int* offset) {
+  View3<const float> vs(src, ssz[0], ssz[1], ssz[2]);
+  View3<float> vd(dst, dsz[0], dsz[1], dsz[2]);
+  try { BinArray3D(ssz, dsz, (cf3)vs.p, vd.p, offset); } catch (VisfdErr&) { return 1; }
+  return 0;
+}
+int vr_unbin_array3d(const float* src, const int* ssz, float* dst, const int* dsz, const int* offset) {
+  View3<const float> vs(src, ssz[0], ssz[1], ssz[2]);
+  View3<float> vd(dst, dsz[0], dsz[1], dsz[2]);
+  try { UnbinArray3D(ssz, dsz, (cf3)vs.p, vd.p, offset); } catch (VisfdErr&) { return 1; }
+  return 0;
+}
+
+int vr_version() { return 3; }
 
 }  // extern "C"

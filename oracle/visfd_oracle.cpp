@@ -808,6 +808,52 @@ void vo_tensor_saliency(const float* tensor, const float* mask, int64_t n, int o
   }
 }
 
-int vo_version() { return 1; }
+// ---- binning (resample.hpp:53-166) ----------------------------------------------
+// sizes are {nx, ny, nz}; offset may be null.  Returns 0, or 1 for an offset outside [0, bin).
+int vo_bin_array3d(const float* src, const int* ssz, float* dst, const int* dsz, const int* offset) {
+  int b[3], o[3];
+  for (int d = 0; d < 3; d++) {
+    b[d] = ssz[d] / dsz[d];
+    o[d] = offset ? offset[d] : 0;
+    if (o[d] < 0 || o[d] >= b[d]) return 1;                                  // resample.hpp:63-69
+  }
+  for (int64_t Iz = 0; Iz < dsz[2]; Iz++)
+    for (int64_t Iy = 0; Iy < dsz[1]; Iy++)
+      for (int64_t Ix = 0; Ix < dsz[0]; Ix++) {
+        float sum = 0.0f;                                                      // resample.hpp:74-91: z, y, x order
+        for (int dz = 0; dz < b[2]; dz++)
+          for (int dy = 0; dy < b[1]; dy++)
+            for (int dx = 0; dx < b[0]; dx++) {
+              const int64_t ix = Ix * b[0] + dx + o[0], iy = Iy * b[1] + dy + o[1], iz = Iz * b[2] + dz + o[2];
+              sum = sum + src[(iz * ssz[1] + iy) * ssz[0] + ix];
+            }
+        dst[(Iz * dsz[1] + Iy) * dsz[0] + Ix] = sum / (float)(b[0] * b[1] * b[2]);   // :93 (Scalar / int)
+      }
+  return 0;
+}
+
+int vo_unbin_array3d(const float* src, const int* ssz, float* dst, const int* dsz, const int* offset) {
+  int b[3], o[3];
+  for (int d = 0; d < 3; d++) {
+    b[d] = dsz[d] / ssz[d];
+    o[d] = offset ? offset[d] : 0;
+    if (o[d] < 0 || o[d] >= b[d]) return 1;                                  // resample.hpp:129-135
+  }
+  for (int64_t Iz = 0; Iz < dsz[2]; Iz++)
+    for (int64_t Iy = 0; Iy < dsz[1]; Iy++)
+      for (int64_t Ix = 0; Ix < dsz[0]; Ix++) {
+        int64_t ix = (Ix - o[0]) / b[0], iy = (Iy - o[1]) / b[1], iz = (Iz - o[2]) / b[2];   // truncating division
+        if (ix < 0) ix = 0;
+        if (iy < 0) iy = 0;
+        if (iz < 0) iz = 0;
+        if (ix >= ssz[0]) ix = ssz[0] - 1;
+        if (iy >= ssz[1]) iy = ssz[1] - 1;
+        if (iz >= ssz[2]) iz = ssz[2] - 1;
+        dst[(Iz * dsz[1] + Iy) * dsz[0] + Ix] = src[(iz * ssz[1] + iy) * ssz[0] + ix];
+      }
+  return 0;
+}
+
+int vo_version() { return 2; }
 
 }  // extern "C"

@@ -126,3 +126,45 @@ def test_cli_discard_blobs_reference_scenario(cli, tmp_path):
     assert "2 blobs remaining" in r.stderr
     # same file names twice / missing separation value are usage errors
     assert run(cli, "-in", os.path.join(GOLDEN, "test_blob_detect.rec"), "-discard-blobs", src, src).returncode == 1
+
+
+@pytest.mark.gpu
+def test_cli_explicit_binning(cli, tmp_path, oracle):
+    """-bin 2 (filter_mrc.cpp:128-137, handlers.cpp:2361-2425): the image is averaged over 2x2x2 bins, the voxel
+    width doubles, and the filter runs on the small image; the output stays small."""
+    src = volgen.membrane_volume((30, 34, 44), seed=3)
+    inp, out = tmp_path / "in.rec", tmp_path / "out.rec"
+    volgen.write_mrc(str(inp), src, voxel_width=1.0)
+    r = run(cli, "-in", inp, "-out", out, "-w", 1, "-bin", 2, "-gauss", 3)
+    assert r.returncode == 0, r.stderr
+    binned = oracle.bin_array3d(src, (15, 17, 22))
+    want, _ = oracle.gauss_ratio(binned, (1.5,) * 3, oracle.ratio_from_threshold(0.03))
+    got = volgen.read_mrc(str(out))
+    assert got.shape == (15, 17, 22)
+    assert_bits_equal(got, want, "CLI -bin 2 -gauss")
+    hdr = np.frombuffer(open(out, "rb").read(1024), "<f4")
+    assert tuple(hdr[10:13]) == (44.0, 34.0, 30.0)     # cell = binned size x doubled voxel width
+
+
+@pytest.mark.gpu
+def test_cli_automatic_binning_for_wide_membranes(cli, tmp_path):
+    """A membrane detector whose sigma exceeds 1.8 voxels bins the image on its own (filter_mrc.cpp:140-175) and
+    un-bins the result afterwards (handlers.cpp:2315-2355): the automatic run equals the explicit `-bin N` run
+    un-binned, and has the input's size."""
+    src = volgen.membrane_volume((40, 48, 56), seed=5)
+    inp, out_auto, out_exp = tmp_path / "in.rec", tmp_path / "auto.rec", tmp_path / "exp.rec"
+    volgen.write_mrc(str(inp), src, voxel_width=1.0)
+    args = ["-in", inp, "-w", 1, "-membrane", "minima", 7, "-tv", 3, "-tv-angle-exponent", 4, "-tv-best", 0.15]
+    r = run(cli, *args, "-out", out_auto)
+    assert r.returncode == 0, r.stderr
+    assert "BINNING THE IMAGE BY A FACTOR OF" in r.stderr
+    n = int(r.stderr.split("BINNING THE IMAGE BY A FACTOR OF")[1].split()[0])
+    assert n >= 2
+    r2 = run(cli, *args, "-bin", n, "-out", out_exp)
+    assert r2.returncode == 0, r2.stderr
+    auto, small = volgen.read_mrc(str(out_auto)), volgen.read_mrc(str(out_exp))
+    assert auto.shape == src.shape and small.shape == tuple(d // n for d in src.shape)
+    iz, iy, ix = np.minimum(np.arange(40) // n, small.shape[0] - 1), np.minimum(np.arange(48) // n, small.shape[1] - 1), \
+        np.minimum(np.arange(56) // n, small.shape[2] - 1)
+    assert_bits_equal(auto, small[np.ix_(iz, iy, ix)], "automatic binning == explicit binning, un-binned")
+    assert np.abs(small).max() > 0

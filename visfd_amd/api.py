@@ -94,6 +94,10 @@ _SIGS = {
                                                 _fp]),
     "visfd_hip_tensor_saliency": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, _vp]),
     "visfd_hip_tensor_saliency_dev": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, _vp]),
+    "visfd_hip_bin_array3d": (C.c_int, [_vp, _vp, C.POINTER(_i64), _vp, C.POINTER(_i64), _ip]),
+    "visfd_hip_bin_array3d_dev": (C.c_int, [_vp, _vp, C.POINTER(_i64), _vp, C.POINTER(_i64), _ip]),
+    "visfd_hip_unbin_array3d": (C.c_int, [_vp, _vp, C.POINTER(_i64), _vp, C.POINTER(_i64), _ip]),
+    "visfd_hip_unbin_array3d_dev": (C.c_int, [_vp, _vp, C.POINTER(_i64), _vp, C.POINTER(_i64), _ip]),
     "visfd_hip_sphere_overlap": (C.c_float, [C.c_float, C.c_float, C.c_float]),
     "visfd_hip_sort_blobs": (C.c_int, [_fp, _fp, _fp, _i64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
     "visfd_hip_discard_masked_blobs": (C.c_int, [_fp, _fp, _fp, C.POINTER(_i64), _vp, _i64, _i64, _i64]),
@@ -399,6 +403,31 @@ class Context:
         self._chk(self._L.visfd_hip_tensor_saliency(self._h, _np(tensor), _np(mask), sal_inout.size, int(order),
                                                     _np(sal_inout)))
         return sal_inout
+
+    # ---- binning (resample.hpp:53-166); numpy shapes are [nz, ny, nx] -------------------------
+    @staticmethod
+    def _sizes(shape):
+        return (_i64 * 3)(int(shape[2]), int(shape[1]), int(shape[0]))
+
+    def bin_array3d(self, src, dst_shape, offset=None):
+        dst = np.empty(tuple(dst_shape), np.float32)
+        self._chk(self._L.visfd_hip_bin_array3d(self._h, _np(src), self._sizes(src.shape), _np(dst),
+                                                self._sizes(dst_shape), _i3(offset) if offset is not None else None))
+        return dst
+
+    def unbin_array3d(self, src, dst_shape, offset=None):
+        dst = np.empty(tuple(dst_shape), np.float32)
+        self._chk(self._L.visfd_hip_unbin_array3d(self._h, _np(src), self._sizes(src.shape), _np(dst),
+                                                  self._sizes(dst_shape), _i3(offset) if offset is not None else None))
+        return dst
+
+    def bin_array3d_dev(self, src, dst, offset=None):
+        self._chk(self._L.visfd_hip_bin_array3d_dev(self._h, _dev(src), self._sizes(src.shape), _dev(dst),
+                                                    self._sizes(dst.shape), _i3(offset) if offset is not None else None))
+
+    def unbin_array3d_dev(self, src, dst, offset=None):
+        self._chk(self._L.visfd_hip_unbin_array3d_dev(self._h, _dev(src), self._sizes(src.shape), _dev(dst),
+                                                      self._sizes(dst.shape), _i3(offset) if offset is not None else None))
 
     def membrane_detect(self, src, sigma, ratio, order, best_fraction=0.05, threshold_abs=0.0, sigma_tv=0.0,
                         tv_exponent=4, tv_cutoff=2.0 ** 0.5, mask=None, want_tensor=True, want_dir=False):

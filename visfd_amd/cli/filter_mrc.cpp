@@ -58,6 +58,13 @@ struct Mrc {
   }
   float* data() { return &a[0][0][0]; }
   size_t nvox() const { return (size_t)nx * ny * nz; }
+  void swap(Mrc& o) {
+    std::swap(nx, o.nx); std::swap(ny, o.ny); std::swap(nz, o.nz); std::swap(mode, o.mode);
+    std::swap(a, o.a); std::swap(loaded, o.loaded);
+    for (int d = 0; d < 3; d++) std::swap(cella[d], o.cella[d]);
+    unsigned char t[1024];
+    std::memcpy(t, raw_header, 1024); std::memcpy(raw_header, o.raw_header, 1024); std::memcpy(o.raw_header, t, 1024);
+  }
 
   void read(const string& path) {
     std::ifstream f(path.c_str(), std::ios::binary);
@@ -105,6 +112,10 @@ struct Mrc {
     std::memcpy(w, h, 1024);
     float fw[256];
     std::memcpy(fw, h, 1024);
+    if (nx != w[0] || ny != w[1] || nz != w[2]) {   // resized by binning: grid and cell follow the new size
+      w[7] = nx; w[8] = ny; w[9] = nz;
+      std::memcpy(&w[10], like.cella, 12);
+    }
     w[0] = nx; w[1] = ny; w[2] = nz; w[3] = 2;
     w[23] = 0;  // no extended header
     const size_t n = nvox();
@@ -125,6 +136,8 @@ struct Mrc {
 struct Settings {
   string in, out, mask, save_base;
   float voxel_width = -1;
+  int bin = 0;                 // settings.cpp:48-49: 0 = not specified (automatic), else the factor
+  bool bin_explicit = false;
   enum { NONE, GAUSS, DOG, LOG, BLOB, BLOB_NONMAX, SURFACE_RIDGE } type = NONE;
   float width_a[3] = {0, 0, 0}, width_b[3] = {0, 0, 0}, log_width[3] = {0, 0, 0};
   float truncate_ratio = -1.0f, truncate_threshold = 0.03f;   // settings.cpp:81,88
@@ -168,7 +181,10 @@ Settings parse(int argc, char** argv) {
     else if (f == "-np") { need(1); i += 2; }  // host threads: not used by the GPU path
     else if (f == "-bin") {
       need(1);
-      if (num(v, i + 1, f) != 1.0f) throw VisfdErr("Error: this build supports \"-bin 1\" only (binning is not on the GPU hot path).\n");
+      const float b = num(v, i + 1, f);
+      if (b < 1.0f || b != std::floor(b)) throw VisfdErr("Error: The " + f + " argument must be followed by a positive integer.\n");
+      s.bin = (int)b;              // settings.cpp:703-716
+      s.bin_explicit = true;
       i += 2;
     }
     else if (f == "-gauss") { need(1); s.width_a[0] = s.width_a[1] = s.width_a[2] = num(v, i + 1, f); s.type = Settings::GAUSS; i += 2; }
@@ -358,6 +374,36 @@ void handle_blob_nonmax(const Settings& s, const float vw[3], float const* const
   }
 }
 
+// HandleBinning, bin/filter_mrc/handlers.cpp:2361-2425: the image (and the mask) shrink by `bin` per axis
+// (BinArray3D averages; trailing voxels are dropped) and the voxel width grows by the same factor.
+void bin_image(Mrc& img, int bin, double voxel_width_binned) {
+  int ssz[3] = {img.nx, img.ny, img.nz};
+  int dsz[3] = {img.nx / bin, img.ny / bin, img.nz / bin};
+  if (dsz[0] < 1 || dsz[1] < 1 || dsz[2] < 1) throw VisfdErr("Error: the image is too small for this bin size.\n");
+  Mrc tmp;
+  tmp.alloc(dsz[0], dsz[1], dsz[2]);
+  BinArray3D(ssz, dsz, img.a, tmp.a);
+  std::memcpy(tmp.raw_header, img.raw_header, 1024);
+  tmp.mode = img.mode;
+  tmp.loaded = true;
+  for (int d = 0; d < 3; d++) tmp.cella[d] = (float)(voxel_width_binned * dsz[d]);
+  img.swap(tmp);
+}
+
+// the tail of HandleTV (handlers.cpp:2315-2355): an image that was binned WITHOUT the user asking for it
+// goes back to the original size (nearest-lower sampling)
+void unbin_image(Mrc& img, const int size_orig[3], const float cella_orig[3]) {
+  int ssz[3] = {img.nx, img.ny, img.nz};
+  Mrc big;
+  big.alloc(size_orig[0], size_orig[1], size_orig[2]);
+  UnbinArray3D(ssz, size_orig, img.a, big.a);
+  std::memcpy(big.raw_header, img.raw_header, 1024);
+  big.mode = img.mode;
+  big.loaded = true;
+  for (int d = 0; d < 3; d++) big.cella[d] = cella_orig[d];
+  img.swap(big);
+}
+
 float ratio_of(const Settings& s) {
   return s.truncate_ratio > 0 ? s.truncate_ratio : visfd_hip_ratio_from_threshold(s.truncate_threshold);
 }
@@ -382,6 +428,30 @@ int main(int argc, char** argv) {
       vw[0] = tomo_in.cella[0] / size[0];  // handlers.cpp:2429-2475: inferred from the header
       vw[1] = vw[2] = vw[0];
       if (!(vw[0] > 0)) vw[0] = vw[1] = vw[2] = 1.0f;
+    }
+    // ---- binning (filter_mrc.cpp:118-209): explicit (-bin N) or automatic for wide features ----
+    const int size_orig[3] = {size[0], size[1], size[2]};
+    const float cella_orig[3] = {tomo_in.cella[0], tomo_in.cella[1], tomo_in.cella[2]};
+    int bin = s.bin;
+    if (bin == 0) {
+      bin = 1;
+      if (s.tv_sigma > 0 && s.width_a[0] > 1.8 * vw[0])
+        bin = (int)std::ceil(s.width_a[0] / (1.8 * vw[0]));
+      else if (!(s.tv_sigma > 0) && !s.blob_diameters.empty() && s.blob_diameters[0] > 15.0 * vw[0])
+        bin = (int)std::ceil(s.blob_diameters[0] / (15.0 * vw[0]));
+      if (bin > 1)
+        cerr << "--- WARNING: this would be very slow unless binning is used.\n"
+                "--- BINNING THE IMAGE BY A FACTOR OF " << bin << "\n"
+                "---           To prevent this, use the \"-bin 1\" argument.\n";
+    }
+    if (bin > 1) {
+      const double w0 = s.voxel_width > 0 ? (double)s.voxel_width : (double)(tomo_in.cella[0] / tomo_in.nx);
+      const double wb = w0 * bin;                      // handlers.cpp:2372-2385
+      bin_image(tomo_in, bin, wb);
+      if (mask.loaded) bin_image(mask, bin, wb);
+      size[0] = tomo_in.nx; size[1] = tomo_in.ny; size[2] = tomo_in.nz;
+      if (s.voxel_width > 0) vw[0] = vw[1] = vw[2] = s.voxel_width * bin;           // handlers.cpp:2445-2460
+      else for (int d = 0; d < 3; d++) vw[d] = tomo_in.cella[d] / size[d];
     }
     cerr << "voxel width = " << vw[0] << "\n";
     for (int d = 0; d < 3; d++) { s.width_a[d] /= vw[d]; s.width_b[d] /= vw[d]; s.log_width[d] /= vw[d]; }
@@ -464,6 +534,12 @@ int main(int argc, char** argv) {
           t.write(name.str(), tomo_in);
         }
       }
+    }
+    if (s.type == Settings::SURFACE_RIDGE && bin > 1 && !s.bin_explicit) {   // handlers.cpp:2315-2355
+      tomo_out.loaded = true;
+      std::memcpy(tomo_out.raw_header, tomo_in.raw_header, 1024);
+      unbin_image(tomo_out, size_orig, cella_orig);
+      unbin_image(tomo_in, size_orig, cella_orig);   // only its header/size is used below
     }
     if (!s.out.empty()) {
       cerr << "writing tomogram (in 32-bit float mode)\n";

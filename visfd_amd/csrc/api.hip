@@ -583,6 +583,49 @@ int visfd_hip_apply_threshold_dev(visfd_hip_ctx* ctx, float* sal, int64_t nvox, 
   return dev_apply_threshold(ctx, sal, nvox, thr);
 }
 
+// ---- f4: binning ------------------------------------------------------------------------------
+int visfd_hip_bin_array3d_dev(visfd_hip_ctx* ctx, const float* src, const int64_t size_src[3], float* dst,
+                              const int64_t size_dst[3], const int* offset) {
+  VH_REQUIRE(ctx && src && dst && size_src && size_dst, "null argument");
+  VH_HIP(hipSetDevice(ctx->device));
+  return dev_bin_array3d(ctx, src, size_src, dst, size_dst, offset);
+}
+
+int visfd_hip_unbin_array3d_dev(visfd_hip_ctx* ctx, const float* src, const int64_t size_src[3], float* dst,
+                                const int64_t size_dst[3], const int* offset) {
+  VH_REQUIRE(ctx && src && dst && size_src && size_dst, "null argument");
+  VH_HIP(hipSetDevice(ctx->device));
+  return dev_unbin_array3d(ctx, src, size_src, dst, size_dst, offset);
+}
+
+int visfd_hip_bin_array3d(visfd_hip_ctx* ctx, const float* src, const int64_t size_src[3], float* dst,
+                          const int64_t size_dst[3], const int* offset) {
+  VH_REQUIRE(ctx && src && dst && size_src && size_dst, "null argument");
+  VH_HIP(hipSetDevice(ctx->device));
+  VH_TRY(check_dims(size_src[0], size_src[1], size_src[2]));
+  VH_TRY(check_dims(size_dst[0], size_dst[1], size_dst[2]));
+  const size_t ns = (size_t)(size_src[0] * size_src[1] * size_src[2]), nd = (size_t)(size_dst[0] * size_dst[1] * size_dst[2]);
+  float *ds, *dd;
+  VH_TRY(upload(ctx, WS_H2D_0, src, ns, &ds));
+  VH_TRY(ws(ctx, WS_H2D_2, nd, &dd));
+  VH_TRY(dev_bin_array3d(ctx, ds, size_src, dd, size_dst, offset));
+  return download(ctx, dst, dd, nd);
+}
+
+int visfd_hip_unbin_array3d(visfd_hip_ctx* ctx, const float* src, const int64_t size_src[3], float* dst,
+                            const int64_t size_dst[3], const int* offset) {
+  VH_REQUIRE(ctx && src && dst && size_src && size_dst, "null argument");
+  VH_HIP(hipSetDevice(ctx->device));
+  VH_TRY(check_dims(size_src[0], size_src[1], size_src[2]));
+  VH_TRY(check_dims(size_dst[0], size_dst[1], size_dst[2]));
+  const size_t ns = (size_t)(size_src[0] * size_src[1] * size_src[2]), nd = (size_t)(size_dst[0] * size_dst[1] * size_dst[2]);
+  float *ds, *dd;
+  VH_TRY(upload(ctx, WS_H2D_0, src, ns, &ds));
+  VH_TRY(ws(ctx, WS_H2D_2, nd, &dd));
+  VH_TRY(dev_unbin_array3d(ctx, ds, size_src, dd, size_dst, offset));
+  return download(ctx, dst, dd, nd);
+}
+
 // ---- a13 + a14 -------------------------------------------------------------------------------
 int visfd_hip_tv_tables(float sigma_tv, float cutoff, int* h_out, float* w, float* rhat) {
   const int h = host_tv_halfwidth(sigma_tv, cutoff);

@@ -135,6 +135,12 @@ int dev_tv_dense_stick(visfd_hip_ctx* ctx, const float* sal, const float* dir_pl
                        i64 ny, i64 nz, i64 z_out0, i64 z_out1, float sigma_tv, int exponent,
                        float cutoff, bool curves);
 
+// resample.hip (sizes are {nx, ny, nz}; offset nullable)
+int dev_bin_array3d(visfd_hip_ctx* ctx, const float* src, const int64_t size_src[3], float* dst,
+                    const int64_t size_dst[3], const int* offset);
+int dev_unbin_array3d(visfd_hip_ctx* ctx, const float* src, const int64_t size_src[3], float* dst,
+                      const int64_t size_dst[3], const int* offset);
+
 // layout helpers for the host-pointer face
 int dev_interleaved_to_planar(visfd_hip_ctx* ctx, const float* aos, float* planar, i64 n, int channels);
 int dev_planar_to_interleaved(visfd_hip_ctx* ctx, const float* planar, float* aos, i64 n, int channels,

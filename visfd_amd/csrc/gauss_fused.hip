@@ -354,14 +354,18 @@ int VH_CAT(launch_gauss_fused_h, VH_FUSED_H)(visfd_hip_ctx* ctx, const float* sr
   if (cfg == 12) return launch_cfg<H, 96, 32, 512, 4, 1>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
 #endif
   (void)cfg;
-  // tilings picked from a sweep on MI355X (1024^3, gpurun_out/perf3.log): wider tiles cut the halo
-  // recomputation of the Z and Y passes, which is what bounds this kernel (VALU, not HBM)
+  // tilings picked from sweeps on MI355X (1024^3; profiles/r01_gauss_tiling_sweep.txt): wide tiles cut the
+  // halo recomputation of the Z and Y passes (the kernel is VALU-bound), until the register ring
+  // (columns per thread x (2H+1)) no longer fits 128 VGPRs; with the 64-wide tile the X pass needs two
+  // outputs per lane to fill its wave, and single-column Y tasks pack the rounds better
   if constexpr (H <= 3)
-    return launch_cfg<H, 128, 16, 512>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
-  else if constexpr (H <= 6)
-    return launch_cfg<H, 128, 32, 1024>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
+    return launch_cfg<H, 128, 16, 512, 4, 2>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
+  else if constexpr (H <= 5)
+    return launch_cfg<H, 128, 32, 1024, 4, 2>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
+  else if constexpr (H <= 8)
+    return launch_cfg<H, 64, 32, 1024, 2, 1>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
   else
-    return launch_cfg<H, 64, 32, 1024>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
+    return launch_cfg<H, 64, 32, 1024, 2, 2>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
 }
 
 }  // namespace vh
