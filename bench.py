@@ -222,7 +222,7 @@ def main():
     value = nvox_rank * world / (ms_per_step * 1e-3) / 1e6  # Mvoxels/s, whole job
 
     # ---- roofline of the separable-Gaussian kernel, timed alone with HIP events ----------------
-    roofline = None
+    roofline = roofline_pass = None
     if rank == 0:
         reps = 10
         pipeline.gauss(ctx, src, dst, GAUSS_SIGMA)
@@ -253,6 +253,28 @@ def main():
                     "ms_per_launch": round(g_ms, 4), "voxels_per_launch": nv,
                     "note": "exact mul+add arithmetic (no FMA) makes this kernel VALU-bound, see DESIGN.md"}
 
+        # one 1-D pass of the separable Gaussian (the 3-pass path used for masks, ragged widths and wide windows):
+        # three launches (Z, Y, X with the normalisation), 8 B/voxel each; average launch time = total / 3
+        os.environ["VISFD_HIP_GAUSS_3PASS"] = "1"
+        try:
+            pipeline.gauss(ctx, src, dst, GAUSS_SIGMA)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(reps):
+                pipeline.gauss(ctx, src, dst, GAUSS_SIGMA)
+            e1.record()
+            torch.cuda.synchronize()
+        finally:
+            del os.environ["VISFD_HIP_GAUSS_3PASS"]
+        p_ms = e0.elapsed_time(e1) / reps / 3.0
+        p_ach = 8.0 * nv / (p_ms * 1e-3) / 1e9
+        roofline_pass = {"bound": "hbm", "kernel": "conv_march_kernel<5> (Z, Y) / conv_row_kernel<5> (X): one 1-D pass of "
+                                                   "the separable Gaussian, sigma=2",
+                         "achieved": round(p_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(p_ach / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes": 8 * nv,
+                         "ms_per_launch": round(p_ms, 4), "voxels_per_launch": nv,
+                         "note": "average of the three pass launches; a device copy on this box runs at ~5.0 TB/s"}
+
     if rank == 0:
         out = {
             "metric": "Mvoxels/s (Gauss+DoG+TV pipeline) on %d^3 float32; %% HBM roofline" % S,
@@ -267,6 +289,7 @@ def main():
                           "membrane_tv": round(stage_ms[2] / args.steps, 3)},
             "results": counts,
             "roofline": roofline,
+            "roofline_pass": roofline_pass,
         }
         if not args.no_cpu and world == 1:  # the CPU baseline is an N=1 line only
             try:

@@ -20,66 +20,207 @@ namespace {
 
 constexpr int BLOCK = 256;
 
-// ---------------------------------------------------------------------------------------------
-// Generic single-axis pass: one thread per output voxel, x-contiguous threads (coalesced for all
-// three axes).  Used for the masked path, for very wide filters and as the fallback of the fused
-// kernel below.  Re-reads of the 2h+1 neighbours are served by L1/L2.
-// ---------------------------------------------------------------------------------------------
 enum { NORM_NONE = 0, NORM_BOX = 1, NORM_DEN = 2 };
 
-template <int AXIS, bool MASKED, int NORM>
+// ---------------------------------------------------------------------------------------------
+// Tuned single-axis passes (one read + one write of the volume each, 8 B/voxel): the source
+// window is staged in LDS, so HBM sees every input once per tile (halo overhead (T+2h)/T) and the
+// 2h+1 re-reads per output are LDS reads.  HT > 0 fixes the half-width at compile time (taps as
+// SGPR operands, fully unrolled sums); HT == 0 takes any half-width up to MAX_HALFWIDTH.
+//
+// conv_march_kernel: the Y or Z pass.  A block of 256 threads = 64 x-columns x 4 groups handles a
+// tile of 64 columns x MARCH_T outputs along the filtered ("march") axis; LDS holds
+// (MARCH_T + 2h) x 64 source values (rows outside the image are zeros: zero extension).  The
+// masked form (Z pass of the masked filter, filter1d.hpp:204-295) also stages the mask, forms
+// w = t*mask first, then w*f, accumulates the denominator, and restates the "no unmasked sample
+// under the window" shortcut.
+// ---------------------------------------------------------------------------------------------
+constexpr int MARCH_T = 128;   // outputs per block along the filtered axis
+constexpr int MARCH_X = 64;    // x-columns per block
+
+template <int HT>
+struct TapsK {
+  float t[2 * (HT > 0 ? HT : 1) + 1];
+};
+
+template <int HT, bool MASKED>
 __global__ void __launch_bounds__(BLOCK)
-conv_axis_kernel(const float* __restrict__ in, float* __restrict__ out,
-                 const float* __restrict__ mask, float* __restrict__ den_out,
-                 const float* __restrict__ den_in,  // NORM_DEN: final denominator volume
-                 const float* __restrict__ Dx, const float* __restrict__ Dy,
-                 const float* __restrict__ Dz, i64 dz_offset,
-                 Taps taps, i64 nx, i64 ny, i64 nz) {
-  const i64 xblocks = (nx + BLOCK - 1) / BLOCK;
-  i64 b = blockIdx.x;
-  const i64 bx = b % xblocks;
+conv_march_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ mask,
+                  float* __restrict__ den_out, TapsK<HT> tk, Taps taps_rt, int nx, int n_march, int n_other,
+                  i64 stride_march, i64 stride_other, int xblocks, int mblocks) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int h = HT > 0 ? HT : taps_rt.h;
+  const int W = 2 * h + 1;
+  const int rows = MARCH_T + 2 * h;
+  float* sF = lds;
+  float* sM = lds + rows * MARCH_X;   // masked form only
+  unsigned b = blockIdx.x;
+  const int bx = b % xblocks;
   b /= xblocks;
-  const i64 iy = b % ny;
-  const i64 iz = b / ny;
-  const i64 ix = bx * BLOCK + threadIdx.x;
-  if (ix >= nx) return;
-  const i64 plane = nx * ny;
-  const i64 c = iz * plane + iy * nx + ix;
-  const int h = taps.h;
-  const i64 n = (AXIS == 0) ? nx : (AXIS == 1) ? ny : nz;
-  const i64 i = (AXIS == 0) ? ix : (AXIS == 1) ? iy : iz;
-  const i64 stride = (AXIS == 0) ? 1 : (AXIS == 1) ? nx : plane;
-  float acc = 0.0f;
-  float den = 0.0f;
-  bool any = false;
-  // j ascending  <=>  source index k = i - j descending
-  int jlo = -h, jhi = h;
-  if (i - jlo > n - 1) jlo = (int)(i - (n - 1));  // k <= n-1
-  if (i - jhi < 0) jhi = (int)i;                  // k >= 0
-  for (int j = jlo; j <= jhi; j++) {
-    const i64 k = c - (i64)j * stride;
-    float w = taps.t[j + h];
-    if (MASKED) {
-      const float m = mask[k];
-      any = any || (m != 0.0f);
-      w = w * m;
-      den = den + w;
+  const int bm = b % mblocks;
+  const int o = b / mblocks;
+  const int tx = threadIdx.x & (MARCH_X - 1), g = threadIdx.x / MARCH_X;
+  const int x = bx * MARCH_X + tx;
+  const int m0 = bm * MARCH_T;
+  const bool xin = x < nx;
+  const i64 base = (i64)o * stride_other + x;
+  // stage rows m0-h .. m0+MARCH_T+h-1 (LDS row r <-> m = m0 - h + r): 16 threads x float4 per row, 16 rows per
+  // sweep, all loads of a batch issued before their LDS stores (the loop is latency-bound otherwise)
+  {
+    const int c4 = (threadIdx.x & 15) * 4, rr = threadIdx.x >> 4;
+    const int xs = bx * MARCH_X + c4;
+    const bool vec_ok = ((nx & 3) == 0) && xs + 3 < nx;   // whole float4 inside the row and 16-byte aligned
+    constexpr int SWEEP = BLOCK / 16;                     // rows per sweep
+    constexpr int BATCH = 5;                              // sweeps in flight
+    for (int r0 = 0; r0 < rows; r0 += SWEEP * BATCH) {
+      float4 vf[BATCH], vm[BATCH];
+#pragma unroll
+      for (int u = 0; u < BATCH; u++) {
+        const int r = r0 + u * SWEEP + rr;
+        const int m = m0 - h + r;
+        const bool ok = r < rows && m >= 0 && m < n_march;
+        const i64 a = (i64)o * stride_other + (i64)m * stride_march + xs;
+        vf[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        vm[u] = vf[u];
+        if (ok && vec_ok) {
+          vf[u] = *reinterpret_cast<const float4*>(in + a);
+          if (MASKED) vm[u] = *reinterpret_cast<const float4*>(mask + a);
+        } else if (ok) {
+          float* pf = &vf[u].x;
+          float* pm = &vm[u].x;
+          for (int e = 0; e < 4; e++)
+            if (xs + e < nx) { pf[e] = in[a + e]; if (MASKED) pm[e] = mask[a + e]; }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < BATCH; u++) {
+        const int r = r0 + u * SWEEP + rr;
+        if (r < rows) {
+          *reinterpret_cast<float4*>(&sF[r * MARCH_X + c4]) = vf[u];
+          if (MASKED) *reinterpret_cast<float4*>(&sM[r * MARCH_X + c4]) = vm[u];
+        }
+      }
     }
-    const float term = w * in[k];
-    acc = acc + term;
   }
-  if (MASKED) {
-    if (!any) { acc = 0.0f; den = 0.0f; }
-    if (den_out) den_out[c] = den;
+  __syncthreads();
+  if (!xin) return;
+  constexpr int PER = MARCH_T / (BLOCK / MARCH_X);   // consecutive outputs per thread
+  for (int q = 0; q < PER; q++) {
+    const int k = g * PER + q;
+    const int m = m0 + k;
+    if (m >= n_march) break;
+    // j ascending <=> source row descending: r = k + 2h - jj
+    const float* pf = sF + (k + 2 * h) * MARCH_X + tx;
+    const float* pm = sM + (k + 2 * h) * MARCH_X + tx;
+    float acc = 0.0f, den = 0.0f;
+    bool any = false;
+    if (HT > 0) {
+#pragma unroll
+      for (int jj = 0; jj < 2 * HT + 1; jj++) {
+        float w = tk.t[jj];
+        if (MASKED) {
+          const float mv = pm[-jj * MARCH_X];
+          any = any || (mv != 0.0f);
+          w = w * mv;
+          den = den + w;
+        }
+        const float term = w * pf[-jj * MARCH_X];
+        acc = acc + term;
+      }
+    } else {
+      for (int jj = 0; jj < W; jj++) {
+        float w = taps_rt.t[jj];
+        if (MASKED) {
+          const float mv = pm[-jj * MARCH_X];
+          any = any || (mv != 0.0f);
+          w = w * mv;
+          den = den + w;
+        }
+        const float term = w * pf[-jj * MARCH_X];
+        acc = acc + term;
+      }
+    }
+    const i64 c = base + (i64)m * stride_march;
+    if (MASKED) {
+      if (!any) { acc = 0.0f; den = 0.0f; }
+      if (den_out) den_out[c] = den;
+    }
+    out[c] = acc;
   }
-  if (NORM == NORM_BOX) {
-    const float d = (Dx[ix] * Dy[iy]) * Dz[iz + dz_offset];
-    acc = acc / d;
-  } else if (NORM == NORM_DEN) {
-    const float d = den_in[c];
-    if (d > 0.0f) acc = acc / d;
+}
+
+// conv_row_kernel: the X pass.  A block handles ROW_X consecutive x of ROW_Y rows (same z); LDS
+// holds the ROW_Y x (ROW_X + 2h) source values; one thread per x computes the ROW_Y outputs of
+// its column position.  NORM_BOX / NORM_DEN fold the normalisation of filter3d.hpp:986-1026 in.
+constexpr int ROW_X = 256;
+constexpr int ROW_Y = 8;
+static_assert(ROW_X == BLOCK && 2 * MAX_HALFWIDTH <= BLOCK, "the row tile is staged with two loads per thread");
+
+template <int HT, int NORM>
+__global__ void __launch_bounds__(BLOCK)
+conv_row_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ den_in,
+                const float* __restrict__ Dx, const float* __restrict__ Dy, const float* __restrict__ Dz,
+                i64 dz_offset, TapsK<HT> tk, Taps taps_rt, int nx, int ny, int nz, int xblocks, int yblocks) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int h = HT > 0 ? HT : taps_rt.h;
+  const int W = 2 * h + 1;
+  const int span = ROW_X + 2 * h;      // LDS row length; LDS index s <-> x = x0 - h + s
+  unsigned b = blockIdx.x;
+  const int bx = b % xblocks;
+  b /= xblocks;
+  const int by = b % yblocks;
+  const int iz = b / yblocks;
+  const int x0 = bx * ROW_X, y0 = by * ROW_Y;
+  const int t = threadIdx.x;
+  const i64 plane = (i64)nx * ny;
+  {  // all loads of the tile issued before the LDS stores: per row a main element and (first 2h threads) a tail one
+    float va[ROW_Y], vb[ROW_Y];
+#pragma unroll
+    for (int r = 0; r < ROW_Y; r++) {
+      const int y = y0 + r;
+      const float* row = in + (i64)iz * plane + (i64)y * nx;
+      const int xa = x0 - h + t, xb = xa + BLOCK;
+      va[r] = (y < ny && xa >= 0 && xa < nx) ? row[xa] : 0.0f;
+      vb[r] = (t < 2 * h && y < ny && xb >= 0 && xb < nx) ? row[xb] : 0.0f;
+    }
+#pragma unroll
+    for (int r = 0; r < ROW_Y; r++) {
+      lds[r * span + t] = va[r];
+      if (t < 2 * h) lds[r * span + t + BLOCK] = vb[r];
+    }
   }
-  out[c] = acc;
+  __syncthreads();
+  const int x = x0 + t;
+  if (x >= nx) return;
+  float dxz = 1.0f;
+  if (NORM == NORM_BOX) dxz = Dx[x];
+  for (int r = 0; r < ROW_Y; r++) {
+    const int y = y0 + r;
+    if (y >= ny) break;
+    const float* p = lds + r * span + t + 2 * h;   // j ascending <=> s descending: s = t + 2h - jj
+    float acc = 0.0f;
+    if (HT > 0) {
+#pragma unroll
+      for (int jj = 0; jj < 2 * HT + 1; jj++) {
+        const float term = tk.t[jj] * p[-jj];
+        acc = acc + term;
+      }
+    } else {
+      for (int jj = 0; jj < W; jj++) {
+        const float term = taps_rt.t[jj] * p[-jj];
+        acc = acc + term;
+      }
+    }
+    const i64 c = (i64)iz * plane + (i64)y * nx + x;
+    if (NORM == NORM_BOX) {
+      const float d = (dxz * Dy[y]) * Dz[iz + dz_offset];
+      acc = acc / d;
+    } else if (NORM == NORM_DEN) {
+      const float d = den_in[c];
+      if (d > 0.0f) acc = acc / d;
+    }
+    out[c] = acc;
+  }
 }
 
 __global__ void __launch_bounds__(BLOCK)
@@ -99,6 +240,60 @@ int fill_taps(Taps* T, const float* t, int h) {
   std::memset(T, 0, sizeof(Taps));
   T->h = h;
   for (int k = 0; k < 2 * h + 1; k++) T->t[k] = t[k];
+  return VISFD_HIP_OK;
+}
+
+template <int HT>
+TapsK<HT> taps_k(const Taps& T) {
+  TapsK<HT> k;
+  for (int i = 0; i < 2 * (HT > 0 ? HT : 1) + 1; i++) k.t[i] = HT > 0 ? T.t[i] : 0.0f;
+  return k;
+}
+
+#define VH_FOR_H(h, ...)                                                                            \
+  switch (h) {                                                                                      \
+    case 1: { constexpr int HT = 1; __VA_ARGS__; } break;   case 2: { constexpr int HT = 2; __VA_ARGS__; } break;   \
+    case 3: { constexpr int HT = 3; __VA_ARGS__; } break;   case 4: { constexpr int HT = 4; __VA_ARGS__; } break;   \
+    case 5: { constexpr int HT = 5; __VA_ARGS__; } break;   case 6: { constexpr int HT = 6; __VA_ARGS__; } break;   \
+    case 7: { constexpr int HT = 7; __VA_ARGS__; } break;   case 8: { constexpr int HT = 8; __VA_ARGS__; } break;   \
+    case 9: { constexpr int HT = 9; __VA_ARGS__; } break;   case 10: { constexpr int HT = 10; __VA_ARGS__; } break; \
+    default: { constexpr int HT = 0; __VA_ARGS__; } break;                                                 \
+  }
+
+// Y pass (axis 1) or Z pass (axis 2) of a [nz][ny][nx] volume
+template <bool MASKED>
+int launch_march(visfd_hip_ctx* ctx, int axis, const float* in, float* out, const float* mask, float* den_out,
+                 const Taps& T, i64 nx, i64 ny, i64 nz) {
+  const i64 plane = nx * ny;
+  const int n_march = (int)(axis == 1 ? ny : nz), n_other = (int)(axis == 1 ? nz : ny);
+  const i64 stride_march = axis == 1 ? nx : plane, stride_other = axis == 1 ? plane : nx;
+  const int xblocks = (int)((nx + MARCH_X - 1) / MARCH_X), mblocks = (n_march + MARCH_T - 1) / MARCH_T;
+  const i64 nblk = (i64)xblocks * mblocks * n_other;
+  if (nblk > 0x7fffffffLL) return fail(VISFD_HIP_EINVAL, "volume too large for one launch");
+  const size_t lds = sizeof(float) * (size_t)(MARCH_T + 2 * T.h) * MARCH_X * (MASKED ? 2 : 1);
+  VH_FOR_H(T.h, {
+    auto kern = conv_march_kernel<HT, MASKED>;
+    if (lds > 48 * 1024)
+      VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    kern<<<dim3((unsigned)nblk), dim3(BLOCK), lds, ctx->stream>>>(in, out, mask, den_out, taps_k<HT>(T), T, (int)nx, n_march,
+                                                                  n_other, stride_march, stride_other, xblocks, mblocks);
+  })
+  VH_HIP(hipGetLastError());
+  return VISFD_HIP_OK;
+}
+
+template <int NORM>
+int launch_row(visfd_hip_ctx* ctx, const float* in, float* out, const float* den_in, const float* Dx, const float* Dy,
+               const float* Dz, i64 dz_offset, const Taps& T, i64 nx, i64 ny, i64 nz) {
+  const int xblocks = (int)((nx + ROW_X - 1) / ROW_X), yblocks = (int)((ny + ROW_Y - 1) / ROW_Y);
+  const i64 nblk = (i64)xblocks * yblocks * nz;
+  if (nblk > 0x7fffffffLL) return fail(VISFD_HIP_EINVAL, "volume too large for one launch");
+  const size_t lds = sizeof(float) * (size_t)ROW_Y * (ROW_X + 2 * T.h);
+  VH_FOR_H(T.h, {
+    conv_row_kernel<HT, NORM><<<dim3((unsigned)nblk), dim3(BLOCK), lds, ctx->stream>>>(
+        in, out, den_in, Dx, Dy, Dz, dz_offset, taps_k<HT>(T), T, (int)nx, (int)ny, (int)nz, xblocks, yblocks);
+  })
+  VH_HIP(hipGetLastError());
   return VISFD_HIP_OK;
 }
 
@@ -152,10 +347,6 @@ int dev_separable3d(visfd_hip_ctx* ctx, const float* src, float* dst, const floa
   if (A_out) *A_out = (tx[hx] * ty[hy]) * tz[hz];  // filter3d.hpp:1044-1046
   const i64 n = nx * ny * nz;
   hipStream_t st = ctx->stream;
-  const i64 xblocks = (nx + BLOCK - 1) / BLOCK;
-  const i64 nblocks = xblocks * ny * nz;
-  if (nblocks > 0x7fffffffLL) return fail(VISFD_HIP_EINVAL, "volume too large for one launch");
-  const dim3 grid((unsigned)nblocks), block(BLOCK);
 
   // boundary normaliser lines (unmasked case): host arithmetic, a few KB
   float *Dx = nullptr, *Dy = nullptr, *Dz = nullptr;
@@ -192,38 +383,25 @@ int dev_separable3d(visfd_hip_ctx* ctx, const float* src, float* dst, const floa
   float *A = nullptr, *B = nullptr;
   VH_TRY(ws(ctx, WS_A, (size_t)n, &A));
   VH_TRY(ws(ctx, WS_B, (size_t)n, &B));
+  if (nx >= (1LL << 31) || ny >= (1LL << 31) || nz >= (1LL << 31)) return fail(VISFD_HIP_EINVAL, "image dimension too large");
   if (!mask) {
-    conv_axis_kernel<2, false, NORM_NONE><<<grid, block, 0, st>>>(
-        src, A, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, Tz, nx, ny, nz);
-    conv_axis_kernel<1, false, NORM_NONE><<<grid, block, 0, st>>>(
-        A, B, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, Ty, nx, ny, nz);
-    if (normalize)
-      conv_axis_kernel<0, false, NORM_BOX><<<grid, block, 0, st>>>(
-          B, dst, nullptr, nullptr, nullptr, Dx, Dy, Dz, slab.z_lo, Tx, nx, ny, nz);
-    else
-      conv_axis_kernel<0, false, NORM_NONE><<<grid, block, 0, st>>>(
-          B, dst, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, Tx, nx, ny, nz);
+    VH_TRY(launch_march<false>(ctx, 2, src, A, nullptr, nullptr, Tz, nx, ny, nz));
+    VH_TRY(launch_march<false>(ctx, 1, A, B, nullptr, nullptr, Ty, nx, ny, nz));
+    if (normalize) VH_TRY(launch_row<NORM_BOX>(ctx, B, dst, nullptr, Dx, Dy, Dz, slab.z_lo, Tx, nx, ny, nz));
+    else VH_TRY(launch_row<NORM_NONE>(ctx, B, dst, nullptr, nullptr, nullptr, nullptr, 0, Tx, nx, ny, nz));
   } else if (!normalize) {
-    conv_axis_kernel<2, true, NORM_NONE><<<grid, block, 0, st>>>(
-        src, A, mask, nullptr, nullptr, nullptr, nullptr, nullptr, 0, Tz, nx, ny, nz);
-    conv_axis_kernel<1, false, NORM_NONE><<<grid, block, 0, st>>>(
-        A, B, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, Ty, nx, ny, nz);
-    conv_axis_kernel<0, false, NORM_NONE><<<grid, block, 0, st>>>(
-        B, dst, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, Tx, nx, ny, nz);
+    VH_TRY(launch_march<true>(ctx, 2, src, A, mask, nullptr, Tz, nx, ny, nz));
+    VH_TRY(launch_march<false>(ctx, 1, A, B, nullptr, nullptr, Ty, nx, ny, nz));
+    VH_TRY(launch_row<NORM_NONE>(ctx, B, dst, nullptr, nullptr, nullptr, nullptr, 0, Tx, nx, ny, nz));
   } else {
     float *DA = nullptr, *DB = nullptr;
     VH_TRY(ws(ctx, WS_DEN_A, (size_t)n, &DA));
     VH_TRY(ws(ctx, WS_DEN_B, (size_t)n, &DB));
-    conv_axis_kernel<2, true, NORM_NONE><<<grid, block, 0, st>>>(
-        src, A, mask, DA, nullptr, nullptr, nullptr, nullptr, 0, Tz, nx, ny, nz);
-    conv_axis_kernel<1, false, NORM_NONE><<<grid, block, 0, st>>>(
-        A, B, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, Ty, nx, ny, nz);
-    conv_axis_kernel<1, false, NORM_NONE><<<grid, block, 0, st>>>(
-        DA, DB, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, Ty, nx, ny, nz);
-    conv_axis_kernel<0, false, NORM_NONE><<<grid, block, 0, st>>>(
-        DB, DA, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, Tx, nx, ny, nz);
-    conv_axis_kernel<0, false, NORM_DEN><<<grid, block, 0, st>>>(
-        B, dst, nullptr, nullptr, DA, nullptr, nullptr, nullptr, 0, Tx, nx, ny, nz);
+    VH_TRY(launch_march<true>(ctx, 2, src, A, mask, DA, Tz, nx, ny, nz));
+    VH_TRY(launch_march<false>(ctx, 1, A, B, nullptr, nullptr, Ty, nx, ny, nz));
+    VH_TRY(launch_march<false>(ctx, 1, DA, DB, nullptr, nullptr, Ty, nx, ny, nz));
+    VH_TRY(launch_row<NORM_NONE>(ctx, DB, DA, nullptr, nullptr, nullptr, nullptr, 0, Tx, nx, ny, nz));
+    VH_TRY(launch_row<NORM_DEN>(ctx, B, dst, DA, nullptr, nullptr, nullptr, 0, Tx, nx, ny, nz));
   }
   VH_HIP(hipGetLastError());
   return VISFD_HIP_OK;
