@@ -173,6 +173,37 @@ int visfd_hip_discard_overlapping_blobs(float* crds, float* diameters, float* sc
                                         float max_volume_overlap_large, float max_volume_overlap_small,
                                         int sort_criteria, int scale);
 
+/* ---- f1: LabelConnected, lib/visfd/connect.hpp:168-1427 (host-side: a sequential priority flood) ------
+ * Clusters the voxels whose saliency passes `threshold_saliency` into connected "islands", growing from the
+ * local saliency maxima (minima if start_from_saliency_maxima == 0) in order of decreasing saliency and merging
+ * islands that touch.  labels[nz][ny][nx] receives 1..n_clusters (1 = largest when sort_by_size != 0, otherwise
+ * ordered by the height of the seeding maximum) and `label_undefined` for unclustered voxels; voxels with
+ * mask == 0 receive the value n_seeds + 1 as in the reference (connect.hpp:1401-1403 skips them).
+ * direction (nullable, [nz][ny][nx][3]) and tensor (nullable, [nz][ny][nx][6] = xx,yy,zz,xy,yz,xz) switch on the
+ * compatibility tests of connect.hpp:455-553 and :625-672 with the four cosine thresholds (values below -1
+ * disable a test; with consider_dot_product_sign == 0 negative vector thresholds become 0).  When
+ * standardize_directions != 0 (and signs are ignored) `direction` is rewritten in place with consistent,
+ * outward-pointing signs (the reference's aaaafVectorStandardized aliasing its aaaafVector, as in
+ * handlers.cpp:1985-2013).  Per-cluster outputs (each nullable; cluster_capacity entries): seed position
+ * x,y,z in final cluster order; sizes and seed saliencies in the provisional (seed-height) order -- the
+ * reference only permutes the positions (connect.hpp:1294-1348).  Every dimension must be >= 3.
+ * Not provided: must-link constraints, voxel weights. */
+int visfd_hip_label_connected(const float* saliency, int64_t* labels, const float* mask, int64_t nx, int64_t ny,
+                              int64_t nz, float threshold_saliency, float* direction,
+                              float threshold_vector_saliency, float threshold_vector_neighbor,
+                              int consider_dot_product_sign, const float* tensor,
+                              float threshold_tensor_saliency, float threshold_tensor_neighbor,
+                              int tensor_is_positive_definite_near_target, int connectivity,
+                              int64_t label_undefined, int sort_by_size, int standardize_directions,
+                              int start_from_saliency_maxima, int64_t* n_clusters, float* cluster_maxima,
+                              float* cluster_sizes, float* cluster_saliencies, int64_t cluster_capacity);
+
+/* Principal eigenvector (eigenvector row 0 of ConvertFlatSym2Evects3 in the given order) of nvox flat tensors
+ * [nvox][6] -> direction [nvox][3], computed on the HOST in the reference's arithmetic (the loop of
+ * bin/filter_mrc/handlers.cpp:1935-1952); voxels with mask == 0 (mask nullable) are left untouched. */
+int visfd_hip_principal_directions_host(const float* tensor, const float* mask, int64_t nvox, int order,
+                                        float* direction);
+
 /* ---- f4: BinArray3D / UnbinArray3D, lib/visfd/resample.hpp:53-166 -------------------------------------
  * Sizes are {nx, ny, nz}.  bin[d] = floor(size_big[d] / size_small[d]); `offset` (nullable) shifts the
  * binning window and must satisfy 0 <= offset[d] < bin[d] (VISFD_HIP_EINVAL otherwise, where the

@@ -69,6 +69,11 @@ class CpuLib:
         if prefix == "vr_":   # blob list post-processing: checked against the reference directly
             _up = C.POINTER(C.c_uint64)
             sig.update({
+                "label_connected": (C.c_int64, [_fp, C.POINTER(C.c_int64), _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp,
+                                                C.c_float, C.c_float, C.c_int, _fp, C.c_float, C.c_float, C.c_int,
+                                                C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp,
+                                                C.c_int64]),
+                "trace_product_sym3": (C.c_float, [_fp, _fp]),
                 "sphere_overlap": (C.c_float, [C.c_float, C.c_float, C.c_float]),
                 "sort_blobs": (None, [_fp, _fp, _fp, C.c_int64, C.c_int, C.c_int, _up]),
                 "discard_masked_blobs": (C.c_int64, [_fp, _fp, _fp, C.c_int64, _fp, C.c_int, C.c_int, C.c_int]),
@@ -222,6 +227,30 @@ class CpuLib:
 
     def unbin_array3d(self, src, dst_shape, offset=None):
         return self._resample("unbin_array3d", src, dst_shape, offset)
+
+    # ---- voxel clustering (reference harness only): same signature and returns as visfd_amd.api.label_connected
+    def label_connected(self, saliency, threshold_saliency, mask=None, direction=None, tensor=None,
+                        threshold_vector_saliency=-np.inf, threshold_vector_neighbor=-np.inf,
+                        consider_dot_product_sign=True, threshold_tensor_saliency=-np.inf,
+                        threshold_tensor_neighbor=-np.inf, tensor_is_positive_definite_near_target=True, connectivity=1,
+                        label_undefined=-1, sort_by_size=True, standardize_directions=False,
+                        start_from_saliency_maxima=True):
+        nz, ny, nx = saliency.shape
+        labels = np.empty((nz, ny, nx), np.int64)
+        cap = int(saliency.size)
+        cm, cs, csal = np.zeros((cap, 3), np.float32), np.zeros(cap, np.float32), np.zeros(cap, np.float32)
+        k = self._fn["label_connected"](
+            _f(saliency), labels.ctypes.data_as(C.POINTER(C.c_int64)), _f(mask), nx, ny, nz, threshold_saliency,
+            _f(direction), threshold_vector_saliency, threshold_vector_neighbor, int(bool(consider_dot_product_sign)),
+            _f(tensor), threshold_tensor_saliency, threshold_tensor_neighbor,
+            int(bool(tensor_is_positive_definite_near_target)), int(connectivity), int(label_undefined),
+            int(bool(sort_by_size)), int(bool(standardize_directions)), int(bool(start_from_saliency_maxima)),
+            _f(cm), _f(cs), _f(csal), cap)
+        return labels, int(k), cm[:k], cs[:k], csal[:k]
+
+    def trace_product_sym3(self, a, b):
+        return float(self._fn["trace_product_sym3"](_f(np.ascontiguousarray(a, np.float32)),
+                                                    _f(np.ascontiguousarray(b, np.float32))))
 
     # ---- blob list post-processing (reference harness only) -------------------------------
     @staticmethod

@@ -354,6 +354,46 @@ int vr_unbin_array3d(const float* src, const int* ssz, float* dst, const int* ds
   return 0;
 }
 
-int vr_version() { return 3; }
+// ---- LabelConnected: connect.hpp:168-1427, called as bin/filter_mrc/handlers.cpp:1985-2013 does --------
+// (Label = ptrdiff_t, Coordinate = float, per-voxel pointers into the caller's AoS arrays; the
+// standardized-direction argument aliases the direction argument as in the handler.)
+int64_t vr_label_connected(const float* saliency, int64_t* labels, const float* mask, int nx, int ny, int nz,
+                           float thr_saliency, float* direction, float thr_vs, float thr_vn, int consider_sign,
+                           float* tensor, float thr_ts, float thr_tn, int tensor_posdef, int connectivity,
+                           int64_t label_undefined, int sort_by_size, int standardize, int from_maxima,
+                           float* cluster_maxima, float* cluster_sizes, float* cluster_saliencies, int64_t capacity) {
+  const int size[3] = {nx, ny, nz};
+  View3<const float> vs(saliency, nx, ny, nz), vm(mask, nx, ny, nz);
+  static_assert(sizeof(ptrdiff_t) == sizeof(int64_t), "labels are ptrdiff_t");
+  View3<ptrdiff_t> vl(reinterpret_cast<ptrdiff_t*>(labels), nx, ny, nz);
+  // per-voxel pointer tables float* [nz][ny][nx]
+  const size_t n = (size_t)nx * ny * nz;
+  std::vector<float*> pd(direction ? n : 0), pt(tensor ? n : 0);
+  for (size_t i = 0; i < pd.size(); i++) pd[i] = direction + 3 * i;
+  for (size_t i = 0; i < pt.size(); i++) pt[i] = tensor + 6 * i;
+  View3<float*> vd(direction ? pd.data() : nullptr, nx, ny, nz), vt(tensor ? pt.data() : nullptr, nx, ny, nz);
+  std::vector<std::array<float, 3> > centers;
+  std::vector<float> sizes, sals;
+  size_t nc = LabelConnected(size, (cf3)vs.p, vl.p, (cf3)vm.p, thr_saliency,
+                             (float* const* const* const*)vd.p, thr_vs, thr_vn, consider_sign != 0,
+                             (float* const* const* const*)vt.p, thr_ts, thr_tn, tensor_posdef != 0, connectivity,
+                             (ptrdiff_t)label_undefined, &centers, &sizes, &sals,
+                             sort_by_size ? RegionSortCriteria::SORT_BY_SIZE : RegionSortCriteria::SORT_BY_VALUE,
+                             static_cast<float***>(nullptr), standardize ? vd.p : static_cast<float****>(nullptr),
+                             static_cast<const std::vector<std::vector<std::array<float, 3> > >*>(nullptr),
+                             static_cast<const std::vector<std::vector<DirectionPairType> >*>(nullptr),
+                             from_maxima != 0, (std::ostream*)nullptr);
+  for (size_t k = 0; k < nc && (int64_t)k < capacity; k++) {
+    if (cluster_maxima) { cluster_maxima[3 * k] = centers[k][0]; cluster_maxima[3 * k + 1] = centers[k][1]; cluster_maxima[3 * k + 2] = centers[k][2]; }
+    if (cluster_sizes) cluster_sizes[k] = sizes[k];
+    if (cluster_saliencies) cluster_saliencies[k] = sals[k];
+  }
+  return (int64_t)nc;
+}
+
+// lin3_utils.hpp:502-529 as compiled (see visfd_amd/csrc/connect.cpp)
+float vr_trace_product_sym3(const float* a, const float* b) { return TraceProductSym3(a, b); }
+
+int vr_version() { return 4; }
 
 }  // extern "C"

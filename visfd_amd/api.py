@@ -98,6 +98,10 @@ _SIGS = {
     "visfd_hip_bin_array3d_dev": (C.c_int, [_vp, _vp, C.POINTER(_i64), _vp, C.POINTER(_i64), _ip]),
     "visfd_hip_unbin_array3d": (C.c_int, [_vp, _vp, C.POINTER(_i64), _vp, C.POINTER(_i64), _ip]),
     "visfd_hip_unbin_array3d_dev": (C.c_int, [_vp, _vp, C.POINTER(_i64), _vp, C.POINTER(_i64), _ip]),
+    "visfd_hip_label_connected": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, C.c_float, _vp, C.c_float, C.c_float, C.c_int,
+                                            _vp, C.c_float, C.c_float, C.c_int, C.c_int, _i64, C.c_int, C.c_int, C.c_int,
+                                            C.POINTER(_i64), _vp, _vp, _vp, _i64]),
+    "visfd_hip_principal_directions_host": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp]),
     "visfd_hip_sphere_overlap": (C.c_float, [C.c_float, C.c_float, C.c_float]),
     "visfd_hip_sort_blobs": (C.c_int, [_fp, _fp, _fp, _i64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
     "visfd_hip_discard_masked_blobs": (C.c_int, [_fp, _fp, _fp, C.POINTER(_i64), _vp, _i64, _i64, _i64]),
@@ -191,6 +195,43 @@ def sigmas_to_diameters(s):
     d = np.empty_like(s)
     load_library().visfd_hip_blob_sigmas_to_diameters(s.ctypes.data_as(_fp), len(s), d.ctypes.data_as(_fp))
     return d
+
+
+# ---- voxel clustering (host-side) ---------------------------------------------------------
+def label_connected(saliency, threshold_saliency, mask=None, direction=None, tensor=None,
+                    threshold_vector_saliency=-np.inf, threshold_vector_neighbor=-np.inf, consider_dot_product_sign=True,
+                    threshold_tensor_saliency=-np.inf, threshold_tensor_neighbor=-np.inf,
+                    tensor_is_positive_definite_near_target=True, connectivity=1, label_undefined=-1, sort_by_size=True,
+                    standardize_directions=False, start_from_saliency_maxima=True):
+    """LabelConnected (connect.hpp:168-1427).  saliency [nz,ny,nx]; direction [nz,ny,nx,3] (rewritten in place when
+    standardize_directions); tensor [nz,ny,nx,6].  Returns (labels int64 [nz,ny,nx], n_clusters, seed positions
+    [n,3] in final order, sizes [n] and seed saliencies [n] in provisional order)."""
+    L = load_library()
+    nz, ny, nx = saliency.shape
+    labels = np.empty((nz, ny, nx), np.int64)
+    n = _i64(0)
+    cap = int(saliency.size)
+    cm, cs, csal = np.zeros((cap, 3), np.float32), np.zeros(cap, np.float32), np.zeros(cap, np.float32)
+    for a in (direction, tensor):
+        assert a is None or (a.dtype == np.float32 and a.flags["C_CONTIGUOUS"])
+    _chk_host(L, L.visfd_hip_label_connected(
+        _np(saliency), labels.ctypes.data, _np(mask), nx, ny, nz, threshold_saliency,
+        None if direction is None else direction.ctypes.data, threshold_vector_saliency, threshold_vector_neighbor,
+        int(bool(consider_dot_product_sign)), None if tensor is None else tensor.ctypes.data, threshold_tensor_saliency,
+        threshold_tensor_neighbor, int(bool(tensor_is_positive_definite_near_target)), int(connectivity),
+        int(label_undefined), int(bool(sort_by_size)), int(bool(standardize_directions)),
+        int(bool(start_from_saliency_maxima)), C.byref(n), cm.ctypes.data, cs.ctypes.data, csal.ctypes.data, cap))
+    k = n.value
+    return labels, k, cm[:k], cs[:k], csal[:k]
+
+
+def principal_directions_host(tensor, order, mask=None):
+    """Eigenvector row 0 of every [.., 6] tensor, host arithmetic (handlers.cpp:1935-1952) -> [.., 3]."""
+    L = load_library()
+    out = np.zeros(tensor.shape[:-1] + (3,), np.float32)
+    _chk_host(L, L.visfd_hip_principal_directions_host(_np(tensor), _np(mask), int(tensor.size // 6), int(order),
+                                                       out.ctypes.data))
+    return out
 
 
 # ---- blob list post-processing (host-side; SURVEY.md 8 f3).  Blob lists are (crds[n,3], diameters[n], scores[n]).

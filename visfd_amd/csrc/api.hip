@@ -251,7 +251,7 @@ int visfd_hip_trim(visfd_hip_ctx* ctx) {
 int visfd_hip_destroy(visfd_hip_ctx* ctx) {
   if (!ctx) return VISFD_HIP_OK;
   int rc = visfd_hip_trim(ctx);
-  if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return rc;
 }

@@ -1,0 +1,395 @@
+// connect.cpp -- LabelConnected (reference lib/visfd/connect.hpp:168-1427 with
+// lib/visfd/morphology_implementation.hpp:57-515 for the seeds): agglomerative clustering of bright,
+// mutually compatible voxels into "islands", the consumer of the tensor-voting output
+// (bin/filter_mrc/handlers.cpp:1925-2035).
+//
+// This is a sequential priority-flood (Meyer) in the reference and stays on the host here: every
+// step depends on the labels written by the steps before it.  What is reproduced exactly, because the
+// labels depend on it:
+//   * seeds: local maxima (or minima) of the saliency including plateaus, found in scan order,
+//     kept if they pass the threshold, ranked by (score, scan rank) -- descending = the exact reverse
+//     of the ascending ranking;
+//   * flood order: a max-heap of (key, basin, (x,y,z)) tuples compared lexicographically, key =
+//     saliency for maxima (-saliency for minima): a strict total order, so any heap pops alike;
+//   * per-voxel admission tests in float: the finite-difference Hessian of the SALIENCY (clamped one
+//     voxel inwards at the faces) against the vote tensor and against the direction, and the
+//     neighbour-to-neighbour tests, with the reference's operand order;
+//   * merges: the cluster with the smaller id absorbs the other; polarity bookkeeping for
+//     sign-less directions; final ids by size (descending, ties to the larger provisional id).
+// One quirk is load-bearing: the reference's TraceProductSym3 (lin3_utils.hpp:502-529) indexes the
+// 6x2 "linear -> (i,j)" table as if it were the 3x3 "(i,j) -> linear" table, so the value it returns
+// is  a0*b0 + a0*b1 + a1*b2 + a1*b0 + a1*b1 + a2*b2 + a2*b1 + a2*b2 + a0*b0  (only the diagonal
+// entries enter).  That effective formula -- pinned against the compiled reference by
+// tests/test_connect.py -- is what is evaluated here, since the thresholds act on it.
+// Not provided: must-link constraints and voxel weights (off the CLI's default path).
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <queue>
+#include <thread>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+#include "common.hpp"
+#include "eigen3.hpp"
+
+namespace {
+
+using vh::i64;
+
+struct Grid {
+  int nx, ny, nz;
+  i64 at(int x, int y, int z) const { return ((i64)z * ny + y) * nx + x; }
+};
+
+std::vector<std::array<int, 3> > neighbour_offsets(int connectivity) {   // connect.hpp:219-250
+  const int r = (int)std::floor(std::sqrt((double)connectivity));
+  std::vector<std::array<int, 3> > v;
+  for (int jz = -r; jz <= r; jz++)
+    for (int jy = -r; jy <= r; jy++)
+      for (int jx = -r; jx <= r; jx++) {
+        if (jx == 0 && jy == 0 && jz == 0) continue;
+        if (jx * jx + jy * jy + jz * jz > connectivity) continue;
+        v.push_back({{jx, jy, jz}});
+      }
+  return v;
+}
+
+// Seeds (morphology_implementation.hpp:57-515, one kind of extremum, allow_borders = true).
+void find_extrema(const Grid& g, const float* S, const float* M, bool seek_minima, float threshold,
+                  const std::vector<std::array<int, 3> >& nb, std::vector<i64>* index, std::vector<float>* score) {
+  if (!seek_minima && threshold == std::numeric_limits<float>::infinity())   // :774-775
+    threshold = -std::numeric_limits<float>::infinity();
+  const i64 n = (i64)g.nx * g.ny * g.nz;
+  std::vector<unsigned char> state((size_t)n, 0);   // 0 undefined, 1 queued, 2 done
+  std::vector<i64> cand;
+  std::vector<float> cscore;
+  std::vector<std::array<int, 3> > plateau;
+  for (int z0 = 0; z0 < g.nz; z0++)
+    for (int y0 = 0; y0 < g.ny; y0++)
+      for (int x0 = 0; x0 < g.nx; x0++) {
+        const i64 c0 = g.at(x0, y0, z0);
+        if (M && M[c0] == 0.0f) continue;
+        if (state[c0] != 0) continue;
+        bool is_min = true, is_max = true;
+        plateau.clear();
+        plateau.push_back({{x0, y0, z0}});
+        state[c0] = 1;
+        for (size_t head = 0; head < plateau.size(); head++) {   // breadth-first over the equal-valued region
+          const int x = plateau[head][0], y = plateau[head][1], z = plateau[head][2];
+          const float v = S[g.at(x, y, z)];
+          for (size_t j = 0; j < nb.size(); j++) {
+            const int xx = x + nb[j][0], yy = y + nb[j][1], zz = z + nb[j][2];
+            if (zz < 0 || zz >= g.nz || yy < 0 || yy >= g.ny || xx < 0 || xx >= g.nx) continue;
+            const i64 cj = g.at(xx, yy, zz);
+            if (M && M[cj] == 0.0f) continue;
+            const float vj = S[cj];
+            if (vj == v) {
+              if (state[cj] == 0) { plateau.push_back({{xx, yy, zz}}); state[cj] = 1; }
+            } else if (vj < v) is_min = false;
+            else if (vj > v) is_max = false;
+          }
+        }
+        for (size_t k = 0; k < plateau.size(); k++) state[g.at(plateau[k][0], plateau[k][1], plateau[k][2])] = 2;
+        const float v0 = S[c0];
+        if (seek_minima ? (is_min && v0 <= threshold) : (is_max && v0 >= threshold)) {
+          cand.push_back(c0);
+          cscore.push_back(v0);
+        }
+      }
+  // ranking: minima ascending, maxima descending = the reverse of ascending (score, rank) (:404-470)
+  std::vector<std::pair<float, i64> > key(cand.size());
+  for (size_t i = 0; i < cand.size(); i++) key[i] = std::make_pair(cscore[i], (i64)i);
+  std::sort(key.begin(), key.end());
+  if (!seek_minima) std::reverse(key.begin(), key.end());
+  index->resize(cand.size());
+  score->resize(cand.size());
+  for (size_t i = 0; i < cand.size(); i++) {
+    (*index)[i] = cand[(size_t)key[i].second];
+    (*score)[i] = cscore[(size_t)key[i].second];
+  }
+}
+
+// lib/visfd/visfd_utils.hpp:528-616: finite-difference Hessian, stencil centre moved one voxel inwards at a face
+void hessian_fd(const Grid& g, const float* S, int ix, int iy, int iz, float H[3][3]) {
+  if (ix == 0) ix++; else if (ix == g.nx - 1) ix--;
+  if (iy == 0) iy++; else if (iy == g.ny - 1) iy--;
+  if (iz == 0) iz++; else if (iz == g.nz - 1) iz--;
+  auto s = [&](int dx, int dy, int dz) { return S[g.at(ix + dx, iy + dy, iz + dz)]; };
+  H[0][0] = (s(1, 0, 0) + s(-1, 0, 0) - 2 * s(0, 0, 0));
+  H[1][1] = (s(0, 1, 0) + s(0, -1, 0) - 2 * s(0, 0, 0));
+  H[2][2] = (s(0, 0, 1) + s(0, 0, -1) - 2 * s(0, 0, 0));
+  H[0][1] = (float)(0.25 * (s(1, 1, 0) + s(-1, -1, 0) - s(1, -1, 0) - s(-1, 1, 0)));
+  H[1][0] = H[0][1];
+  H[1][2] = (float)(0.25 * (s(0, 1, 1) + s(0, -1, -1) - s(0, 1, -1) - s(0, -1, 1)));
+  H[2][1] = H[1][2];
+  H[2][0] = (float)(0.25 * (s(1, 0, 1) + s(-1, 0, -1) - s(-1, 0, 1) - s(1, 0, -1)));
+  H[0][2] = H[2][0];
+}
+
+// the value the reference's TraceProductSym3 actually returns (see the header comment)
+inline float trace_product_sym3(const float a[6], const float b[6]) {
+  return a[0] * b[0] + a[0] * b[1] + a[1] * b[2] + a[1] * b[0] + a[1] * b[1] + a[2] * b[2] + a[2] * b[1] +
+         a[2] * b[2] + a[0] * b[0];
+}
+inline float frobenius_sym3(const float a[6]) { return std::sqrt(trace_product_sym3(a, a)); }
+inline float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+inline float sqr(float x) { return x * x; }
+
+}  // namespace
+
+extern "C" int visfd_hip_label_connected(const float* saliency, int64_t* labels, const float* mask, int64_t nx64,
+                                         int64_t ny64, int64_t nz64, float threshold_saliency, float* direction,
+                                         float threshold_vector_saliency, float threshold_vector_neighbor,
+                                         int consider_dot_product_sign, const float* tensor,
+                                         float threshold_tensor_saliency, float threshold_tensor_neighbor,
+                                         int tensor_is_positive_definite_near_target, int connectivity,
+                                         int64_t label_undefined, int sort_by_size, int standardize_directions,
+                                         int start_from_saliency_maxima, int64_t* n_clusters_out,
+                                         float* cluster_maxima, float* cluster_sizes, float* cluster_saliencies,
+                                         int64_t cluster_capacity) {
+  if (!saliency || !labels) return vh::fail(VISFD_HIP_EINVAL, "label_connected: null image");
+  VH_TRY(vh::check_dims(nx64, ny64, nz64));
+  if (nx64 < 3 || ny64 < 3 || nz64 < 3)   // visfd_utils.hpp:585-587 (asserted there)
+    return vh::fail(VISFD_HIP_EINVAL, "label_connected: the image must be at least 3 voxels wide in every direction");
+  if (nx64 * ny64 * nz64 >= (1LL << 31)) return vh::fail(VISFD_HIP_EINVAL, "label_connected: image too large");
+  if (connectivity < 1) return vh::fail(VISFD_HIP_EINVAL, "label_connected: connectivity must be >= 1");
+  const Grid g = {(int)nx64, (int)ny64, (int)nz64};
+  const i64 n = (i64)g.nx * g.ny * g.nz;
+  const float* S = saliency;
+  const float* M = mask;
+  float* V = direction;
+  const float* T = tensor;
+  const bool from_max = start_from_saliency_maxima != 0;
+  const bool signs = consider_dot_product_sign != 0;
+  const bool standardize = V && standardize_directions && !signs;
+  const int order = from_max ? VISFD_HIP_DECREASING_EIVALS : VISFD_HIP_INCREASING_EIVALS;   // connect.hpp:197-201
+  if (!signs) {   // connect.hpp:207-216: a negative threshold means "do not compare"
+    if (threshold_vector_saliency < 0) threshold_vector_saliency = 0.0f;
+    if (threshold_vector_neighbor < 0) threshold_vector_neighbor = 0.0f;
+  }
+  const std::vector<std::array<int, 3> > nb = neighbour_offsets(connectivity);
+  const float SIGN = from_max ? -1.0f : 1.0f;
+
+  std::vector<i64> seed;
+  std::vector<float> seed_score;
+  find_extrema(g, S, M, !from_max, threshold_saliency, nb, &seed, &seed_score);
+  const i64 nseeds = (i64)seed.size();
+  const i64 UNDEFINED = nseeds + 1, QUEUED = nseeds + 2;
+  for (i64 i = 0; i < n; i++) labels[i] = UNDEFINED;
+
+  typedef std::tuple<float, i64, float, float, float> Entry;   // key, basin, x, y, z (coordinates compare as floats)
+  std::priority_queue<Entry> q;
+  for (i64 i = 0; i < nseeds; i++) {
+    const i64 c = seed[(size_t)i];
+    const int x = (int)(c % g.nx), y = (int)((c / g.nx) % g.ny), z = (int)(c / ((i64)g.nx * g.ny));
+    const float sc = seed_score[(size_t)i] * SIGN;
+    q.push(Entry(-sc, i, (float)x, (float)y, (float)z));
+    labels[c] = QUEUED;
+  }
+  std::vector<i64> basin2cluster((size_t)nseeds);
+  std::vector<std::vector<i64> > cluster2basins((size_t)nseeds);
+  for (i64 i = 0; i < nseeds; i++) { basin2cluster[(size_t)i] = i; cluster2basins[(size_t)i].assign(1, i); }
+  std::vector<signed char> polarity((size_t)nseeds, 1);
+
+  while (!q.empty()) {
+    const Entry p = q.top();
+    q.pop();
+    const float i_score = -std::get<0>(p);
+    const i64 basin = std::get<1>(p);
+    const int ix = (int)std::get<2>(p), iy = (int)std::get<3>(p), iz = (int)std::get<4>(p);
+    const i64 c = g.at(ix, iy, iz);
+    if (i_score > threshold_saliency * SIGN) { labels[c] = UNDEFINED; continue; }
+    if (M && M[c] == 0.0f) { labels[c] = UNDEFINED; continue; }
+    {   // is the saliency's own shape here compatible with the tensor / direction? (connect.hpp:455-553)
+      float H3[3][3];
+      hessian_fd(g, S, ix, iy, iz, H3);
+      if ((tensor_is_positive_definite_near_target != 0) == from_max)
+        for (int a = 0; a < 3; a++)
+          for (int b = a; b < 3; b++) H3[a][b] *= -1.0f;
+      const float H[6] = {H3[0][0], H3[1][1], H3[2][2], H3[0][1], H3[1][2], H3[0][2]};   // lin3_utils.hpp:400-403
+      bool discard = false;
+      if (T) {
+        const float tp = trace_product_sym3(H, T + 6 * c);
+        const float fs = frobenius_sym3(H), ft = frobenius_sym3(T + 6 * c);
+        if (tp < threshold_tensor_saliency * fs * ft) discard = true;
+      }
+      if (V) {
+        float d6[6], e0[3];
+        vh::eig::diagonalize_flat(H, order, d6);      // ConvertFlatSym2Evects3: principal eigenvector = row 0
+        vh::eig::shoemake_row0(d6 + 3, e0);
+        const float* v = V + 3 * c;
+        bool exceeded = false;
+        if (signs) {
+          if (dot3(e0, v) < (threshold_vector_saliency * std::sqrt(dot3(e0, e0)) * std::sqrt(dot3(v, v)))) exceeded = true;
+        } else {
+          if (sqr(dot3(e0, v)) < (sqr(threshold_vector_saliency) * dot3(e0, e0) * dot3(v, v))) exceeded = true;
+        }
+        if (exceeded) discard = true;
+      }
+      if (discard) {
+        labels[c] = UNDEFINED;
+        if (c == seed[(size_t)basin]) basin2cluster[(size_t)basin] = -1;   // the whole basin is dropped
+        continue;
+      }
+    }
+    labels[c] = basin;
+    for (size_t j = 0; j < nb.size(); j++) {
+      const int xx = ix + nb[j][0], yy = iy + nb[j][1], zz = iz + nb[j][2];
+      if (zz < 0 || zz >= g.nz || yy < 0 || yy >= g.ny || xx < 0 || xx >= g.nx) continue;
+      const i64 cj = g.at(xx, yy, zz);
+      if (M && M[cj] == 0.0f) continue;
+      if (T) {   // neighbour compatibility (connect.hpp:625-672; both tests sit under "if tensor" there)
+        const float* ti = T + 6 * c;
+        const float* tj = T + 6 * cj;
+        if (trace_product_sym3(ti, tj) < (threshold_tensor_neighbor * frobenius_sym3(ti) * frobenius_sym3(tj))) continue;
+        if (V) {
+          const float* vi = V + 3 * c;
+          const float* vj = V + 3 * cj;
+          if (signs) {
+            if (dot3(vi, vj) < (threshold_tensor_neighbor * std::sqrt(dot3(vi, vi)) * std::sqrt(dot3(vj, vj)))) continue;
+          } else {
+            if (sqr(dot3(vi, vj)) < (sqr(threshold_vector_neighbor) * dot3(vi, vi) * dot3(vj, vj))) continue;
+          }
+        }
+      }
+      if (labels[cj] == QUEUED) continue;
+      if (labels[cj] == UNDEFINED) {
+        labels[cj] = QUEUED;
+        const float ns = S[cj] * SIGN;
+        q.push(Entry(-ns, basin, (float)xx, (float)yy, (float)zz));
+        if (standardize && dot3(V + 3 * c, V + 3 * cj) < 0.0f) {   // newcomers follow the voxel that reached them
+          V[3 * cj] *= -1.0f; V[3 * cj + 1] *= -1.0f; V[3 * cj + 2] *= -1.0f;
+        }
+        continue;
+      }
+      // the neighbour already belongs to a basin: same cluster, or merge
+      const i64 basin_i = basin, basin_j = labels[cj];
+      const i64 ci = basin2cluster[(size_t)basin_i], cjl = basin2cluster[(size_t)basin_j];
+      bool polarity_match = true;
+      if (standardize && (float)(dot3(V + 3 * c, V + 3 * cj) * polarity[(size_t)basin_i] * polarity[(size_t)basin_j]) < 0.0f)
+        polarity_match = false;
+      if (ci == cjl) continue;   // (a polarity mismatch inside one cluster only skips this neighbour)
+      const i64 keep = std::min(ci, cjl), gone = std::max(ci, cjl);
+      if (keep < 0) {   // a basin whose seed was discarded carries cluster -1 (connect.hpp:549); the reference indexes
+        continue;       // cluster2basins[-1] there (undefined behaviour) -- such contacts are ignored here
+      }
+      for (size_t k = 0; k < cluster2basins[(size_t)gone].size(); k++) {
+        const i64 b = cluster2basins[(size_t)gone][k];
+        cluster2basins[(size_t)keep].push_back(b);
+        basin2cluster[(size_t)b] = keep;
+        if (standardize && !polarity_match) polarity[(size_t)b] = (signed char)-polarity[(size_t)b];
+      }
+      cluster2basins[(size_t)gone].clear();
+    }
+  }
+
+  // provisional cluster numbers 0..n_clusters-1 in basin order (connect.hpp:1049-1075)
+  std::vector<i64> old2new((size_t)nseeds), deepest;
+  i64 n_clusters = 0;
+  for (i64 i = 0; i < nseeds; i++) {
+    old2new[(size_t)i] = n_clusters;
+    if (basin2cluster[(size_t)i] == i) { deepest.push_back(i); n_clusters++; }
+  }
+  for (i64 i = 0; i < nseeds; i++)
+    if (basin2cluster[(size_t)i] >= 0) basin2cluster[(size_t)i] = old2new[(size_t)basin2cluster[(size_t)i]];
+  auto live = [&](i64 c) { return !(M && M[c] == 0.0f) && labels[c] != UNDEFINED; };
+  if (standardize)
+    for (i64 c = 0; c < n; c++)
+      if (live(c)) {
+        const float pol = (float)polarity[(size_t)labels[c]];
+        V[3 * c] *= pol; V[3 * c + 1] *= pol; V[3 * c + 2] *= pol;
+      }
+  for (i64 c = 0; c < n; c++)
+    if (live(c)) labels[c] = basin2cluster[(size_t)labels[c]];
+  std::vector<long double> sizes((size_t)n_clusters, 0.0L);
+  for (i64 c = 0; c < n; c++)
+    if (live(c)) sizes[(size_t)labels[c]] += 1.0L;
+  if (standardize) {   // outward orientation by the sign of sum (r - r_com).n (connect.hpp:1192-1290)
+    std::vector<std::array<long double, 3> > com((size_t)n_clusters, std::array<long double, 3>{{0.0L, 0.0L, 0.0L}});
+    for (int z = 0; z < g.nz; z++)
+      for (int y = 0; y < g.ny; y++)
+        for (int x = 0; x < g.nx; x++) {
+          const i64 c = g.at(x, y, z);
+          if (!live(c)) continue;
+          com[(size_t)labels[c]][0] += x; com[(size_t)labels[c]][1] += y; com[(size_t)labels[c]][2] += z;
+        }
+    for (i64 k = 0; k < n_clusters; k++)
+      for (int d = 0; d < 3; d++) com[(size_t)k][d] /= sizes[(size_t)k];
+    std::vector<long double> sum_dot((size_t)n_clusters, 0.0L);
+    for (int z = 0; z < g.nz; z++)
+      for (int y = 0; y < g.ny; y++)
+        for (int x = 0; x < g.nx; x++) {
+          const i64 c = g.at(x, y, z);
+          if (!live(c)) continue;
+          const i64 k = labels[c];
+          const float r[3] = {(float)(x - com[(size_t)k][0]), (float)(y - com[(size_t)k][1]), (float)(z - com[(size_t)k][2])};
+          sum_dot[(size_t)k] += (long double)dot3(r, V + 3 * c);
+        }
+    for (i64 c = 0; c < n; c++)
+      if (live(c) && sum_dot[(size_t)labels[c]] < 0.0L) { V[3 * c] *= -1.0f; V[3 * c + 1] *= -1.0f; V[3 * c + 2] *= -1.0f; }
+  }
+  // per-cluster outputs in provisional order, then the final order
+  std::vector<i64> perm((size_t)n_clusters);
+  for (i64 k = 0; k < n_clusters; k++) perm[(size_t)k] = k;
+  if (sort_by_size && n_clusters > 0) {   // connect.hpp:1322-1365: (float size, id) descending = reverse of ascending
+    std::vector<std::pair<float, i64> > key((size_t)n_clusters);
+    for (i64 k = 0; k < n_clusters; k++) key[(size_t)k] = std::make_pair((float)sizes[(size_t)k], k);
+    std::sort(key.begin(), key.end());
+    std::reverse(key.begin(), key.end());
+    std::vector<i64> inv((size_t)n_clusters);
+    for (i64 k = 0; k < n_clusters; k++) { perm[(size_t)k] = key[(size_t)k].second; inv[(size_t)key[(size_t)k].second] = k; }
+    for (i64 c = 0; c < n; c++)
+      if (live(c)) labels[c] = inv[(size_t)labels[c]];
+  }
+  for (i64 c = 0; c < n; c++) {
+    if (M && M[c] == 0.0f) continue;             // masked voxels keep the provisional "undefined" code (connect.hpp:1401-1403)
+    if (labels[c] == UNDEFINED) labels[c] = label_undefined;
+    else labels[c] += 1;
+  }
+  if (n_clusters_out) *n_clusters_out = n_clusters;
+  if (cluster_maxima || cluster_sizes || cluster_saliencies) {
+    if (cluster_capacity < n_clusters) return vh::fail(VISFD_HIP_ECAPACITY, "label_connected: cluster arrays too small");
+    for (i64 k = 0; k < n_clusters; k++) {
+      // quirk kept: only the seed list follows the size ordering; sizes and saliencies stay in provisional
+      // order (connect.hpp:1294-1315 fill all three before the sort, :1347-1348 permutes the maxima only)
+      const i64 cm = seed[(size_t)deepest[(size_t)perm[(size_t)k]]];
+      if (cluster_maxima) {
+        cluster_maxima[3 * k] = (float)(cm % g.nx);
+        cluster_maxima[3 * k + 1] = (float)((cm / g.nx) % g.ny);
+        cluster_maxima[3 * k + 2] = (float)(cm / ((i64)g.nx * g.ny));
+      }
+      if (cluster_sizes) cluster_sizes[k] = (float)sizes[(size_t)k];
+      if (cluster_saliencies) cluster_saliencies[k] = S[seed[(size_t)deepest[(size_t)k]]];
+    }
+  }
+  return VISFD_HIP_OK;
+}
+
+// Principal eigenvector (row 0 of ConvertFlatSym2Evects3) of every voxel's tensor, on the HOST with glibc
+// arithmetic -- bit-identical to the reference's loop at bin/filter_mrc/handlers.cpp:1935-1952, which matters
+// because LabelConnected thresholds act on these directions.  Voxels with mask == 0 are left untouched.
+// The voxels are independent, so the loop is split over the host's cores.
+extern "C" int visfd_hip_principal_directions_host(const float* tensor, const float* mask, int64_t nvox, int order,
+                                                   float* direction) {
+  if (!tensor || !direction || nvox < 0) return vh::fail(VISFD_HIP_EINVAL, "principal_directions_host: bad argument");
+  unsigned nt = std::thread::hardware_concurrency();
+  if (nt < 1) nt = 1;
+  if ((int64_t)nt > nvox / 4096 + 1) nt = (unsigned)(nvox / 4096 + 1);
+  auto work = [&](int64_t lo, int64_t hi) {
+    for (int64_t i = lo; i < hi; i++) {
+      if (mask && mask[i] == 0.0f) continue;
+      float d6[6];
+      vh::eig::diagonalize_flat(tensor + 6 * i, order, d6);
+      vh::eig::shoemake_row0(d6 + 3, direction + 3 * i);
+    }
+  };
+  std::vector<std::thread> pool;
+  const int64_t chunk = (nvox + nt - 1) / nt;
+  for (unsigned t = 1; t < nt; t++) pool.emplace_back(work, std::min<int64_t>(nvox, t * chunk), std::min<int64_t>(nvox, (t + 1) * chunk));
+  work(0, std::min<int64_t>(nvox, chunk));
+  for (size_t t = 0; t < pool.size(); t++) pool[t].join();
+  return VISFD_HIP_OK;
+}

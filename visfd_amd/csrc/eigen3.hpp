@@ -1,5 +1,5 @@
-// eigen3.hpp -- device-side 3x3 symmetric eigen-decomposition and the Shoemake frame packing used
-// by the ridge detector and the tensor-voting score.
+// eigen3.hpp -- 3x3 symmetric eigen-decomposition and the Shoemake frame packing used by the ridge
+// detector and the tensor-voting score (device), and by the host-side voxel clustering (connect.cpp).
 //
 // Behavioural contract (reference lib/visfd/eigen3_simple.hpp:47-342 and
 // lib/visfd/lin3_utils.hpp:230-394).  Written from the mathematics:
@@ -10,28 +10,33 @@
 //     one by cross product;
 //   * requested order (increasing / decreasing) only swaps entries 0 and 2;
 //   * frame -> quaternion -> Shoemake triple stored as float; unpacking in float.
-// The device libm differs from glibc in the last ulp of atan2/sin/cos, so results agree with the
-// CPU path to ~1e-7 relative rather than bit-for-bit (tests use the 1e-5 relative bound of
-// BASELINE.json).
+// The device libm differs from glibc in the last ulp of atan2/sin/cos, so device results agree with
+// the CPU path to ~1e-7 relative rather than bit-for-bit (tests use the 1e-5 relative bound of
+// BASELINE.json).  Compiled for the host the same functions use glibc and are bit-identical to the
+// reference's CPU results.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#define VH_HD __host__ __device__ __forceinline__
 
 namespace vh {
 namespace eig {
 
 struct D3 { double x, y, z; };
 
-__device__ __forceinline__ D3 cross3(const D3& a, const D3& b) {
+VH_HD D3 cross3(const D3& a, const D3& b) {
   D3 c;
   c.z = a.x * b.y - a.y * b.x;
   c.x = a.y * b.z - a.z * b.y;
   c.y = a.z * b.x - a.x * b.z;
   return c;
 }
-__device__ __forceinline__ double dot3(const D3& a, const D3& b) {
+VH_HD double dot3(const D3& a, const D3& b) {
   return a.x * b.x + a.y * b.y + a.z * b.z;
 }
-__device__ __forceinline__ void unit_or_x(D3& a) {
+VH_HD void unit_or_x(D3& a) {
   const double L = sqrt(dot3(a, a));
   if (L > 0.0) {
     const double inv = 1.0 / L;
@@ -48,7 +53,7 @@ struct Sym3 {
 
 // Null vector of the (numerically rank-2) matrix S - lam*I; rep = its column with the largest
 // |diagonal| entry.
-__device__ __forceinline__ D3 null_vector(const Sym3& S, double lam, D3& rep) {
+VH_HD D3 null_vector(const Sym3& S, double lam, D3& rep) {
   const double d0 = S.m00 - lam, d1 = S.m11 - lam, d2 = S.m22 - lam;
   const D3 c0 = {d0, S.m01, S.m02};
   const D3 c1 = {S.m01, d1, S.m12};
@@ -76,7 +81,7 @@ __device__ __forceinline__ D3 null_vector(const Sym3& S, double lam, D3& rep) {
 }
 
 // m6 = (xx,yy,zz,xy,yz,xz).  lam[3] and rows E[3]; order 0 = increasing, 1 = decreasing.
-__device__ __forceinline__ void eig_sym3(const float m6[6], int order, double lam[3], D3 E[3],
+VH_HD void eig_sym3(const float m6[6], int order, double lam[3], D3 E[3],
                                          bool want_vectors) {
   const double eps = 2.220446049250313e-16;
   const double a00 = m6[0], a11 = m6[1], a22 = m6[2], a01 = m6[3], a12 = m6[4], a02 = m6[5];
@@ -106,7 +111,11 @@ __device__ __forceinline__ void eig_sym3(const float m6[6], int order, double la
     const double rho = sqrt(a_3);
     const double theta = atan2(sqrt(q), half_b) * inv3;
     double st, ct;
+#if defined(__HIP_DEVICE_COMPILE__)
     sincos(theta, &st, &ct);
+#else
+    ct = std::cos(theta); st = std::sin(theta);
+#endif
     lam[0] = c2_3 - rho * (ct + sqrt3 * st);
     lam[1] = c2_3 - rho * (ct - sqrt3 * st);
     lam[2] = c2_3 + 2.0 * rho * ct;
@@ -152,7 +161,7 @@ __device__ __forceinline__ void eig_sym3(const float m6[6], int order, double la
 }
 
 // rows of a rotation -> quaternion (w,x,y,z) -> Shoemake triple (double in, float out)
-__device__ __forceinline__ void frame_to_shoemake(const D3 M[3], float sm[3]) {
+VH_HD void frame_to_shoemake(const D3 M[3], float sm[3]) {
   const double m00 = M[0].x, m01 = M[0].y, m02 = M[0].z;
   const double m10 = M[1].x, m11 = M[1].y, m12 = M[1].z;
   const double m20 = M[2].x, m21 = M[2].y, m22 = M[2].z;
@@ -183,7 +192,7 @@ __device__ __forceinline__ void frame_to_shoemake(const D3 M[3], float sm[3]) {
 }
 
 // flat symmetric matrix -> [lam0, lam1, lam2, shoemake0..2] (eigen3_simple.hpp:271-342)
-__device__ __forceinline__ void diagonalize_flat(const float m6[6], int order, float out6[6]) {
+VH_HD void diagonalize_flat(const float m6[6], int order, float out6[6]) {
   double lam[3];
   D3 E[3];
   eig_sym3(m6, order, lam, E, true);
@@ -197,15 +206,20 @@ __device__ __forceinline__ void diagonalize_flat(const float m6[6], int order, f
 
 // First row of the frame recovered from the float Shoemake triple (lin3_utils.hpp:310-337 and
 // :279-305, float arithmetic): the principal direction handed to tensor voting.
-__device__ __forceinline__ void shoemake_row0(const float sm[3], float row0[3]) {
+VH_HD void shoemake_row0(const float sm[3], float row0[3]) {
   const float two_pi = 6.283185307179586f;
   const float X0 = sm[0];
   const float th1 = two_pi * sm[1], th2 = two_pi * sm[2];
   const float r1 = (float)sqrt(1.0 - (double)X0);
   const float r2 = sqrtf(X0);
   float s1, c1, s2, c2;
+#if defined(__HIP_DEVICE_COMPILE__)
   sincosf(th1, &s1, &c1);
   sincosf(th2, &s2, &c2);
+#else
+  s1 = std::sin(th1); c1 = std::cos(th1);
+  s2 = std::sin(th2); c2 = std::cos(th2);
+#endif
   const float q0 = s1 * r1, q1 = c1 * r1, q2 = s2 * r2, q3 = c2 * r2;
   row0[0] = (float)(1.0 - (double)(2 * (q2 * q2)) - (double)(2 * (q3 * q3)));
   row0[1] = 2 * (q1 * q2 - q3 * q0);

@@ -474,7 +474,9 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
     const bool last_of_group = (band == 0) && (((pl + 1) % p.group == 0) || (pl + 1 == nplanes));
     if (last_of_group) {
       __syncthreads();
+#ifdef VH_TV_STATS
       const bool had = n_list > 0;
+#endif
       if (n_list > 0) flush(n_list, ez_first);
       n_list = 0;
       __syncthreads();     // list and slices free for the next group
