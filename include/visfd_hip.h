@@ -203,6 +203,11 @@ int visfd_hip_label_connected(const float* saliency, int64_t* labels, const floa
  * bin/filter_mrc/handlers.cpp:1935-1952); voxels with mask == 0 (mask nullable) are left untouched. */
 int visfd_hip_principal_directions_host(const float* tensor, const float* mask, int64_t nvox, int order,
                                         float* direction);
+/* Post-vote score lambda0 - lambda1 (bin/filter_mrc/handlers.cpp:1868-1888) of nvox flat tensors on the HOST in
+ * the reference's arithmetic (the device kernel visfd_hip_tensor_saliency agrees to ~1e-7 relative only);
+ * used before visfd_hip_label_connected, whose flood order and thresholds act on this number. */
+int visfd_hip_tensor_saliency_host(const float* tensor, const float* mask, int64_t nvox, int order,
+                                   float* saliency);
 
 /* ---- f4: BinArray3D / UnbinArray3D, lib/visfd/resample.hpp:53-166 -------------------------------------
  * Sizes are {nx, ny, nz}.  bin[d] = floor(size_big[d] / size_small[d]); `offset` (nullable) shifts the

@@ -168,3 +168,28 @@ def test_cli_automatic_binning_for_wide_membranes(cli, tmp_path):
         np.minimum(np.arange(56) // n, small.shape[2] - 1)
     assert_bits_equal(auto, small[np.ix_(iz, iy, ix)], "automatic binning == explicit binning, un-binned")
     assert np.abs(small).max() > 0
+
+
+@pytest.mark.gpu
+def test_cli_membrane_clustering_reference_scenario(cli, tmp_path):
+    """tests/test_membrane_detection.sh of the reference, both commands: detect + vote with -bin 2 and
+    -save-progress, then -load-progress ... -connect 1e+09 -connect-angle 30.  Known answers of the reference
+    (SURVEY.md §4): six 8x8x8 tensor files, "Number of clusters found: 1", 69 voxels with label 1."""
+    inp = os.path.join(GOLDEN, "test_image_membrane.rec")
+    out, base = tmp_path / "surf.rec", tmp_path / "test_image_membrane"
+    common = ["-w", 19.2, "-in", inp, "-out", out, "-membrane", "minima", 55, "-tv", 4, "-tv-angle-exponent", 4, "-bin", 2]
+    r = run(cli, *common, "-save-progress", base)
+    assert r.returncode == 0, r.stderr
+    for c in range(6):
+        assert volgen.read_mrc("%s_tensor_%d.rec" % (base, c)).shape == (8, 8, 8)
+    r = run(cli, *common, "-load-progress", base, "-connect", 1e9, "-connect-angle", 30, "-select-cluster", 1)
+    assert r.returncode == 0, r.stderr
+    assert "Number of clusters found: 1" in r.stderr
+    lab = volgen.read_mrc(str(out))
+    assert lab.shape == (8, 8, 8)
+    assert int(((lab > 0.99) & (lab < 1.01)).sum()) == 69
+    # clustering in the same run as the voting gives the same labels
+    out2 = tmp_path / "surf2.rec"
+    r = run(cli, *common[:4], "-out", out2, *common[6:], "-connect", 1e9, "-connect-angle", 30)
+    assert r.returncode == 0, r.stderr
+    assert_bits_equal(volgen.read_mrc(str(out2)), lab, "clustering after -load-progress == clustering in one run")

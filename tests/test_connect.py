@@ -108,6 +108,10 @@ def test_principal_directions_host_equal_reference_arithmetic(oracle):
         want = np.ascontiguousarray(ev.reshape(ten.shape[:-1] + (3, 3))[..., 0, :])
         got = api.principal_directions_host(ten, order)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        want_sal = np.zeros(ten.shape[:-1], np.float32)
+        oracle.tensor_saliency(ten, order, want_sal)
+        got_sal = api.tensor_saliency_host(ten, order, np.zeros(ten.shape[:-1], np.float32))
+        assert np.array_equal(got_sal.view(np.uint32), want_sal.view(np.uint32))
     rng = np.random.default_rng(4)
     rnd = rng.normal(0, 5, (5000, 6)).astype(np.float32)
     rnd[:50, 3:] = 0                      # diagonal matrices

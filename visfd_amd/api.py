@@ -102,6 +102,7 @@ _SIGS = {
                                             _vp, C.c_float, C.c_float, C.c_int, C.c_int, _i64, C.c_int, C.c_int, C.c_int,
                                             C.POINTER(_i64), _vp, _vp, _vp, _i64]),
     "visfd_hip_principal_directions_host": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp]),
+    "visfd_hip_tensor_saliency_host": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp]),
     "visfd_hip_sphere_overlap": (C.c_float, [C.c_float, C.c_float, C.c_float]),
     "visfd_hip_sort_blobs": (C.c_int, [_fp, _fp, _fp, _i64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
     "visfd_hip_discard_masked_blobs": (C.c_int, [_fp, _fp, _fp, C.POINTER(_i64), _vp, _i64, _i64, _i64]),
@@ -223,6 +224,14 @@ def label_connected(saliency, threshold_saliency, mask=None, direction=None, ten
         int(bool(start_from_saliency_maxima)), C.byref(n), cm.ctypes.data, cs.ctypes.data, csal.ctypes.data, cap))
     k = n.value
     return labels, k, cm[:k], cs[:k], csal[:k]
+
+
+def tensor_saliency_host(tensor, order, sal_inout, mask=None):
+    """lambda0 - lambda1 of every [.., 6] tensor, host arithmetic (handlers.cpp:1868-1888), into sal_inout."""
+    L = load_library()
+    _chk_host(L, L.visfd_hip_tensor_saliency_host(_np(tensor), _np(mask), int(tensor.size // 6), int(order),
+                                                  _np(sal_inout)))
+    return sal_inout
 
 
 def principal_directions_host(tensor, order, mask=None):

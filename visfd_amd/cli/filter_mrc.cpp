@@ -154,6 +154,16 @@ struct Settings {
   float nonmax_min_radial_separation_ratio = 0.0f;            // settings.cpp:137
   float nonmax_max_overlap_large = std::numeric_limits<float>::infinity();
   float nonmax_max_overlap_small = std::numeric_limits<float>::infinity();
+  // clustering of the detected surface (-connect ...), settings.cpp:163-178
+  bool cluster_connected_voxels = false;
+  float connect_threshold_saliency = std::numeric_limits<float>::infinity();
+  float connect_threshold_vector_saliency = (float)std::cos(M_PI * 15 / 180.0);
+  float connect_threshold_vector_neighbor = (float)std::cos(M_PI * 15 / 180.0);
+  float connect_threshold_tensor_saliency = (float)std::cos(M_PI * 15 / 180.0);
+  float connect_threshold_tensor_neighbor = (float)std::cos(M_PI * 15 / 180.0);
+  bool undefined_voxels_are_max = true;                       // settings.cpp:43-44
+  float undefined_voxel_brightness = -1.0f;
+  string load_base;
   // membranes
   bool ridges_are_maxima = false;
   float hessian_thr = 0.05f;                                  // settings.cpp:150-151
@@ -275,10 +285,39 @@ Settings parse(int argc, char** argv) {
     }
     else if (f == "-detection-threshold") { need(1); s.hessian_thr = num(v, i + 1, f); s.hessian_thr_is_fraction = false; i += 2; }
     else if (f == "-save-progress") { need(1); s.save_base = v[i + 1]; i += 2; }
+    else if (f == "-load-progress") { need(1); s.load_base = v[i + 1]; i += 2; }
+    else if (f == "-connect" || f == "-connect-bright" || f == "-connect-saliency") {   // settings.cpp:3036-3052
+      need(1); s.cluster_connected_voxels = true; s.connect_threshold_saliency = num(v, i + 1, f); i += 2;
+    }
+    else if (f == "-connect-angle") {                                                    // settings.cpp:3075-3094
+      need(1); s.cluster_connected_voxels = true;
+      const double theta = num(v, i + 1, f);
+      const float c = (float)std::cos(theta * M_PI / 180.0);
+      s.connect_threshold_vector_saliency = s.connect_threshold_vector_neighbor = c;
+      s.connect_threshold_tensor_saliency = s.connect_threshold_tensor_neighbor = c;
+      i += 2;
+    }
+    else if (f == "-connect-vector-saliency") { need(1); s.cluster_connected_voxels = true; s.connect_threshold_vector_saliency = num(v, i + 1, f); i += 2; }
+    else if (f == "-connect-vector-neighbor") { need(1); s.cluster_connected_voxels = true; s.connect_threshold_vector_neighbor = num(v, i + 1, f); i += 2; }
+    else if (f == "-connect-tensor-saliency") { need(1); s.cluster_connected_voxels = true; s.connect_threshold_tensor_saliency = num(v, i + 1, f); i += 2; }
+    else if (f == "-connect-tensor-neighbor") { need(1); s.cluster_connected_voxels = true; s.connect_threshold_tensor_neighbor = num(v, i + 1, f); i += 2; }
+    else if (f == "-undefined-out") {                                                    // settings.cpp:2683-2700
+      need(1);
+      if (v[i + 1] == "max") s.undefined_voxels_are_max = true;
+      else { s.undefined_voxels_are_max = false; s.undefined_voxel_brightness = num(v, i + 1, f); }
+      i += 2;
+    }
+    else if (f == "-select-cluster") { need(1); i += 2; }   // only selects what -normals-file writes (not provided)
     else throw VisfdErr("Error: Unrecognized (or unsupported on the GPU hot path) argument: \"" + f + "\"\n");
   }
   if (s.in.empty()) throw VisfdErr("Error: You must specify an input file (-in).\n");
   if (s.type == Settings::SURFACE_RIDGE) s.tv_sigma *= s.width_a[0];   // settings.cpp:3535-3540
+  if (s.cluster_connected_voxels && s.type != Settings::SURFACE_RIDGE)
+    throw VisfdErr("Error: this build clusters voxels (-connect) only after \"-membrane ... -tv ...\".\n");
+  if (s.cluster_connected_voxels && s.connect_threshold_saliency == std::numeric_limits<float>::infinity())
+    throw VisfdErr("Error: clustering needs a saliency threshold (-connect THRESHOLD).\n");
+  if ((s.cluster_connected_voxels || !s.load_base.empty()) && !(s.tv_sigma > 0))
+    throw VisfdErr("Error: -connect and -load-progress need tensor voting (-tv).\n");
   return s;
 }
 
@@ -515,23 +554,69 @@ int main(int argc, char** argv) {
       cerr << "filter_type = surface ridge detector\n";
       const int order = s.ridges_are_maxima ? VISFD_HIP_INCREASING_EIVALS : VISFD_HIP_DECREASING_EIVALS;  // handlers.cpp:1524-1535
       const size_t n = tomo_in.nvox();
-      vector<float> tensor(s.save_base.empty() || s.tv_sigma <= 0 ? 0 : 6 * n);
-      float thr = 0;
-      hip_detail::check(visfd_hip_membrane_detect(
-          hip_detail::context(), tomo_in.data(), mask.loaded ? mask.data() : nullptr, size[0], size[1], size[2],
-          s.width_a[0], ratio, order, s.hessian_thr_is_fraction ? s.hessian_thr : -1.0f, s.hessian_thr, s.tv_sigma,
-          s.tv_exponent, s.tv_truncate, tomo_out.data(), tensor.empty() ? nullptr : tensor.data(), nullptr, &thr));
-      cerr << "  (saliency threshold = " << thr << ")\n";
-      if (!tensor.empty()) {
+      const bool want_tensor = s.tv_sigma > 0 && (!s.save_base.empty() || s.cluster_connected_voxels || !s.load_base.empty());
+      vector<float> tensor(want_tensor ? 6 * n : 0);
+      const float* mptr = mask.loaded ? mask.data() : nullptr;
+      if (s.load_base.empty()) {
+        float thr = 0;
+        hip_detail::check(visfd_hip_membrane_detect(
+            hip_detail::context(), tomo_in.data(), mptr, size[0], size[1], size[2],
+            s.width_a[0], ratio, order, s.hessian_thr_is_fraction ? s.hessian_thr : -1.0f, s.hessian_thr, s.tv_sigma,
+            s.tv_exponent, s.tv_truncate, tomo_out.data(), tensor.empty() ? nullptr : tensor.data(), nullptr, &thr));
+        cerr << "  (saliency threshold = " << thr << ")\n";
+      } else {
+        // handlers.cpp:1840-1862: the vote tensors come from "<base>_tensor_<d>.rec" (written by -save-progress)
+        for (int c = 0; c < 6; c++) {
+          std::ostringstream name;
+          name << s.load_base << "_tensor_" << c << ".rec";
+          cerr << "loading \"" << name.str() << "\"\n";
+          Mrc t;
+          t.read(name.str());
+          if (t.nx != size[0] || t.ny != size[1] || t.nz != size[2])
+            throw VisfdErr("Error: \"" + name.str() + "\" does not have the size of the (binned) input image.\n");
+          const float* p = t.data();
+          for (size_t i = 0; i < n; i++)
+            if (!mptr || mptr[i] != 0.0f) tensor[6 * i + c] = p[i];
+        }
+        hip_detail::check(visfd_hip_tensor_saliency_host(tensor.data(), mptr, (int64_t)n, order, tomo_out.data()));
+      }
+      if (!tensor.empty() && !s.save_base.empty()) {
         Mrc t;
         t.alloc(size[0], size[1], size[2]);
+        std::memcpy(t.raw_header, tomo_in.raw_header, 1024);
+        for (int d = 0; d < 3; d++) t.cella[d] = tomo_in.cella[d];
+        // (the reference starts each tensor file from a copy of tomo_out: masked voxels keep its values)
         for (int c = 0; c < 6; c++) {
           float* o = t.data();
-          for (size_t i = 0; i < n; i++) o[i] = tensor[6 * i + c];
+          const float* base = tomo_out.data();
+          for (size_t i = 0; i < n; i++) o[i] = (!mptr || mptr[i] != 0.0f) ? tensor[6 * i + c] : base[i];
           std::ostringstream name;
           name << s.save_base << "_tensor_" << c << ".rec";
           cerr << "writing \"" << name.str() << "\"\n";
           t.write(name.str(), tomo_in);
+        }
+      }
+      if (s.cluster_connected_voxels) {
+        // handlers.cpp:1925-2035.  Saliency and directions are recomputed on the host in the reference's own
+        // arithmetic (the flood order and the angle thresholds act on them); the vote tensors are exact already.
+        hip_detail::check(visfd_hip_tensor_saliency_host(tensor.data(), mptr, (int64_t)n, order, tomo_out.data()));
+        vector<float> direction(3 * n, 0.0f);
+        hip_detail::check(visfd_hip_principal_directions_host(tensor.data(), mptr, (int64_t)n, order, direction.data()));
+        vector<int64_t> labels(n);
+        int64_t n_clusters = 0;
+        hip_detail::check(visfd_hip_label_connected(
+            tomo_out.data(), labels.data(), mptr, size[0], size[1], size[2], s.connect_threshold_saliency,
+            direction.data(), s.connect_threshold_vector_saliency, s.connect_threshold_vector_neighbor, 0, tensor.data(),
+            s.connect_threshold_tensor_saliency, s.connect_threshold_tensor_neighbor, 1, 1, -1, 1, 1, 1, &n_clusters,
+            nullptr, nullptr, nullptr, 0));
+        cerr << "Number of clusters found: " << n_clusters << "\n";
+        int64_t max_label = labels[0];
+        for (size_t i = 0; i < n; i++)
+          if (!mptr || mptr[i] != 0.0f) max_label = std::max(max_label, labels[i]);
+        float* o = tomo_out.data();
+        for (size_t i = 0; i < n; i++) {
+          o[i] = (float)labels[i];
+          if (labels[i] == -1) o[i] = s.undefined_voxels_are_max ? (float)(max_label + 1) : s.undefined_voxel_brightness;
         }
       }
     }

@@ -368,6 +368,40 @@ extern "C" int visfd_hip_label_connected(const float* saliency, int64_t* labels,
   return VISFD_HIP_OK;
 }
 
+namespace {
+template <typename F>
+void parallel_voxels(int64_t nvox, F work) {
+  unsigned nt = std::thread::hardware_concurrency();
+  if (nt < 1) nt = 1;
+  if ((int64_t)nt > nvox / 4096 + 1) nt = (unsigned)(nvox / 4096 + 1);
+  std::vector<std::thread> pool;
+  const int64_t chunk = (nvox + nt - 1) / nt;
+  for (unsigned t = 1; t < nt; t++)
+    pool.emplace_back(work, std::min<int64_t>(nvox, t * chunk), std::min<int64_t>(nvox, (t + 1) * chunk));
+  work(0, std::min<int64_t>(nvox, chunk));
+  for (size_t t = 0; t < pool.size(); t++) pool[t].join();
+}
+}  // namespace
+
+// Post-vote score lambda0 - lambda1 (handlers.cpp:1868-1888) of nvox flat tensors [nvox][6], on the HOST in the
+// reference's arithmetic: the clustering that follows orders and thresholds voxels by this number, so the
+// command-line path recomputes it here instead of using the device kernel's value (equal to ~1e-7 only).
+extern "C" int visfd_hip_tensor_saliency_host(const float* tensor, const float* mask, int64_t nvox, int order,
+                                              float* saliency) {
+  if (!tensor || !saliency || nvox < 0) return vh::fail(VISFD_HIP_EINVAL, "tensor_saliency_host: bad argument");
+  parallel_voxels(nvox, [&](int64_t lo, int64_t hi) {
+    for (int64_t i = lo; i < hi; i++) {
+      if (mask && mask[i] == 0.0f) continue;
+      double lam[3];
+      vh::eig::D3 E[3];
+      vh::eig::eig_sym3(tensor + 6 * i, order, lam, E, true);   // the reference diagonalises fully (same eigenvalues)
+      const double l1 = (float)lam[0], l2 = (float)lam[1];      // stored as float, re-read as double
+      saliency[i] = (float)(l1 - l2);
+    }
+  });
+  return VISFD_HIP_OK;
+}
+
 // Principal eigenvector (row 0 of ConvertFlatSym2Evects3) of every voxel's tensor, on the HOST with glibc
 // arithmetic -- bit-identical to the reference's loop at bin/filter_mrc/handlers.cpp:1935-1952, which matters
 // because LabelConnected thresholds act on these directions.  Voxels with mask == 0 are left untouched.
@@ -375,21 +409,13 @@ extern "C" int visfd_hip_label_connected(const float* saliency, int64_t* labels,
 extern "C" int visfd_hip_principal_directions_host(const float* tensor, const float* mask, int64_t nvox, int order,
                                                    float* direction) {
   if (!tensor || !direction || nvox < 0) return vh::fail(VISFD_HIP_EINVAL, "principal_directions_host: bad argument");
-  unsigned nt = std::thread::hardware_concurrency();
-  if (nt < 1) nt = 1;
-  if ((int64_t)nt > nvox / 4096 + 1) nt = (unsigned)(nvox / 4096 + 1);
-  auto work = [&](int64_t lo, int64_t hi) {
+  parallel_voxels(nvox, [&](int64_t lo, int64_t hi) {
     for (int64_t i = lo; i < hi; i++) {
       if (mask && mask[i] == 0.0f) continue;
       float d6[6];
       vh::eig::diagonalize_flat(tensor + 6 * i, order, d6);
       vh::eig::shoemake_row0(d6 + 3, direction + 3 * i);
     }
-  };
-  std::vector<std::thread> pool;
-  const int64_t chunk = (nvox + nt - 1) / nt;
-  for (unsigned t = 1; t < nt; t++) pool.emplace_back(work, std::min<int64_t>(nvox, t * chunk), std::min<int64_t>(nvox, (t + 1) * chunk));
-  work(0, std::min<int64_t>(nvox, chunk));
-  for (size_t t = 0; t < pool.size(); t++) pool[t].join();
+  });
   return VISFD_HIP_OK;
 }
