@@ -317,3 +317,44 @@ def test_tensor_voting_dense_saliency(ctx, oracle):
     ten = ctx.tv_dense_stick(sal, d, 3.0, 2, 2.0 ** 0.5)
     assert_bits_equal(ten, oracle.tv_dense_stick(sal, d, 3.0, 2, 2.0 ** 0.5), "dense-saliency tensor")
 
+
+
+# ------------------------------------------------------------------------------------------ BASELINE-size volumes
+def test_gauss_large_volume_crops_equal_oracle(ctx, oracle):
+    """1024 x 1024 x 256 (the BASELINE plane size): the filter is local, so the result inside a crop equals the
+    CPU restatement run on the crop plus a halo of h voxels -- bit for bit, for the single-sweep kernel and for
+    the three single-axis kernels, in the interior and at faces/corners of the big volume."""
+    import torch
+    dev = torch.device("cuda:0")
+    nz, ny, nx = 256, 1024, 1024
+    g = torch.Generator(device=dev).manual_seed(77)
+    src = torch.randn((nz, ny, nx), device=dev, generator=g) * 100 + 1000
+    sigma, h = (2.0,) * 3, 5
+    outs = {}
+    dst = torch.empty_like(src)
+    ctx.gauss_dev(src, dst, sigma, (h, h, h))
+    ctx.synchronize()      # the library runs on its own stream here: finish before torch copies the result
+    outs["fused"] = dst.clone()
+    torch.cuda.synchronize()
+    os.environ["VISFD_HIP_GAUSS_3PASS"] = "1"
+    try:
+        ctx.gauss_dev(src, dst, sigma, (h, h, h))
+    finally:
+        del os.environ["VISFD_HIP_GAUSS_3PASS"]
+    outs["3-pass"] = dst
+    ctx.synchronize()
+    assert torch.equal(outs["fused"], outs["3-pass"])
+    E = 24   # crop edge
+    got = torch.empty_like(src)
+    ctx.gauss_dev(src, got, sigma, (h, h, h), None, False)
+    ctx.synchronize()
+    for (z0, y0, x0) in [(0, 0, 0), (nz - E, ny - E, nx - E), (100, 500, 1000), (7, 1000, 3), (128, 512, 512)]:
+        lo = [max(0, z0 - h), max(0, y0 - h), max(0, x0 - h)]
+        hi = [min(nz, z0 + E + h), min(ny, y0 + E + h), min(nx, x0 + E + h)]
+        sub = src[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]].cpu().numpy().copy()
+        # normalise=False: the boundary normaliser of the sub-volume differs from the big volume's, so compare
+        # the un-normalised filter (the normaliser itself is covered by the small-volume tests)
+        want, _ = oracle.gauss_hw(sub, sigma, (h, h, h), None, False)
+        a = got[z0:z0 + E, y0:y0 + E, x0:x0 + E].cpu().numpy()
+        b = want[z0 - lo[0]:z0 - lo[0] + E, y0 - lo[1]:y0 - lo[1] + E, x0 - lo[2]:x0 - lo[2] + E]
+        assert_bits_equal(a, b, "crop at %s" % ((z0, y0, x0),))

@@ -120,6 +120,13 @@ def load_library():
         if not os.path.exists(LIB_PATH):
             raise ImportError("%s is missing: build it with `python -m visfd_amd.build` "
                               "(there is no CPU fallback)" % LIB_PATH)
+        # PyTorch-ROCm ships its own copy of the HIP runtime; if this library pulled in the system copy first, a
+        # later `import torch` in the same process would bring a second runtime that cannot see the GPU ("no
+        # ROCm-capable device").  Loading torch's first makes both share one runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(lib, name)
