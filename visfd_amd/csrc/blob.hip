@@ -8,8 +8,9 @@
 // bit-for-bit whenever the three LoG volumes do.
 //
 // Two kernels:
-//   1. candidates: an HBM sweep of the MIDDLE volume only (4 B/voxel).  A workgroup owns a 64 x 4
-//      column tile and marches along z; each plane goes through an LDS tile with a one-voxel halo,
+//   1. candidates: an HBM sweep of the MIDDLE volume only (4 B/voxel).  A workgroup owns a 64 x 8
+//      column tile and marches along z four planes at a time (the next four already requested); each
+//      plane goes through an LDS tile with a one-voxel halo,
 //      each thread takes the min and max of its 3x3 neighbourhood, and a three-plane register ring
 //      gives the 3x3x3 box min/max.  A voxel is a candidate when it equals the box min (or max)
 //      and passes the sign/threshold tests -- a non-strict superset of the 26-neighbour rule.
@@ -17,6 +18,7 @@
 //      (strict comparisons, masks) and appends the survivors.
 // LoG volumes are smooth, so candidates are a small fraction of the voxels and kernel 2 is cheap.
 #include <algorithm>
+#include <cstdlib>
 #include <limits>
 
 #include "common.hpp"
@@ -27,9 +29,11 @@ namespace {
 
 constexpr int BLOCK = 512;
 constexpr int TX = 64, TY = 8;          // one voxel column per thread
-constexpr int FLUSH_EVERY = 4;          // planes between flushes of the workgroup's candidate buffer
-constexpr int BUFCAP = FLUSH_EVERY * BLOCK;
+constexpr int PZ = 4;                   // planes staged per step (and between flushes of the candidate buffer)
+constexpr int BUFCAP = 2 * PZ * BLOCK;  // candidate buffer (32-bit tile-relative codes): flushed when a step might not fit
 constexpr int LW = TX + 2, LH = TY + 2; // LDS tile with halo
+
+static_assert(BLOCK == 512 && TX == 64, "candidate codes pack the thread index in 9 bits");
 
 struct Cand {
   int ix, iy, iz;
@@ -42,9 +46,9 @@ blob_candidates_kernel(const float* __restrict__ mid, const float* __restrict__ 
                        float min_thr, float max_thr, int zchunk, int tiles_x, int tiles_y,
                        unsigned long long* __restrict__ out, unsigned long long capacity,
                        unsigned long long* __restrict__ counter) {
-  __shared__ float tile[2][LH * LW];
+  __shared__ float tile[PZ][LH * LW];
   // candidates are collected per workgroup and written out with ONE global atomic per flush
-  __shared__ unsigned long long buf[BUFCAP];
+  __shared__ unsigned int buf[BUFCAP];   // (z - zs) << 9 | thread index: one voxel of this workgroup's column
   __shared__ unsigned int buf_n;
   __shared__ unsigned long long buf_base;
   if (threadIdx.x == 0) buf_n = 0;
@@ -62,16 +66,27 @@ blob_candidates_kernel(const float* __restrict__ mid, const float* __restrict__ 
   const i64 plane = (i64)nx * ny;
   const bool interior = gx >= 1 && gx <= nx - 2 && gy >= 1 && gy <= ny - 2;
 
-  // cooperative load of one haloed plane into LDS (values outside the image are irrelevant: they
-  // only influence face voxels, which can never be blobs, feature.hpp:245-252)
-  auto load_plane = [&](int z, float* dst) {
-    for (int i = tid; i < LH * LW; i += BLOCK) {
-      const int r = i / LW, c = i - r * LW;
-      const int sx = x0 - 1 + c, sy = y0 - 1 + r;
-      float v = 0.0f;
-      if (sx >= 0 && sx < nx && sy >= 0 && sy < ny) v = mid[(i64)z * plane + (i64)sy * nx + sx];
-      dst[i] = v;
-    }
+  // cooperative load of one haloed plane (values outside the image are irrelevant: they only influence
+  // face voxels, which can never be blobs, feature.hpp:245-252).  Split in two so that the global loads
+  // of plane z+2 are in flight while plane z+1 is being compared (the march is latency-bound otherwise):
+  // fetch() reads this thread's (up to NLD) tile elements into registers, stash() writes them to LDS.
+  constexpr int NLD = (LH * LW + BLOCK - 1) / BLOCK;
+  i64 ld_off[NLD];   // offset inside a plane, -1: outside the image or beyond the tile
+#pragma unroll
+  for (int k = 0; k < NLD; k++) {
+    const int i = tid + k * BLOCK;
+    const int r = i / LW, c = i - r * LW;
+    const int sx = x0 - 1 + c, sy = y0 - 1 + r;
+    ld_off[k] = (i < LH * LW && sx >= 0 && sx < nx && sy >= 0 && sy < ny) ? ((i64)sy * nx + sx) : -1;
+  }
+  auto fetch = [&](int z, float v[NLD]) {
+#pragma unroll
+    for (int k = 0; k < NLD; k++) v[k] = (ld_off[k] >= 0 && z < nz) ? mid[(i64)z * plane + ld_off[k]] : 0.0f;
+  };
+  auto stash = [&](const float v[NLD], float* dst) {
+#pragma unroll
+    for (int k = 0; k < NLD; k++)
+      if (tid + k * BLOCK < LH * LW) dst[tid + k * BLOCK] = v[k];
   };
   // min and max over the 3x3 neighbourhood of (lx, ly) in an LDS plane, plus the centre value
   auto minmax9 = [&](const float* t, float& mn, float& mx, float& centre) {
@@ -85,45 +100,75 @@ blob_candidates_kernel(const float* __restrict__ mid, const float* __restrict__ 
     mn = fminf(mn, fminf(fminf(a, bb), c)); mx = fmaxf(mx, fmaxf(fmaxf(a, bb), c));
   };
 
+  // March in steps of PZ planes: the PZ planes after the current one are staged in LDS together (one barrier
+  // per step instead of one per plane) while the global loads of the following PZ planes are already in
+  // flight in registers, so the HBM latency is covered by PZ planes of comparisons.
   float mn_prev, mx_prev, c_prev, mn_cur, mx_cur, c_cur;
-  load_plane(zs - 1, tile[0]);
+  float pre[PZ][NLD];
+  fetch(zs - 1, pre[0]);
+  fetch(zs, pre[1]);
+  stash(pre[0], tile[0]);
+  stash(pre[1], tile[1]);
+#pragma unroll
+  for (int k = 0; k < PZ; k++) fetch(zs + 1 + k, pre[k]);
   __syncthreads();
   minmax9(tile[0], mn_prev, mx_prev, c_prev);
-  load_plane(zs, tile[1]);
-  __syncthreads();
   minmax9(tile[1], mn_cur, mx_cur, c_cur);
-  for (int z = zs; z < ze; z++) {
-    float* nxt = tile[(z - zs) & 1];      // the buffer that held plane z-1: free since the last barrier
-    load_plane(z + 1, nxt);
+  __syncthreads();   // both tiles free again
+  for (int z0 = zs; z0 < ze; z0 += PZ) {
+#pragma unroll
+    for (int k = 0; k < PZ; k++) stash(pre[k], tile[k]);                   // planes z0+1 .. z0+PZ
+#pragma unroll
+    for (int k = 0; k < PZ; k++) fetch(z0 + PZ + 1 + k, pre[k]);           // the next step's planes
     __syncthreads();
-    float mn_nxt, mx_nxt, c_nxt;
-    minmax9(nxt, mn_nxt, mx_nxt, c_nxt);
-    const float e = c_cur;
-    const float bmin = fminf(fminf(mn_prev, mn_cur), mn_nxt);
-    const float bmax = fmaxf(fmaxf(mx_prev, mx_cur), mx_nxt);
-    const bool is_min = (e == bmin) && (e < 0.0f) && (e < min_thr);
-    const bool is_max = (e == bmax) && (e > 0.0f) && (e > max_thr);
-    if (interior && (is_min || is_max)) {
-      const i64 v = (i64)z * plane + (i64)gy * nx + gx;
-      if (!(mask && mask[v] == 0.0f)) buf[atomicAdd(&buf_n, 1u)] = (unsigned long long)v;
-    }
-    mn_prev = mn_cur; mx_prev = mx_cur;
-    mn_cur = mn_nxt; mx_cur = mx_nxt; c_cur = c_nxt;
-    // no second barrier for the tiles: the buffer overwritten in the next step was last read before
-    // this step's barrier, and the one read in this step is only overwritten after the next one's
-    if (((z - zs) % FLUSH_EVERY) == FLUSH_EVERY - 1 || z == ze - 1) {   // uniform
-      __syncthreads();
-      const unsigned int n = buf_n;
-      if (tid == 0 && n) buf_base = atomicAdd(counter, (unsigned long long)n);
-      __syncthreads();
-      if (n) {
-        const unsigned long long base = buf_base;
-        for (unsigned int i = tid; i < n; i += BLOCK)
-          if (base + i < capacity) out[base + i] = buf[i];
+#pragma unroll
+    for (int k = 0; k < PZ; k++) {
+      const int z = z0 + k;
+      if (z < ze) {   // uniform
+        float mn_nxt, mx_nxt, c_nxt;
+        minmax9(tile[k], mn_nxt, mx_nxt, c_nxt);
+        const float e = c_cur;
+        const float bmin = fminf(fminf(mn_prev, mn_cur), mn_nxt);
+        const float bmax = fmaxf(fmaxf(mx_prev, mx_cur), mx_nxt);
+        const bool is_min = (e == bmin) && (e < 0.0f) && (e < min_thr);
+        const bool is_max = (e == bmax) && (e > 0.0f) && (e > max_thr);
+        {  // append with ONE LDS atomic per wave (ballot + prefix count) instead of one per candidate
+          const i64 v = (i64)z * plane + (i64)gy * nx + gx;
+          bool cand = interior && (is_min || is_max);
+          if (cand && mask && mask[v] == 0.0f) cand = false;
+          const unsigned long long bal = __ballot(cand);
+          if (bal != 0ull) {
+            const int lane = tid & 63;
+            const int leader = __ffsll((long long)bal) - 1;
+            unsigned int base = 0;
+            if (lane == leader) base = atomicAdd(&buf_n, (unsigned int)__popcll(bal));
+            base = (unsigned int)__shfl((int)base, leader);
+            if (cand) buf[base + (unsigned int)__popcll(bal & ((1ull << lane) - 1ull))] = ((unsigned int)(z - zs) << 9) | (unsigned int)tid;
+          }
+        }
+        mn_prev = mn_cur; mx_prev = mx_cur;
+        mn_cur = mn_nxt; mx_cur = mx_nxt; c_cur = c_nxt;
       }
+    }
+    // Flush the workgroup's candidates with ONE global atomic -- and only when the next step might not fit:
+    // every workgroup of the grid adds to the same counter, and atomics on one address are served one
+    // at a time by L2 (flushing every step made this kernel 3x slower than its memory traffic).
+    // The first barrier also keeps the next step's stash from overwriting tiles that are still being read.
+    __syncthreads();
+    const unsigned int n = buf_n;
+    const bool last = z0 + PZ >= ze;
+    if (n > (unsigned int)(BUFCAP - PZ * BLOCK) || (last && n)) {   // uniform
+      if (tid == 0) buf_base = atomicAdd(counter, (unsigned long long)n);
       __syncthreads();
-      if (tid == 0) buf_n = 0;
-      // the next append happens after the next plane's barrier, which orders this reset before it
+      const unsigned long long base = buf_base;
+      for (unsigned int i = tid; i < n; i += BLOCK)
+        if (base + i < capacity) {
+          const unsigned int code = buf[i];
+          const int t = (int)(code & 511u), zz = zs + (int)(code >> 9);
+          out[base + i] = (unsigned long long)((i64)zz * plane + (i64)(y0 + (t >> 6)) * nx + (x0 + (t & (TX - 1))));
+        }
+      __syncthreads();
+      if (tid == 0) buf_n = 0;   // ordered before the next appends by the next step's barrier
     }
   }
 }
@@ -214,6 +259,7 @@ int dev_blob_scan(visfd_hip_ctx* ctx, const float* lo, const float* mid, const f
     unsigned long long n_cand = 0;
     VH_HIP(hipMemcpyAsync(&n_cand, counters, sizeof(n_cand), hipMemcpyDeviceToHost, st));
     VH_HIP(hipStreamSynchronize(st));
+    if (getenv("VISFD_HIP_DEBUG")) fprintf(stderr, "[blob scan] scale %d: %llu candidates\n", scale_index, n_cand);
     if (n_cand > cap_idx) { cap_idx = (size_t)n_cand; continue; }   // rare: grow and rescan
     unsigned long long count = 0;
     if (n_cand) {
