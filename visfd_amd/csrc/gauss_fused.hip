@@ -24,6 +24,8 @@
 // term as the reference does (filter1d.hpp:98-99) for finite data.
 //
 // This file is compiled once per window half-width (-DVH_FUSED_H=h, see visfd_amd/build.py).
+#include <cstdlib>
+
 #include "common.hpp"
 
 #ifndef VH_FUSED_H
@@ -312,7 +314,9 @@ int launch_cfg(visfd_hip_ctx* ctx, const float* src, float* dst, i64 nx, i64 ny,
   // z chunks: enough workgroups to fill the chip several times over, but marches long enough
   // to amortise the 2H-plane ring warm-up
   const i64 tiles = (i64)tiles_x * tiles_y;
-  i64 want_chunks = ((i64)ctx->num_cus * 6 + tiles - 1) / tiles;
+  int per_cu = 2;   // sweep at 1024^3: 1-2 workgroups per CU are best (fewer ring warm-ups), 6 costs 2.5 %
+  if (const char* e = getenv("VISFD_HIP_GAUSS_WG_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 64) per_cu = v; }   // tuning aid
+  i64 want_chunks = ((i64)ctx->num_cus * per_cu + tiles - 1) / tiles;
   if (want_chunks < 1) want_chunks = 1;
   i64 zchunk = (nz + want_chunks - 1) / want_chunks;
   const i64 min_chunk = 12 * H;
