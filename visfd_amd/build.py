@@ -23,7 +23,7 @@ SOURCES = ["host_math.cpp", "blob_post.cpp", "connect.cpp", "api.hip", "gauss.hi
 # the vote loop is faster without the SLP vectoriser's packed-f32 shuffles (profiles/r01 notes)
 TV_VARIANT = [("tv_tiled.hip", "tv_tiled", ["-fno-slp-vectorize"])]
 VARIANTS = TV_VARIANT + [("gauss_fused.hip", "gauss_fused_h%d" % h, ["-DVH_FUSED_H=%d" % h, "-fno-slp-vectorize"])
-                         for h in range(1, 11)]
+                         for h in range(1, 9)]
 if os.environ.get("VISFD_FUSED_EXTRA_CFGS"):
     VARIANTS = [(s, o, f + ["-DVH_FUSED_EXTRA_CFGS"]) for s, o, f in VARIANTS]
 HEADERS = ["common.hpp", "eigen3.hpp", os.path.join("..", "..", "include", "visfd_hip.h")]

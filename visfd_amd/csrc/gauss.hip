@@ -151,7 +151,8 @@ conv_march_kernel(const float* __restrict__ in, float* __restrict__ out, const f
 
 // conv_row_kernel: the X pass.  A block handles ROW_X consecutive x of ROW_Y rows (same z); LDS
 // holds the ROW_Y x (ROW_X + 2h) source values; one thread per x computes the ROW_Y outputs of
-// its column position.  NORM_BOX / NORM_DEN fold the normalisation of filter3d.hpp:986-1026 in.
+// its column position.  NORM_BOX / NORM_DEN fold the normalisation of filter3d.hpp:986-1026 in, and an
+// optional minuend turns the store into the DoG/LoG result (minuend - G) * scale.
 constexpr int ROW_X = 256;
 constexpr int ROW_Y = 8;
 static_assert(ROW_X == BLOCK && 2 * MAX_HALFWIDTH <= BLOCK, "the row tile is staged with two loads per thread");
@@ -160,7 +161,8 @@ template <int HT, int NORM>
 __global__ void __launch_bounds__(BLOCK)
 conv_row_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ den_in,
                 const float* __restrict__ Dx, const float* __restrict__ Dy, const float* __restrict__ Dz,
-                i64 dz_offset, TapsK<HT> tk, Taps taps_rt, int nx, int ny, int nz, int xblocks, int yblocks) {
+                i64 dz_offset, TapsK<HT> tk, Taps taps_rt, int nx, int ny, int nz, int xblocks, int yblocks,
+                const float* __restrict__ minuend, float log_scale) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int h = HT > 0 ? HT : taps_rt.h;
   const int W = 2 * h + 1;
@@ -218,6 +220,10 @@ conv_row_kernel(const float* __restrict__ in, float* __restrict__ out, const flo
     } else if (NORM == NORM_DEN) {
       const float d = den_in[c];
       if (d > 0.0f) acc = acc / d;
+    }
+    if (minuend) {   // DoG/LoG epilogue (filter3d.hpp:1387-1390, :1495-1498): two roundings; out may alias minuend
+      const float dd = minuend[c] - acc;
+      acc = dd * log_scale;
     }
     out[c] = acc;
   }
@@ -284,14 +290,16 @@ int launch_march(visfd_hip_ctx* ctx, int axis, const float* in, float* out, cons
 
 template <int NORM>
 int launch_row(visfd_hip_ctx* ctx, const float* in, float* out, const float* den_in, const float* Dx, const float* Dy,
-               const float* Dz, i64 dz_offset, const Taps& T, i64 nx, i64 ny, i64 nz) {
+               const float* Dz, i64 dz_offset, const Taps& T, i64 nx, i64 ny, i64 nz, const float* minuend = nullptr,
+               float log_scale = 1.0f) {
   const int xblocks = (int)((nx + ROW_X - 1) / ROW_X), yblocks = (int)((ny + ROW_Y - 1) / ROW_Y);
   const i64 nblk = (i64)xblocks * yblocks * nz;
   if (nblk > 0x7fffffffLL) return fail(VISFD_HIP_EINVAL, "volume too large for one launch");
   const size_t lds = sizeof(float) * (size_t)ROW_Y * (ROW_X + 2 * T.h);
   VH_FOR_H(T.h, {
     conv_row_kernel<HT, NORM><<<dim3((unsigned)nblk), dim3(BLOCK), lds, ctx->stream>>>(
-        in, out, den_in, Dx, Dy, Dz, dz_offset, taps_k<HT>(T), T, (int)nx, (int)ny, (int)nz, xblocks, yblocks);
+        in, out, den_in, Dx, Dy, Dz, dz_offset, taps_k<HT>(T), T, (int)nx, (int)ny, (int)nz, xblocks, yblocks, minuend,
+        log_scale);
   })
   VH_HIP(hipGetLastError());
   return VISFD_HIP_OK;
@@ -306,18 +314,20 @@ int launch_row(visfd_hip_ctx* ctx, const float* in, float* out, const float* den
                                const float* Dx, const float* Dy, const float* Dz, i64 dz_offset,  \
                                bool normalize, int cfg, const float* minuend, float log_scale);
 VH_DECL_FUSED(1) VH_DECL_FUSED(2) VH_DECL_FUSED(3) VH_DECL_FUSED(4) VH_DECL_FUSED(5)
-VH_DECL_FUSED(6) VH_DECL_FUSED(7) VH_DECL_FUSED(8) VH_DECL_FUSED(9) VH_DECL_FUSED(10)
+VH_DECL_FUSED(6) VH_DECL_FUSED(7) VH_DECL_FUSED(8)
 #undef VH_DECL_FUSED
 
-// The single-sweep kernel covers the unmasked case with equal half-widths 1..10 on the three axes
-// (any sigma per axis), nx a multiple of 4, and planes below 2 GiB; everything else takes the 3-pass path.
+// The single-sweep kernel covers the unmasked case with equal half-widths 1..8 on the three axes (any sigma
+// per axis), nx a multiple of 4, and planes below 2 GiB; everything else takes the 3-pass path.  (Beyond h = 8
+// the register ring no longer fits 128 VGPRs: the spilling single-sweep kernels ran at 10 and 16 ms for
+// h = 9 and 10 at 1024^3, three bandwidth-bound passes take 5.3 ms.)
 static int dev_gauss_fused(visfd_hip_ctx* ctx, const float* src, float* dst, i64 nx, i64 ny, i64 nz,
                            const Taps& tx, const Taps& ty, const Taps& tz, const float* Dx,
                            const float* Dy, const float* Dz, i64 dz_offset, bool normalize,
                            const float* minuend, float log_scale, bool* handled) {
   *handled = false;
   const int H = tx.h;
-  if (ty.h != H || tz.h != H || H < 1 || H > 10) return VISFD_HIP_OK;
+  if (ty.h != H || tz.h != H || H < 1 || H > 8) return VISFD_HIP_OK;
   if ((nx & 3) || nx * ny >= (1LL << 29) || nz >= (1LL << 31)) return VISFD_HIP_OK;
   if (src == dst) return VISFD_HIP_OK;  // in place: 3-pass path through scratch volumes
   const char* force = getenv("VISFD_HIP_GAUSS_3PASS");
@@ -327,7 +337,7 @@ static int dev_gauss_fused(visfd_hip_ctx* ctx, const float* src, float* dst, i64
   *handled = true;
   switch (H) {
 #define VH_CASE(HH) case HH: return launch_gauss_fused_h##HH(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, cfg, minuend, log_scale);
-    VH_CASE(1) VH_CASE(2) VH_CASE(3) VH_CASE(4) VH_CASE(5) VH_CASE(6) VH_CASE(7) VH_CASE(8) VH_CASE(9) VH_CASE(10)
+    VH_CASE(1) VH_CASE(2) VH_CASE(3) VH_CASE(4) VH_CASE(5) VH_CASE(6) VH_CASE(7) VH_CASE(8)
 #undef VH_CASE
   }
   *handled = false;
@@ -373,12 +383,10 @@ int dev_separable3d(visfd_hip_ctx* ctx, const float* src, float* dst, const floa
       return VISFD_HIP_OK;
     }
   }
-  // the DoG/LoG epilogue exists only in the single-sweep kernel: when it does not apply, nothing is
-  // computed here (dst may alias the minuend) and the caller takes the two-volume route
-  if (minuend) {
-    if (!epilogue_done) return fail(VISFD_HIP_EINVAL, "internal: unfused epilogue request");
-    return VISFD_HIP_OK;
-  }
+  // the DoG/LoG epilogue is also folded into the X pass of the three-pass route (the intermediate volumes are
+  // workspace slots, so dst may alias the minuend here as well)
+  if (minuend && !epilogue_done) return fail(VISFD_HIP_EINVAL, "internal: epilogue request without a result flag");
+  if (minuend) *epilogue_done = true;
 
   float *A = nullptr, *B = nullptr;
   VH_TRY(ws(ctx, WS_A, (size_t)n, &A));
@@ -387,12 +395,12 @@ int dev_separable3d(visfd_hip_ctx* ctx, const float* src, float* dst, const floa
   if (!mask) {
     VH_TRY(launch_march<false>(ctx, 2, src, A, nullptr, nullptr, Tz, nx, ny, nz));
     VH_TRY(launch_march<false>(ctx, 1, A, B, nullptr, nullptr, Ty, nx, ny, nz));
-    if (normalize) VH_TRY(launch_row<NORM_BOX>(ctx, B, dst, nullptr, Dx, Dy, Dz, slab.z_lo, Tx, nx, ny, nz));
-    else VH_TRY(launch_row<NORM_NONE>(ctx, B, dst, nullptr, nullptr, nullptr, nullptr, 0, Tx, nx, ny, nz));
+    if (normalize) VH_TRY(launch_row<NORM_BOX>(ctx, B, dst, nullptr, Dx, Dy, Dz, slab.z_lo, Tx, nx, ny, nz, minuend, log_scale));
+    else VH_TRY(launch_row<NORM_NONE>(ctx, B, dst, nullptr, nullptr, nullptr, nullptr, 0, Tx, nx, ny, nz, minuend, log_scale));
   } else if (!normalize) {
     VH_TRY(launch_march<true>(ctx, 2, src, A, mask, nullptr, Tz, nx, ny, nz));
     VH_TRY(launch_march<false>(ctx, 1, A, B, nullptr, nullptr, Ty, nx, ny, nz));
-    VH_TRY(launch_row<NORM_NONE>(ctx, B, dst, nullptr, nullptr, nullptr, nullptr, 0, Tx, nx, ny, nz));
+    VH_TRY(launch_row<NORM_NONE>(ctx, B, dst, nullptr, nullptr, nullptr, nullptr, 0, Tx, nx, ny, nz, minuend, log_scale));
   } else {
     float *DA = nullptr, *DB = nullptr;
     VH_TRY(ws(ctx, WS_DEN_A, (size_t)n, &DA));
@@ -401,7 +409,7 @@ int dev_separable3d(visfd_hip_ctx* ctx, const float* src, float* dst, const floa
     VH_TRY(launch_march<false>(ctx, 1, A, B, nullptr, nullptr, Ty, nx, ny, nz));
     VH_TRY(launch_march<false>(ctx, 1, DA, DB, nullptr, nullptr, Ty, nx, ny, nz));
     VH_TRY(launch_row<NORM_NONE>(ctx, DB, DA, nullptr, nullptr, nullptr, nullptr, 0, Tx, nx, ny, nz));
-    VH_TRY(launch_row<NORM_DEN>(ctx, B, dst, DA, nullptr, nullptr, nullptr, 0, Tx, nx, ny, nz));
+    VH_TRY(launch_row<NORM_DEN>(ctx, B, dst, DA, nullptr, nullptr, nullptr, 0, Tx, nx, ny, nz, minuend, log_scale));
   }
   VH_HIP(hipGetLastError());
   return VISFD_HIP_OK;

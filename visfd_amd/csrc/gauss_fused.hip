@@ -366,10 +366,8 @@ int VH_CAT(launch_gauss_fused_h, VH_FUSED_H)(visfd_hip_ctx* ctx, const float* sr
     return launch_cfg<H, 128, 16, 512, 4, 2>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
   else if constexpr (H <= 5)
     return launch_cfg<H, 128, 32, 1024, 4, 2>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
-  else if constexpr (H <= 8)
-    return launch_cfg<H, 64, 32, 1024, 2, 1>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
   else
-    return launch_cfg<H, 64, 32, 1024, 2, 2>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
+    return launch_cfg<H, 64, 32, 1024, 2, 1>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
 }
 
 }  // namespace vh
