@@ -358,3 +358,40 @@ def test_gauss_large_volume_crops_equal_oracle(ctx, oracle):
         a = got[z0:z0 + E, y0:y0 + E, x0:x0 + E].cpu().numpy()
         b = want[z0 - lo[0]:z0 - lo[0] + E, y0 - lo[1]:y0 - lo[1] + E, x0 - lo[2]:x0 - lo[2] + E]
         assert_bits_equal(a, b, "crop at %s" % ((z0, y0, x0),))
+
+
+# ------------------------------------------------------------------------------------------ empty / degenerate inputs
+def test_empty_and_degenerate_inputs(ctx, oracle):
+    """No salient voxel, a single salient voxel, a single-plane volume, a constant image: the cases where lists
+    are empty, windows are clipped on every side, or nothing can be an extremum."""
+    from visfd_amd import api
+    shape = (9, 20, 24)
+    d = np.zeros(shape + (3,), np.float32)
+    d[..., 2] = 1.0
+    zero = np.zeros(shape, np.float32)
+    for dense in ("0", "1"):
+        os.environ["VISFD_HIP_TV_DENSE"] = dense
+        try:
+            ten = ctx.tv_dense_stick(zero, d, 3.0, 4, 2.0 ** 0.5)
+            assert not ten.any(), "votes without senders"
+            one = zero.copy()
+            one[4, 10, 12] = 2.5
+            assert_bits_equal(ctx.tv_dense_stick(one, d, 3.0, 4, 2.0 ** 0.5), oracle.tv_dense_stick(one, d, 3.0, 4, 2.0 ** 0.5),
+                              "single sender")
+            flat = np.random.default_rng(3).uniform(0, 1, (1, 20, 24)).astype(np.float32) * (np.arange(24) % 5 == 0)
+            dflat = np.ascontiguousarray(d[:1])
+            assert_bits_equal(ctx.tv_dense_stick(flat, dflat, 3.0, 4, 2.0 ** 0.5),
+                              oracle.tv_dense_stick(flat, dflat, 3.0, 4, 2.0 ** 0.5), "single-plane volume")
+        finally:
+            del os.environ["VISFD_HIP_TV_DENSE"]
+    const = np.full((12, 14, 16), 7.0, np.float32)
+    sig = np.array([1.0, 1.3, 1.7, 2.2], np.float32)
+    mins, maxs = ctx.blob_dog(const, sig, None, None, 0.02, oracle.ratio_from_threshold(0.03))
+    a, b = oracle.blob_dog(const, sig, None, None, 0.02, oracle.ratio_from_threshold(0.03))
+    assert len(mins) == len(a) and len(maxs) == len(b)
+    with pytest.raises(api.VisfdHipError):
+        ctx.threshold_fraction(zero.copy(), 1.5)          # the fraction selects no voxel
+    mask0 = np.zeros(shape, np.float32)
+    out, _ = ctx.gauss_hw(np.ones(shape, np.float32), (1.0,) * 3, (2, 2, 2), mask0, True)
+    want, _ = oracle.gauss_hw(np.ones(shape, np.float32), (1.0,) * 3, (2, 2, 2), mask0, True)
+    assert_bits_equal(out, want, "all-masked Gaussian")
