@@ -57,7 +57,7 @@ int visfd_hip_synchronize(visfd_hip_ctx* ctx);
 /* release the cached workspace (it otherwise persists between calls) */
 int visfd_hip_trim(visfd_hip_ctx* ctx);
 const char* visfd_hip_last_error(void);
-int visfd_hip_abi_version(void);
+int visfd_hip_abi_version(void);   /* 2: entry points only get added between versions */
 /* bytes of device workspace currently held by the context */
 int64_t visfd_hip_workspace_bytes(visfd_hip_ctx* ctx);
 

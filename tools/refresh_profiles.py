@@ -17,6 +17,9 @@ with open(os.path.join(ROOT, "profiles", "r01_bench_1024_summary.txt"), "w") as 
     f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu"
             "   (MI355X, 1024^3, round 1, final kernels)\n")
     f.write("# 3 pipeline steps + 11 extra Gaussian launches (roofline timing) + synthetic-input generation\n")
+    f.write("# gauss_fused_kernel<5,...>: the 11 roofline launches + 3 pipeline launches are plain Gaussians (the roofline\n"
+            "#   object's ms_per_launch); the other 12 are second Gaussians of LoG scales, which also read the minuend\n"
+            "#   (12 B/voxel), so the average over all calls sits a few percent above ms_per_launch\n")
     f.write("%-100s %6s %12s %10s %7s\n" % ("kernel", "calls", "total_ms", "avg_ms", "pct"))
     for r in rows[:22]:
         f.write("%-100s %6d %12.3f %10.4f %7s\n" % (r["Name"][:100], int(r["Calls"]), int(r["TotalDurationNs"]) / 1e6,

@@ -94,7 +94,8 @@ __device__ __forceinline__ void acc(float& t, float x) {
   asm("v_add_f32 %0, %0, %1" : "+v"(t) : "v"(x));
 }
 
-// MODE 0: surfaces with angular exponent 4 (the CLI default, settings.cpp:154); MODE 1: general.
+// MODE 0: surfaces with angular exponent 4 (the CLI default, settings.cpp:154); MODE 2: surfaces with exponent 2;
+// MODE 1: general (any exponent through pow, curve mode).
 // The vote of one (sender, receiver) pair in two halves, so that the vote loop can put LDS reads
 // between them: vote_dir gives the magnitude and the voted direction, vote_acc adds the outer product.
 template <int MODE>
@@ -106,8 +107,8 @@ __device__ __forceinline__ void vote_dir(float sal, float fv, float r0, float r1
   const float u2 = u * u;
   const float c2 = 1.0f - u2;
   float dec;
-  if (MODE == 0) {
-    dec = c2 * c2;
+  if (MODE == 0 || MODE == 2) {
+    dec = (MODE == 0) ? c2 * c2 : c2;
     m0 = ux2 * r0 - n0; m1 = ux2 * r1 - n1; m2 = ux2 * r2 - n2;
   } else {
     const float ang = curves ? u2 : c2;
@@ -138,7 +139,7 @@ __device__ __forceinline__ float with_sign_of(float m, int j) {
 }
 
 template <bool MASKED_SRC, int MODE>
-__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MODE != 1 ? 4 : 2, 4)))
 tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, float* __restrict__ ten,
                 const float* __restrict__ mask_src, const float* __restrict__ mask_dst,
                 const float4* __restrict__ table /* [(2h+1)^3] : w, rhat_x, rhat_y, rhat_z at j */,
@@ -546,7 +547,7 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
   const size_t lds = sizeof(float4) * slice_f4;   // dynamic part
   const size_t lds_static = (size_t)ENT_BYTES * (CAP + 1) + (size_t)4 * CAP + (size_t)4 * (NWORDS + 1) * NT + 64;
   if (lds + lds_static > 150 * 1024) return VISFD_HIP_OK;   // window too wide for the LDS slices: baseline kernel
-  const int mode = (exponent == 4 && !curves) ? 0 : 1;
+  const int mode = curves ? 1 : (exponent == 4 ? 0 : (exponent == 2 ? 2 : 1));
 #define VH_TV_LAUNCH(MSK, MD)                                                                        \
   do {                                                                                               \
     VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tv_tiled_kernel<MSK, MD>),             \
@@ -554,8 +555,8 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
     tv_tiled_kernel<MSK, MD><<<dim3((unsigned)nblk), dim3(NT), lds, st>>>(sal, dir, ten, mask_src,   \
                                                                          mask_dst, dtab, p);         \
   } while (0)
-  if (mask_src) { if (mode == 0) VH_TV_LAUNCH(true, 0); else VH_TV_LAUNCH(true, 1); }
-  else          { if (mode == 0) VH_TV_LAUNCH(false, 0); else VH_TV_LAUNCH(false, 1); }
+  if (mask_src) { if (mode == 0) VH_TV_LAUNCH(true, 0); else if (mode == 2) VH_TV_LAUNCH(true, 2); else VH_TV_LAUNCH(true, 1); }
+  else          { if (mode == 0) VH_TV_LAUNCH(false, 0); else if (mode == 2) VH_TV_LAUNCH(false, 2); else VH_TV_LAUNCH(false, 1); }
 #undef VH_TV_LAUNCH
   VH_HIP(hipGetLastError());
 #ifdef VH_TV_STATS
