@@ -222,7 +222,7 @@ def main():
     value = nvox_rank * world / (ms_per_step * 1e-3) / 1e6  # Mvoxels/s, whole job
 
     # ---- roofline of the separable-Gaussian kernel, timed alone with HIP events ----------------
-    roofline = roofline_pass = None
+    roofline = roofline_pass = roofline_tv = None
     if rank == 0:
         reps = 10
         pipeline.gauss(ctx, src, dst, GAUSS_SIGMA)
@@ -275,6 +275,32 @@ def main():
                          "ms_per_launch": round(p_ms, 4), "voxels_per_launch": nv,
                          "note": "average of the three pass launches; a device copy on this box runs at ~5.0 TB/s"}
 
+        # the tensor-voting kernel (84 % of the step): a VALU-bound stencil, priced against the FP32 vector peak as
+        # SURVEY.md 8d asks -- 45 flop per evaluated vote (feature.hpp:2312-2377), votes = salient senders x non-zero taps
+        # (boundary clipping ignored: < 4 % at this size)
+        order = api.DECREASING_EIVALS
+        ratio = api.ratio_from_threshold(0.03)
+        ctx.ridge_saliency_dev(src, sal, dirs, MEMBRANE["sigma"], ratio, order)
+        ctx.threshold_fraction_dev(sal, MEMBRANE["best_fraction"])
+        n_salient = int(torch.count_nonzero(sal).item())
+        _, w_tab, _ = api.tv_tables(sigma_tv, math.sqrt(2.0))
+        n_taps = int(np.count_nonzero(w_tab))
+        torch.cuda.synchronize()
+        e0.record()
+        ctx.tv_dense_stick_dev(sal, dirs, ten, sigma_tv, MEMBRANE["tv_exponent"], math.sqrt(2.0))
+        e1.record()
+        torch.cuda.synchronize()
+        tv_ms = e0.elapsed_time(e1)
+        votes = float(n_salient) * n_taps
+        tv_tflops = 45.0 * votes / (tv_ms * 1e-3) / 1e12
+        roofline_tv = {"bound": "valu", "kernel": "tv_tiled_kernel (dense stick tensor voting, sigma_tv=8.66, h=12)",
+                       "achieved": round(tv_tflops, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tv_tflops / 157.3, 4),
+                       "traffic": None, "ms_per_launch": round(tv_ms, 2), "votes_per_launch": votes,
+                       "flop_per_vote": 45, "salient_senders": n_salient, "nonzero_taps": n_taps,
+                       "note": "peak = nominal FP32 vector rate (packed FMA); the reference's operation order forbids FMA "
+                               "and packing, which leaves ~39 T scalar fp32 instructions/s to issue: the kernel issues "
+                               "~85 % of that (DESIGN.md 4.2)"}
+
     if rank == 0:
         out = {
             "metric": "Mvoxels/s (Gauss+DoG+TV pipeline) on %d^3 float32; %% HBM roofline" % S,
@@ -290,6 +316,7 @@ def main():
             "results": counts,
             "roofline": roofline,
             "roofline_pass": roofline_pass,
+            "roofline_tv": roofline_tv,
         }
         if not args.no_cpu and world == 1:  # the CPU baseline is an N=1 line only
             try:
