@@ -395,3 +395,28 @@ def test_empty_and_degenerate_inputs(ctx, oracle):
     out, _ = ctx.gauss_hw(np.ones(shape, np.float32), (1.0,) * 3, (2, 2, 2), mask0, True)
     want, _ = oracle.gauss_hw(np.ones(shape, np.float32), (1.0,) * 3, (2, 2, 2), mask0, True)
     assert_bits_equal(out, want, "all-masked Gaussian")
+
+
+def test_tensor_voting_large_volume_crops(ctx, oracle):
+    """Voting is local (window half-width h): inside a crop, at least h voxels from the crop's faces, the vote tensor
+    of the crop alone equals the tensor of the whole volume -- bit for bit, although tiles, sender lists and flush
+    boundaries fall differently (the crop's origin is not a multiple of the tile size).  One crop is also checked
+    against the CPU restatement."""
+    shape, sigma_tv, h = (96, 208, 272), 8.66, 12
+    rng = np.random.default_rng(31)
+    sal = (rng.random(shape) < 0.05).astype(np.float32) * rng.uniform(0.5, 3.0, shape).astype(np.float32)
+    sal[40:44, 60:140, 50:200] = rng.uniform(1.0, 2.0, (4, 80, 150)).astype(np.float32)     # a dense sheet
+    d = rng.standard_normal(shape + (3,)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True).astype(np.float32)
+    d = np.ascontiguousarray(d, np.float32)
+    full = ctx.tv_dense_stick(sal, d, sigma_tv, 4, 2.0 ** 0.5)
+    for (z0, y0, x0), (cz, cy, cx), check_oracle in (((21, 37, 53), (52, 70, 90), False), ((30, 50, 45), (34, 44, 52), True)):
+        s_c = np.ascontiguousarray(sal[z0:z0 + cz, y0:y0 + cy, x0:x0 + cx])
+        d_c = np.ascontiguousarray(d[z0:z0 + cz, y0:y0 + cy, x0:x0 + cx])
+        part = ctx.tv_dense_stick(s_c, d_c, sigma_tv, 4, 2.0 ** 0.5)
+        a = part[h:cz - h, h:cy - h, h:cx - h]
+        b = full[z0 + h:z0 + cz - h, y0 + h:y0 + cy - h, x0 + h:x0 + cx - h]
+        assert a.size > 0 and np.abs(a).max() > 0
+        assert_bits_equal(a, b, "crop at %s" % ((z0, y0, x0),))
+        if check_oracle:
+            assert_bits_equal(part, oracle.tv_dense_stick(s_c, d_c, sigma_tv, 4, 2.0 ** 0.5), "crop vs oracle")
