@@ -412,6 +412,78 @@ inline void DiscardOverlappingBlobs(std::vector<std::array<float, 3> >& blob_crd
   if (pReportProgress) *pReportProgress << "done.\n";
 }
 
+// ---- LabelConnected: lib/visfd/connect.hpp:47-65, :168-197 ------------------------------------------------
+// The form bin/filter_mrc/handlers.cpp:1985-2013 calls: Scalar = float, Label = ptrdiff_t, Coordinate = float,
+// directions as array<float,3>*** (contiguous, Alloc3D), tensors as one float* per voxel (nullptr = no storage,
+// e.g. CompactMultiChannelImage3D::aaaafI).  Must-link constraints and voxel weights are not provided.
+typedef enum eRegionSortCriteria { SORT_BY_VALUE, SORT_BY_SIZE } RegionSortCriteria;
+typedef enum eDirectionPairType { SAME_DIRECTION, OPPOSITE_DIRECTION, AUTO } DirectionPairType;
+
+inline size_t LabelConnected(
+    const int image_size[3], float const* const* const* aaafSaliency, ptrdiff_t*** aaaiDest,
+    float const* const* const* aaafMask,
+    float threshold_saliency = -std::numeric_limits<float>::infinity(),
+    std::array<float, 3> const* const* const* aaaafVector = nullptr,
+    float threshold_vector_saliency = -std::numeric_limits<float>::infinity(),
+    float threshold_vector_neighbor = -std::numeric_limits<float>::infinity(), bool consider_dot_product_sign = true,
+    float* const* const* const* aaaafSymmetricTensor = nullptr,
+    float threshold_tensor_saliency = -std::numeric_limits<float>::infinity(),
+    float threshold_tensor_neighbor = -std::numeric_limits<float>::infinity(),
+    bool tensor_is_positive_definite_near_target = true, int connectivity = 1, ptrdiff_t label_undefined = -1,
+    std::vector<std::array<float, 3> >* pv_cluster_maxima = nullptr, std::vector<float>* pv_cluster_sizes = nullptr,
+    std::vector<float>* pv_cluster_saliencies = nullptr, RegionSortCriteria sort_criteria = SORT_BY_SIZE,
+    float const* const* const* aaafVoxelWeights = nullptr, std::array<float, 3>*** aaaafVectorStandardized = nullptr,
+    const std::vector<std::vector<std::array<float, 3> > >* pMustLinkConstraints = nullptr,
+    const std::vector<std::vector<DirectionPairType> >* pMustLinkDirections = nullptr,
+    bool start_from_saliency_maxima = true, std::ostream* pReportProgress = nullptr) {
+  static_assert(sizeof(ptrdiff_t) == sizeof(int64_t), "labels travel as 64-bit integers");
+  if (aaafVoxelWeights || pMustLinkConstraints || pMustLinkDirections)
+    throw VisfdErr("visfd_hip: LabelConnected does not provide voxel weights or must-link constraints");
+  hip_detail::require_contiguous(aaafSaliency, image_size);
+  const size_t n = (size_t)image_size[0] * image_size[1] * image_size[2];
+  // directions: the standardized output array if one is given (it starts as a copy of the input), else a copy
+  std::vector<float> dir_copy;
+  float* dir = nullptr;
+  if (aaaafVector) {
+    const float* in = reinterpret_cast<const float*>(&aaaafVector[0][0][0]);
+    if (aaaafVectorStandardized) {
+      dir = reinterpret_cast<float*>(&aaaafVectorStandardized[0][0][0]);
+      if (dir != in) for (size_t i = 0; i < 3 * n; i++) dir[i] = in[i];
+    } else {
+      dir_copy.assign(in, in + 3 * n);
+      dir = dir_copy.data();
+    }
+  }
+  std::vector<float> ten;
+  if (aaaafSymmetricTensor) {
+    ten.assign(6 * n, 0.0f);
+    size_t v = 0;
+    for (int iz = 0; iz < image_size[2]; iz++)
+      for (int iy = 0; iy < image_size[1]; iy++)
+        for (int ix = 0; ix < image_size[0]; ix++, v++)
+          if (aaaafSymmetricTensor[iz][iy][ix])
+            for (int c = 0; c < 6; c++) ten[6 * v + c] = aaaafSymmetricTensor[iz][iy][ix][c];
+  }
+  std::vector<float> cm(pv_cluster_maxima ? 3 * n : 0), cs(pv_cluster_sizes ? n : 0), csal(pv_cluster_saliencies ? n : 0);
+  int64_t n_clusters = 0;
+  hip_detail::check(visfd_hip_label_connected(
+      hip_detail::flat(aaafSaliency), reinterpret_cast<int64_t*>(&aaaiDest[0][0][0]), hip_detail::flat(aaafMask),
+      image_size[0], image_size[1], image_size[2], threshold_saliency, dir, threshold_vector_saliency,
+      threshold_vector_neighbor, consider_dot_product_sign ? 1 : 0, aaaafSymmetricTensor ? ten.data() : nullptr,
+      threshold_tensor_saliency, threshold_tensor_neighbor, tensor_is_positive_definite_near_target ? 1 : 0, connectivity,
+      (int64_t)label_undefined, sort_criteria == SORT_BY_SIZE ? 1 : 0, aaaafVectorStandardized ? 1 : 0,
+      start_from_saliency_maxima ? 1 : 0, &n_clusters, cm.empty() ? nullptr : cm.data(), cs.empty() ? nullptr : cs.data(),
+      csal.empty() ? nullptr : csal.data(), (int64_t)n));
+  if (pReportProgress) *pReportProgress << "Number of clusters found: " << n_clusters << "\n";
+  if (pv_cluster_maxima) {
+    pv_cluster_maxima->resize((size_t)n_clusters);
+    for (int64_t k = 0; k < n_clusters; k++) (*pv_cluster_maxima)[(size_t)k] = {{cm[3 * k], cm[3 * k + 1], cm[3 * k + 2]}};
+  }
+  if (pv_cluster_sizes) pv_cluster_sizes->assign(cs.begin(), cs.begin() + n_clusters);
+  if (pv_cluster_saliencies) pv_cluster_saliencies->assign(csal.begin(), csal.begin() + n_clusters);
+  return (size_t)n_clusters;
+}
+
 // ---- eigenvalue order: lib/visfd/eigen3_simple.hpp:36-43 ------------------------------------------------
 namespace selfadjoint_eigen3 {
 typedef enum eEigenOrderType {

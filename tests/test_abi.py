@@ -63,3 +63,19 @@ def test_no_cpu_fallback(lib):
         pytest.skip("GPU present")
     with pytest.raises(lib.VisfdHipError):
         lib.Context(0)
+
+
+def test_cpp_shim_compiles_and_runs_host_entry_points(lib, tmp_path):
+    """include/visfd_hip.hpp under g++ -std=c++11 -Wall -Werror, linked against the library; the program exercises
+    the reference-signature wrappers of the host-side rows (LabelConnected, blob list post-processing)."""
+    import subprocess
+    exe = str(tmp_path / "shim_host_check")
+    libdir = os.path.dirname(lib.LIB_PATH)
+    cmd = ["g++", "-std=c++11", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "shim_host_check.cpp"), "-L" + libdir, "-lvisfd_hip", "-Wl,-rpath," + libdir,
+           "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "clusters 2 sizes 270 108 undefined 702" in r.stdout and "blobs kept 2" in r.stdout
