@@ -148,12 +148,16 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
   // list entry e (32 bytes): float4 {sal, n0, n1, n2} | int e16 | float mask value | pad.
   // Entry CAP is a permanent dummy (zero saliency and normal): lanes that have run out of hits vote
   // it, which adds +-0 to their accumulators and leaves them bit-for-bit unchanged.
-  __shared__ __attribute__((aligned(16))) unsigned char l_ent[ENT_BYTES * (CAP + 1)];
+  // (one static block with the entry list first: its LDS address is then 0 and drops out of the vote loop's
+  // address arithmetic)
+  constexpr int OFF_POS = ENT_BYTES * (CAP + 1), OFF_HITW = OFF_POS + 4 * CAP, OFF_TOT = OFF_HITW + 4 * (NWORDS + 1) * NT;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_static[OFF_TOT + 2 * (NT / 64) * 4];
+  unsigned char* l_ent = lds_static;
   // distance-test operand of the listed senders (see phase A): packed signed bytes
   // (e'x, e'y, -(|e'|^2 >> 7), |e'|^2 & 127) with e' = sender position relative to the tile centre
-  __shared__ __attribute__((aligned(16))) unsigned l_pos[CAP];
-  __shared__ __attribute__((aligned(16))) unsigned char hitw[4 * (NWORDS + 1) * NT];  // [NWORDS + sentinel][NT]
-  __shared__ int wave_tot[2][NT / 64];
+  unsigned* l_pos = reinterpret_cast<unsigned*>(lds_static + OFF_POS);
+  unsigned char* hitw = lds_static + OFF_HITW;                                    // [NWORDS + sentinel][NT]
+  int (*wave_tot)[NT / 64] = reinterpret_cast<int (*)[NT / 64]>(lds_static + OFF_TOT);
   // dynamic LDS: the table slices of the current plane group, [group][(2h+1)^2] float4
   extern __shared__ __attribute__((aligned(16))) unsigned char slices[];
 
