@@ -17,6 +17,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def built_library():
+    """The tests call the product through visfd_amd/libvisfd_hip.so; build it (hipcc cross-compiles without a GPU)
+    when a fresh checkout has not run `python -m visfd_amd.build` / __graft_entry__.build() yet."""
+    from visfd_amd import api
+    if not os.path.exists(api.LIB_PATH):
+        from visfd_amd import build
+        build.build(verbose=False)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU restatement (oracle/libvisfd_oracle.so); built on demand with g++."""
