@@ -54,7 +54,11 @@ def test_cli_config1_gauss(cli, tmp_path):
     r = run(cli, "-in", os.path.join(GOLDEN, "test_blob_detect.rec"), "-mask",
             os.path.join(GOLDEN, "test_blob_detect_mask.rec"), "-out", out, "-gauss", 2, "-w", 1)
     assert r.returncode == 0, r.stderr
-    assert_bits_equal(volgen.read_mrc(str(out)), golden("gauss_blobrec")["out_masked"], "CLI masked gauss")
+    # library result inside the mask; outside it the program writes the "masked" brightness 0 (filter_mrc.cpp:765-776)
+    got, want = volgen.read_mrc(str(out)), golden("gauss_blobrec")["out_masked"].copy()
+    m = volgen.read_mrc(os.path.join(GOLDEN, "test_blob_detect_mask.rec"))
+    want[m == 0] = 0.0
+    assert_bits_equal(got, want, "CLI masked gauss")
 
 
 @pytest.mark.gpu
@@ -193,3 +197,83 @@ def test_cli_membrane_clustering_reference_scenario(cli, tmp_path):
     r = run(cli, *common[:4], "-out", out2, *common[6:], "-connect", 1e9, "-connect-angle", 30)
     assert r.returncode == 0, r.stderr
     assert_bits_equal(volgen.read_mrc(str(out2)), lab, "clustering after -load-progress == clustering in one run")
+
+
+# ------------------------------------------------------------------------------------------ against the reference's own program
+REF_CLI = os.path.join(ROOT, "oracle", "_ref", "filter_mrc_ref")
+
+
+@pytest.fixture(scope="module")
+def ref_cli():
+    """The reference's filter_mrc, compiled by `make -C oracle ref_cli` from its sources (CPU, OpenMP)."""
+    if not os.path.exists(REF_CLI):
+        pytest.skip("oracle/_ref/filter_mrc_ref not built (needs /root/reference)")
+    return REF_CLI
+
+
+def both(cli, ref_cli, tmp_path, args, out_name="out.rec"):
+    """Runs the same command line through both programs in separate directories; returns the two directories."""
+    dirs = []
+    for tag, exe in (("mine", cli), ("ref", ref_cli)):
+        d = tmp_path / tag
+        d.mkdir(exist_ok=True)
+        r = subprocess.run([exe] + [str(a) for a in args] + ["-out", out_name], cwd=str(d), capture_output=True, text=True)
+        assert r.returncode == 0, (tag, r.stderr[-2000:])
+        dirs.append(d)
+    return dirs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [
+    ["-gauss", 40, "-w", 19.6],
+    ["-gauss-aniso", 30, 45, 25, "-w", 19.6],
+    ["-gauss", 2, "-w", 1, "-mask", os.path.join(GOLDEN, "test_blob_detect_mask.rec")],
+    ["-dog", 30, 48, "-w", 19.6],
+    ["-log-d", 120, "-w", 19.6, "-mask", os.path.join(GOLDEN, "test_blob_detect_mask.rec")],
+    ["-gauss", 60, "-w", 19.6, "-bin", 2],
+])
+def test_cli_filters_equal_reference_program(cli, ref_cli, tmp_path, flags):
+    mine, ref = both(cli, ref_cli, tmp_path, ["-in", os.path.join(GOLDEN, "test_blob_detect.rec")] + flags)
+    assert_bits_equal(volgen.read_mrc(str(mine / "out.rec")), volgen.read_mrc(str(ref / "out.rec")), " ".join(map(str, flags)))
+
+
+@pytest.mark.gpu
+def test_cli_blob_files_equal_reference_program(cli, ref_cli, tmp_path):
+    """-blob minima/maxima list files and the -discard-blobs result, text for text."""
+    common = ["-w", 19.6, "-mask", os.path.join(GOLDEN, "test_blob_detect_mask.rec"), "-in", os.path.join(GOLDEN, "test_blob_detect.rec")]
+    outs = {}
+    for tag, exe in (("mine", cli), ("ref", ref_cli)):
+        d = tmp_path / tag
+        d.mkdir()
+        for args in (["-blob", "minima", "mins.txt", 160.0, 280.0, 1.01],
+                     ["-blob", "all", "both", 150.0, 300.0, 1.05],
+                     ["-discard-blobs", "mins.txt", "kept.txt", "-blob-separation", 1.1, "-minima-threshold", -90]):
+            r = subprocess.run([exe] + [str(a) for a in common + args], cwd=str(d), capture_output=True, text=True)
+            assert r.returncode == 0, (tag, args, r.stderr[-2000:])
+        outs[tag] = {f: open(d / f).read() for f in sorted(os.listdir(d)) if f.endswith(".txt")}
+    assert sorted(outs["mine"]) == sorted(outs["ref"]), (sorted(outs["mine"]), sorted(outs["ref"]))
+    for f in outs["ref"]:
+        assert outs["mine"][f] == outs["ref"][f], f
+    assert len(outs["ref"]["kept.txt"].strip().split("\n")) == 2
+
+
+@pytest.mark.gpu
+def test_cli_membrane_scenario_equals_reference_program(cli, ref_cli, tmp_path):
+    """Both commands of tests/test_membrane_detection.sh through both programs: the six vote-tensor files and the
+    post-vote saliency agree to 1e-5 (the senders' directions come from the device's fp64 eigen solver, equal to
+    glibc's to ~1e-7), and the cluster labels -- computed from the SAME tensor files -- are identical."""
+    inp = os.path.join(GOLDEN, "test_image_membrane.rec")
+    base = ["-w", 19.2, "-in", inp, "-membrane", "minima", 55, "-tv", 4, "-tv-angle-exponent", 4, "-bin", 2]
+    mine, ref = both(cli, ref_cli, tmp_path, base + ["-save-progress", "prog"], "sal.rec")
+    for c in range(6):
+        assert_close_rel(volgen.read_mrc(str(mine / ("prog_tensor_%d.rec" % c))),
+                         volgen.read_mrc(str(ref / ("prog_tensor_%d.rec" % c))), 1e-5, "vote tensor channel %d" % c)
+    assert_close_rel(volgen.read_mrc(str(mine / "sal.rec")), volgen.read_mrc(str(ref / "sal.rec")), 1e-5, "post-vote saliency")
+    for c in range(6):   # cluster from identical inputs: the reference's tensor files
+        os.replace(str(ref / ("prog_tensor_%d.rec" % c)), str(mine / ("prog_tensor_%d.rec" % c)))
+        import shutil
+        shutil.copy(str(mine / ("prog_tensor_%d.rec" % c)), str(ref / ("prog_tensor_%d.rec" % c)))
+    mine, ref = both(cli, ref_cli, tmp_path, base + ["-load-progress", "prog", "-connect", 1e9, "-connect-angle", 30], "labels.rec")
+    a, b = volgen.read_mrc(str(mine / "labels.rec")), volgen.read_mrc(str(ref / "labels.rec"))
+    assert_bits_equal(a, b, "cluster labels")
+    assert int(((b > 0.99) & (b < 1.01)).sum()) == 69

@@ -138,6 +138,7 @@ struct Settings {
   float voxel_width = -1;
   int bin = 0;                 // settings.cpp:48-49: 0 = not specified (automatic), else the factor
   bool bin_explicit = false;
+  float masked_voxel_brightness = 0.0f;   // settings.cpp:41-42: voxels with mask == 0 get this value in the output
   enum { NONE, GAUSS, DOG, LOG, BLOB, BLOB_NONMAX, SURFACE_RIDGE } type = NONE;
   float width_a[3] = {0, 0, 0}, width_b[3] = {0, 0, 0}, log_width[3] = {0, 0, 0};
   float truncate_ratio = -1.0f, truncate_threshold = 0.03f;   // settings.cpp:81,88
@@ -188,6 +189,7 @@ Settings parse(int argc, char** argv) {
     else if (f == "-out" || f == "-o") { need(1); s.out = v[i + 1]; i += 2; }
     else if (f == "-mask") { need(1); s.mask = v[i + 1]; i += 2; }
     else if (f == "-w") { need(1); s.voxel_width = num(v, i + 1, f); i += 2; }
+    else if (f == "-mask-out") { need(1); s.masked_voxel_brightness = num(v, i + 1, f); i += 2; }   // settings.cpp:662-674
     else if (f == "-np") { need(1); i += 2; }  // host threads: not used by the GPU path
     else if (f == "-bin") {
       need(1);
@@ -625,6 +627,14 @@ int main(int argc, char** argv) {
       std::memcpy(tomo_out.raw_header, tomo_in.raw_header, 1024);
       unbin_image(tomo_out, size_orig, cella_orig);
       unbin_image(tomo_in, size_orig, cella_orig);   // only its header/size is used below
+      if (mask.loaded) unbin_image(mask, size_orig, cella_orig);
+    }
+    // filter_mrc.cpp:765-776: after everything else, voxels outside the mask take the "masked" brightness
+    if (mask.loaded && s.type != Settings::BLOB && s.type != Settings::BLOB_NONMAX) {
+      float* o = tomo_out.data();
+      const float* mp = mask.data();
+      for (size_t i = 0; i < tomo_out.nvox(); i++)
+        if (mp[i] == 0.0f) o[i] = s.masked_voxel_brightness;
     }
     if (!s.out.empty()) {
       cerr << "writing tomogram (in 32-bit float mode)\n";
