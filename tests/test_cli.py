@@ -277,3 +277,28 @@ def test_cli_membrane_scenario_equals_reference_program(cli, ref_cli, tmp_path):
     a, b = volgen.read_mrc(str(mine / "labels.rec")), volgen.read_mrc(str(ref / "labels.rec"))
     assert_bits_equal(a, b, "cluster labels")
     assert int(((b > 0.99) & (b < 1.01)).sum()) == 69
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags,exact", [
+    (["-membrane", "minima", 55, "-tv", 4, "-tv-angle-exponent", 4, "-bin", 1], False),
+    (["-membrane", "maxima", 55, "-tv", 3, "-tv-angle-exponent", 2, "-bin", 1, "-tv-best", 0.2], False),
+    (["-membrane", "minima", 45, "-bin", 1], False),                                   # ridge saliency only, no voting
+    (["-membrane", "minima", 55, "-tv", 4, "-bin", 1, "-detection-threshold", 2000.0], False),
+    (["-membrane", "minima", 90, "-tv", 3], False),                                    # sigma > 1.8 voxels: automatic binning + un-binning
+    (["-membrane", "minima", 55, "-tv", 4, "-bin", 1, "-truncate", 2.0, "-tv-truncate-ratio", 1.2], False),
+    (["-log-d", 60, "-dog-delta", 0.05, "-truncate-threshold", 0.01], True),
+    (["-gauss", 30, "-normalize-filters", "no"], True),
+])
+def test_cli_membrane_and_options_equal_reference_program(cli, ref_cli, tmp_path, flags, exact):
+    """More of the command line against the reference's own program on its 16^3 membrane fixture: eigen-derived
+    outputs to 1e-5 (relative to the volume's scale), pure filters bit for bit."""
+    inp = os.path.join(GOLDEN, "test_image_membrane.rec")
+    mine, ref = both(cli, ref_cli, tmp_path, ["-w", 19.2, "-in", inp] + flags)
+    a, b = volgen.read_mrc(str(mine / "out.rec")), volgen.read_mrc(str(ref / "out.rec"))
+    assert a.shape == b.shape
+    if exact:
+        assert_bits_equal(a, b, " ".join(map(str, flags)))
+    else:
+        assert np.abs(b).max() > 0
+        assert_close_rel(a, b, 1e-5, " ".join(map(str, flags)))

@@ -279,7 +279,7 @@ Settings parse(int argc, char** argv) {
     }
     else if (f == "-tv") { need(1); s.tv_sigma = num(v, i + 1, f); i += 2; }
     else if (f == "-tv-angle-exponent") { need(1); s.tv_exponent = (int)num(v, i + 1, f); i += 2; }
-    else if (f == "-tv-truncate") { need(1); s.tv_truncate = num(v, i + 1, f); i += 2; }
+    else if (f == "-tv-truncate-ratio") { need(1); s.tv_truncate = num(v, i + 1, f); i += 2; }   // settings.cpp:2931-2946
     else if (f == "-tv-best" || f == "-best") {
       need(1); s.hessian_thr = num(v, i + 1, f); s.hessian_thr_is_fraction = true;
       if (!(s.hessian_thr >= 0.0f && s.hessian_thr <= 1.0f)) throw VisfdErr("Error: -tv-best needs a number between 0 and 1.\n");
