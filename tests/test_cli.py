@@ -302,3 +302,50 @@ def test_cli_membrane_and_options_equal_reference_program(cli, ref_cli, tmp_path
     else:
         assert np.abs(b).max() > 0
         assert_close_rel(a, b, 1e-5, " ".join(map(str, flags)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [
+    ["-blob-s", "all", "b", 20.0, 48.0, 1.3, "-minima-threshold", -20, "-maxima-threshold", 20],
+    ["-blob-r", "maxima", "b.txt", 40.0, 80.0, 1.25],
+    ["-blob-s", "all", "b", 1.0, 2.4, 1.3],                      # scales far below a voxel: both lists empty
+    ["-blob", "minima", "b.txt", 60.0, 150.0, 1.2, "-dog-delta", 0.05, "-truncate-threshold", 0.02],
+])
+def test_cli_blob_variants_equal_reference_program(cli, ref_cli, tmp_path, flags):
+    """Blob detector spellings (-blob = diameters, -blob-s = sigmas, -blob-r = radii; minima / maxima / all) and
+    score thresholds on the small membrane fixture: list files identical text for text."""
+    inp = os.path.join(GOLDEN, "test_image_membrane.rec")
+    outs = {}
+    for tag, exe in (("mine", cli), ("ref", ref_cli)):
+        d = tmp_path / tag
+        d.mkdir()
+        r = subprocess.run([exe] + [str(a) for a in ["-w", 19.2, "-in", inp] + flags], cwd=str(d), capture_output=True, text=True)
+        assert r.returncode == 0, (tag, r.stderr[-2000:])
+        outs[tag] = {f: open(d / f).read() for f in sorted(os.listdir(d))}
+    assert sorted(outs["mine"]) == sorted(outs["ref"]) and outs["ref"], (sorted(outs["mine"]), sorted(outs["ref"]))
+    for f in outs["ref"]:
+        assert outs["mine"][f] == outs["ref"][f], f
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [
+    ["-connect", 1e9, "-connect-angle", 30, "-undefined-out", -3],
+    ["-connect", 5e8, "-connect-vector-saliency", 0.5, "-connect-vector-neighbor", 0.7, "-connect-tensor-saliency", 0.1,
+     "-connect-tensor-neighbor", 0.6],
+    ["-connect", 2e9],
+])
+def test_cli_clustering_options_equal_reference_program(cli, ref_cli, tmp_path, flags):
+    """Clustering of the SAME vote tensors (written once by the reference's -save-progress) with different
+    thresholds: label volumes identical."""
+    inp = os.path.join(GOLDEN, "test_image_membrane.rec")
+    base = ["-w", 19.2, "-in", inp, "-membrane", "minima", 55, "-tv", 4, "-tv-angle-exponent", 4, "-bin", 2]
+    import shutil
+    for tag in ("mine", "ref"):
+        (tmp_path / tag).mkdir()
+    r = subprocess.run([ref_cli] + [str(a) for a in base + ["-save-progress", "prog", "-out", "s.rec"]],
+                       cwd=str(tmp_path / "ref"), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for c in range(6):
+        shutil.copy(str(tmp_path / "ref" / ("prog_tensor_%d.rec" % c)), str(tmp_path / "mine" / ("prog_tensor_%d.rec" % c)))
+    mine, ref = both(cli, ref_cli, tmp_path, base + ["-load-progress", "prog"] + flags, "labels.rec")
+    assert_bits_equal(volgen.read_mrc(str(mine / "labels.rec")), volgen.read_mrc(str(ref / "labels.rec")), " ".join(map(str, flags)))

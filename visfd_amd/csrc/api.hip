@@ -427,12 +427,12 @@ int visfd_hip_blob_dog(visfd_hip_ctx* ctx, const float* src, const float* mask, 
 }
 
 int visfd_hip_blob_diameters_to_sigmas(const float* d, int n, float* s) {
-  VH_REQUIRE(d && s && n >= 0, "bad argument");
+  VH_REQUIRE(n >= 0 && (n == 0 || (d && s)), "bad argument");   // empty lists have no storage
   for (int i = 0; i < n; i++) s[i] = (float)(d[i] / (2.0 * std::sqrt(3.0)));  // feature.hpp:475
   return VISFD_HIP_OK;
 }
 int visfd_hip_blob_sigmas_to_diameters(const float* s, int n, float* d) {
-  VH_REQUIRE(d && s && n >= 0, "bad argument");
+  VH_REQUIRE(n >= 0 && (n == 0 || (d && s)), "bad argument");
   for (int i = 0; i < n; i++) d[i] = (float)(s[i] * 2.0 * std::sqrt(3.0));  // feature.hpp:504
   return VISFD_HIP_OK;
 }
