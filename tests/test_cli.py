@@ -349,3 +349,34 @@ def test_cli_clustering_options_equal_reference_program(cli, ref_cli, tmp_path, 
         shutil.copy(str(tmp_path / "ref" / ("prog_tensor_%d.rec" % c)), str(tmp_path / "mine" / ("prog_tensor_%d.rec" % c)))
     mine, ref = both(cli, ref_cli, tmp_path, base + ["-load-progress", "prog"] + flags, "labels.rec")
     assert_bits_equal(volgen.read_mrc(str(mine / "labels.rec")), volgen.read_mrc(str(ref / "labels.rec")), " ".join(map(str, flags)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,mode,imod_flags,use_w", [
+    ("a.mrc", 2, None, False),      # float, voxel width from the header's cell size
+    ("a.mrc", 0, None, True),       # bytes in .mrc: signed
+    ("a.rec", 0, None, True),       # bytes in .rec: unsigned (mrc_simple.cpp:186-192)
+    ("a.mrc", 0, 0, True),          # IMOD stamp, flag bit 0 clear: unsigned
+    ("a.mrc", 0, 1, True),          # IMOD stamp, flag bit 0 set: signed
+    ("a.mrc", 1, None, True),       # int16
+    ("a.mrc", 6, None, True),       # uint16
+])
+def test_cli_mrc_input_modes_equal_reference_program(cli, ref_cli, tmp_path, name, mode, imod_flags, use_w):
+    """The bulk MRC reader against the reference's one-voxel-at-a-time reader: every input mode and the signed-byte
+    rules, checked through a Gaussian of the decoded volume; and the output header's size, mode and cell."""
+    rng = np.random.default_rng(9)
+    lo, hi = {0: (-100, 100), 1: (-3000, 3000), 2: (-5, 5), 6: (0, 60000)}[mode]
+    if mode == 0 and (name.endswith(".rec") or imod_flags == 0):
+        lo, hi = 0, 250
+    vol = rng.uniform(lo, hi, (10, 12, 16))
+    vol = vol.astype(np.float32) if mode == 2 else np.round(vol)
+    inp = tmp_path / name
+    volgen.write_mrc(str(inp), vol, voxel_width=2.5, mode=mode, imod_flags=imod_flags)
+    flags = ["-in", inp, "-gauss", 4.0] + (["-w", 2.5] if use_w else [])
+    mine, ref = both(cli, ref_cli, tmp_path, flags)
+    assert_bits_equal(volgen.read_mrc(str(mine / "out.rec")), volgen.read_mrc(str(ref / "out.rec")), "%s mode %d" % (name, mode))
+    ha = np.frombuffer(open(mine / "out.rec", "rb").read(1024), "<i4")
+    hb = np.frombuffer(open(ref / "out.rec", "rb").read(1024), "<i4")
+    assert list(ha[0:4]) == list(hb[0:4])                                                     # nx, ny, nz, mode 2
+    assert np.allclose(ha.view("<f4")[10:13], hb.view("<f4")[10:13])                          # cell size
+    assert np.allclose(ha.view("<f4")[19:22], hb.view("<f4")[19:22], rtol=1e-5, atol=1e-4)    # dmin, dmax, dmean

@@ -130,21 +130,29 @@ def read_mrc(path):
     return np.ascontiguousarray(a.reshape(nz, ny, nx).astype(np.float32))
 
 
-def write_mrc(path, vol, voxel_width=1.0):
-    vol = np.ascontiguousarray(vol, np.float32)
+def write_mrc(path, vol, voxel_width=1.0, mode=2, imod_flags=None):
+    """Writes a minimal MRC2014 file.  mode 2: float32; 0: bytes (signed unless the IMOD stamp + flag bit 0 say
+    otherwise or the name ends in .rec -- the reference's rules); 1: int16; 6: uint16."""
     nz, ny, nx = vol.shape
+    dt = {0: "i1", 1: "<i2", 2: "<f4", 6: "<u2"}[mode]
+    if mode == 0 and (path.endswith(".rec") or (imod_flags is not None and not (imod_flags & 1))):
+        dt = "u1"
+    data = np.ascontiguousarray(vol).astype(dt)
     h = np.zeros(256, "<i4")
     h[0:3] = (nx, ny, nz)
-    h[3] = 2
+    h[3] = mode
     h[7:10] = (nx, ny, nz)
     hf = h.view("<f4")
     hf[10:13] = (nx * voxel_width, ny * voxel_width, nz * voxel_width)
     hf[13:16] = 90.0
     h[16:19] = (1, 2, 3)
-    hf[19:22] = (float(vol.min()), float(vol.max()), float(vol.mean()))
+    hf[19:22] = (float(data.min()), float(data.max()), float(data.astype(np.float64).mean()))
+    if imod_flags is not None:
+        h[38] = 1146047817   # "IMOD"
+        h[39] = imod_flags
     raw = bytearray(h.tobytes())
     raw[208:212] = b"MAP "
     raw[212:216] = bytes([0x44, 0x44, 0, 0])
     with open(path, "wb") as f:
         f.write(bytes(raw))
-        f.write(vol.tobytes())
+        f.write(data.tobytes())
