@@ -209,6 +209,21 @@ int visfd_hip_principal_directions_host(const float* tensor, const float* mask, 
 int visfd_hip_tensor_saliency_host(const float* tensor, const float* mask, int64_t nvox, int order,
                                    float* saliency);
 
+/* DiagonalizeSym3<float> (lib/visfd/eigen3_simple.hpp:137-266) on the host: m9 = symmetric 3x3, row-major;
+ * eivects9 = eigenvectors as rows; order 0..3 = INCREASING, DECREASING, INCREASING_ABS, DECREASING_ABS_EIVALS. */
+int visfd_hip_diagonalize_sym3_f32_host(const float* m9, int order, float* eivals3, float* eivects9);
+/* The oriented point cloud of a clustered surface (the -normals-file tail of HandleTV,
+ * bin/filter_mrc/handlers.cpp:2039-2309), host-side.  voxel2cluster = the label volume as floats (what HandleTV
+ * writes to its output image; NULL: export every unmasked voxel unchanged), direction = [nz][ny][nx][3]
+ * (standardized), select_cluster = the label to export, curve_ds / find_ridge / max_distance_to_feature = the
+ * reference's settings (defaults 0.2, 1, 1.3 voxels; settings.cpp:147-149).  crds/norms receive n_points x 3
+ * floats each (capacity points; pass NULL pointers to only count). */
+int visfd_hip_surface_points(const float* saliency, const float* voxel2cluster, const float* direction,
+                             const float* mask, int64_t nx, int64_t ny, int64_t nz, int select_cluster,
+                             const float voxel_width[3], float curve_ds, int find_ridge,
+                             float max_distance_to_feature, float* crds, float* norms, int64_t capacity,
+                             int64_t* n_points);
+
 /* ---- f4: BinArray3D / UnbinArray3D, lib/visfd/resample.hpp:53-166 -------------------------------------
  * Sizes are {nx, ny, nz}.  bin[d] = floor(size_big[d] / size_small[d]); `offset` (nullable) shifts the
  * binning window and must satisfy 0 <= offset[d] < bin[d] (VISFD_HIP_EINVAL otherwise, where the

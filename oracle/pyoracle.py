@@ -74,6 +74,7 @@ class CpuLib:
                                                 C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp,
                                                 C.c_int64]),
                 "trace_product_sym3": (C.c_float, [_fp, _fp]),
+                "diagonalize_sym3_f32": (None, [_fp, C.c_int, _fp, _fp]),
                 "sphere_overlap": (C.c_float, [C.c_float, C.c_float, C.c_float]),
                 "sort_blobs": (None, [_fp, _fp, _fp, C.c_int64, C.c_int, C.c_int, _up]),
                 "discard_masked_blobs": (C.c_int64, [_fp, _fp, _fp, C.c_int64, _fp, C.c_int, C.c_int, C.c_int]),
@@ -247,6 +248,15 @@ class CpuLib:
             int(bool(sort_by_size)), int(bool(standardize_directions)), int(bool(start_from_saliency_maxima)),
             _f(cm), _f(cs), _f(csal), cap)
         return labels, int(k), cm[:k], cs[:k], csal[:k]
+
+    def diagonalize_sym3_f32(self, m, order):
+        m = np.ascontiguousarray(m, np.float32)
+        vals = np.empty(m.shape[:-2] + (3,), np.float32)
+        vecs = np.empty(m.shape, np.float32)
+        mf, vf, ef = m.reshape(-1, 9), vals.reshape(-1, 3), vecs.reshape(-1, 9)
+        for i in range(len(mf)):
+            self._fn["diagonalize_sym3_f32"](_f(mf[i]), int(order), _f(vf[i]), _f(ef[i]))
+        return vals, vecs
 
     def trace_product_sym3(self, a, b):
         return float(self._fn["trace_product_sym3"](_f(np.ascontiguousarray(a, np.float32)),

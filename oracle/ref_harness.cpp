@@ -394,6 +394,14 @@ int64_t vr_label_connected(const float* saliency, int64_t* labels, const float* 
 // lin3_utils.hpp:502-529 as compiled (see visfd_amd/csrc/connect.cpp)
 float vr_trace_product_sym3(const float* a, const float* b) { return TraceProductSym3(a, b); }
 
-int vr_version() { return 4; }
+// eigen3_simple.hpp:137-266 instantiated for float (the form bin/filter_mrc/handlers.cpp:2249-2252 uses)
+void vr_diagonalize_sym3_f32(const float* m9, int order, float* eivals3, float* eivects9) {
+  float M[3][3], E[3][3];
+  for (int i = 0; i < 9; i++) M[i / 3][i % 3] = m9[i];
+  selfadjoint_eigen3::DiagonalizeSym3(M, eivals3, E, (selfadjoint_eigen3::EigenOrderType)order);
+  for (int i = 0; i < 9; i++) eivects9[i] = E[i / 3][i % 3];
+}
+
+int vr_version() { return 5; }
 
 }  // extern "C"

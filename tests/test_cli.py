@@ -380,3 +380,42 @@ def test_cli_mrc_input_modes_equal_reference_program(cli, ref_cli, tmp_path, nam
     assert list(ha[0:4]) == list(hb[0:4])                                                     # nx, ny, nz, mode 2
     assert np.allclose(ha.view("<f4")[10:13], hb.view("<f4")[10:13])                          # cell size
     assert np.allclose(ha.view("<f4")[19:22], hb.view("<f4")[19:22], rtol=1e-5, atol=1e-4)    # dmin, dmax, dmean
+
+
+def _cluster_and_normals(cli, ref_cli, tmp_path, bin_flag, extra=()):
+    """The reference program writes the vote tensors once; both programs then cluster them and export the oriented
+    point cloud of cluster 1.  Returns (labels mine, labels ref, ply mine, ply ref)."""
+    import shutil
+    inp = os.path.join(GOLDEN, "test_image_membrane.rec")
+    base = ["-w", 19.2, "-in", inp, "-membrane", "minima", 55, "-tv", 4, "-tv-angle-exponent", 4, "-bin", bin_flag]
+    for tag in ("mine", "ref"):
+        (tmp_path / tag).mkdir()
+    r = subprocess.run([ref_cli] + [str(a) for a in base + ["-save-progress", "prog", "-out", "s.rec"]],
+                       cwd=str(tmp_path / "ref"), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for c in range(6):
+        shutil.copy(str(tmp_path / "ref" / ("prog_tensor_%d.rec" % c)), str(tmp_path / "mine" / ("prog_tensor_%d.rec" % c)))
+    mine, ref = both(cli, ref_cli, tmp_path, base + ["-load-progress", "prog", "-connect", 1e9, "-connect-angle", 30,
+                                                     "-normals-file", "n.ply", "-select-cluster", 1] + list(extra), "labels.rec")
+    return (volgen.read_mrc(str(mine / "labels.rec")), volgen.read_mrc(str(ref / "labels.rec")),
+            open(mine / "n.ply").read(), open(ref / "n.ply").read())
+
+
+@pytest.mark.parametrize("extra", [(), ("-max-voxels-to-feature", 0.6), ("-max-distance-to-feature", "inf")])
+def test_cli_clustering_and_normals_host_path_equal_reference_program(cli, ref_cli, tmp_path, extra):
+    """-load-progress ... -connect ... -normals-file with -bin 1 needs no GPU at all (tensor files in, host-side
+    clustering and surface-point export): label volume identical and PLY file identical text for text."""
+    a, b, pa, pb = _cluster_and_normals(cli, ref_cli, tmp_path, 1, extra)
+    assert_bits_equal(a, b, "cluster labels")
+    assert pa == pb
+    assert int(pb.split("element vertex ")[1].split()[0]) > 20
+
+
+@pytest.mark.gpu
+def test_cli_normals_file_reference_scenario(cli, ref_cli, tmp_path):
+    """The second command of tests/test_membrane_detection.sh including -normals-file: 58 vertices,
+    file identical to the reference program's."""
+    a, b, pa, pb = _cluster_and_normals(cli, ref_cli, tmp_path, 2)
+    assert_bits_equal(a, b, "cluster labels")
+    assert "element vertex 58" in pb
+    assert pa == pb

@@ -126,3 +126,26 @@ def test_label_connected_argument_checks():
     s = np.zeros((2, 8, 8), np.float32)
     with pytest.raises(api.VisfdHipError):
         api.label_connected(s, 0.0)
+
+
+def test_diagonalize_sym3_float_equals_reference(ref):
+    """The float instantiation of the 3x3 eigen solver (used by the surface-point export) against the compiled
+    reference, bit for bit, for every eigenvalue order, on general, diagonal, degenerate and tiny/huge matrices."""
+    rng = np.random.default_rng(8)
+    a = rng.normal(0, 3, (3000, 3, 3)).astype(np.float32)
+    m = ((a + np.swapaxes(a, 1, 2)) / 2).astype(np.float32)
+    m[:40] *= np.float32(1e-12)
+    m[40:80] *= np.float32(1e12)
+    for k in range(80, 120):
+        m[k] = np.diag(rng.normal(0, 2, 3)).astype(np.float32)
+    m[120:130] = 0
+    for k in range(130, 140):
+        m[k] = np.eye(3, dtype=np.float32) * np.float32(rng.normal())
+    v = rng.normal(size=(20, 3)).astype(np.float32)
+    for k in range(20):
+        m[140 + k] = np.outer(v[k], v[k]).astype(np.float32)      # rank one: two equal eigenvalues
+    for order in range(4):
+        gv, ge = api.diagonalize_sym3_f32_host(m, order)
+        wv, we = ref.diagonalize_sym3_f32(m, order)
+        assert np.array_equal(gv.view(np.uint32), wv.view(np.uint32)), "eigenvalues, order %d" % order
+        assert np.array_equal(ge.view(np.uint32), we.view(np.uint32)), "eigenvectors, order %d" % order

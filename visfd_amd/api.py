@@ -103,6 +103,9 @@ _SIGS = {
                                             C.POINTER(_i64), _vp, _vp, _vp, _i64]),
     "visfd_hip_principal_directions_host": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp]),
     "visfd_hip_tensor_saliency_host": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp]),
+    "visfd_hip_diagonalize_sym3_f32_host": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "visfd_hip_surface_points": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, C.c_int, _fp, C.c_float, C.c_int, C.c_float,
+                                           _vp, _vp, _i64, C.POINTER(_i64)]),
     "visfd_hip_sphere_overlap": (C.c_float, [C.c_float, C.c_float, C.c_float]),
     "visfd_hip_sort_blobs": (C.c_int, [_fp, _fp, _fp, _i64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
     "visfd_hip_discard_masked_blobs": (C.c_int, [_fp, _fp, _fp, C.POINTER(_i64), _vp, _i64, _i64, _i64]),
@@ -239,6 +242,18 @@ def tensor_saliency_host(tensor, order, sal_inout, mask=None):
     _chk_host(L, L.visfd_hip_tensor_saliency_host(_np(tensor), _np(mask), int(tensor.size // 6), int(order),
                                                   _np(sal_inout)))
     return sal_inout
+
+
+def diagonalize_sym3_f32_host(m, order):
+    """DiagonalizeSym3<float> (eigen3_simple.hpp:137-266) of m [..., 3, 3] -> (eivals [..., 3], eivects [..., 3, 3] rows)."""
+    L = load_library()
+    m = np.ascontiguousarray(m, np.float32)
+    vals = np.empty(m.shape[:-2] + (3,), np.float32)
+    vecs = np.empty(m.shape, np.float32)
+    mf, vf, ef = m.reshape(-1, 9), vals.reshape(-1, 3), vecs.reshape(-1, 9)
+    for i in range(len(mf)):
+        _chk_host(L, L.visfd_hip_diagonalize_sym3_f32_host(mf[i].ctypes.data, int(order), vf[i].ctypes.data, ef[i].ctypes.data))
+    return vals, vecs
 
 
 def principal_directions_host(tensor, order, mask=None):

@@ -162,6 +162,11 @@ struct Settings {
   float connect_threshold_vector_neighbor = (float)std::cos(M_PI * 15 / 180.0);
   float connect_threshold_tensor_saliency = (float)std::cos(M_PI * 15 / 180.0);
   float connect_threshold_tensor_neighbor = (float)std::cos(M_PI * 15 / 180.0);
+  string out_normals_file;                                    // -normals-file (settings.cpp:2965-2979)
+  int select_cluster = 0;                                     // settings.cpp:168
+  float max_distance_to_feature = 1.3f;                       // settings.cpp:147 (voxels; negative: physical units)
+  float surface_normal_curve_ds = 0.2f;                       // settings.cpp:148
+  bool surface_find_ridge = true;                             // settings.cpp:149
   bool undefined_voxels_are_max = true;                       // settings.cpp:43-44
   float undefined_voxel_brightness = -1.0f;
   string load_base;
@@ -309,7 +314,24 @@ Settings parse(int argc, char** argv) {
       else { s.undefined_voxels_are_max = false; s.undefined_voxel_brightness = num(v, i + 1, f); }
       i += 2;
     }
-    else if (f == "-select-cluster") { need(1); i += 2; }   // only selects what -normals-file writes (not provided)
+    else if (f == "-select-cluster") {                                                     // settings.cpp:3163-3182
+      need(1); s.select_cluster = (int)num(v, i + 1, f); s.cluster_connected_voxels = true;
+      if (s.select_cluster < 0) throw VisfdErr("Error: The " + f + " argument must be followed by a positive integer.\n");
+      i += 2;
+    }
+    else if (f == "-normals-file" || f == "-surface-normals-file") { need(1); s.out_normals_file = v[i + 1]; i += 2; }
+    else if (f == "-max-voxels-to-feature" || f == "-max-voxels-to-surface" || f == "-max-voxels-to-membrane") {   // settings.cpp:2983-3005
+      need(1);
+      const string a = v[i + 1];
+      s.max_distance_to_feature = (a == "inf" || a == "infinity" || a == "disable") ? 0.0f : num(v, i + 1, f);
+      i += 2;
+    }
+    else if (f == "-max-distance-to-feature" || f == "-max-distance-to-surface" || f == "-max-distance-to-membrane") {   // :3010-3032
+      need(1);
+      const string a = v[i + 1];
+      s.max_distance_to_feature = (a == "inf" || a == "infinity" || a == "disable") ? 0.0f : -num(v, i + 1, f);
+      i += 2;
+    }
     else throw VisfdErr("Error: Unrecognized (or unsupported on the GPU hot path) argument: \"" + f + "\"\n");
   }
   if (s.in.empty()) throw VisfdErr("Error: You must specify an input file (-in).\n");
@@ -318,6 +340,8 @@ Settings parse(int argc, char** argv) {
     throw VisfdErr("Error: this build clusters voxels (-connect) only after \"-membrane ... -tv ...\".\n");
   if (s.cluster_connected_voxels && s.connect_threshold_saliency == std::numeric_limits<float>::infinity())
     throw VisfdErr("Error: clustering needs a saliency threshold (-connect THRESHOLD).\n");
+  if (!s.out_normals_file.empty() && !s.cluster_connected_voxels)
+    throw VisfdErr("Error: this build writes surface normals (-normals-file) for a clustered surface only (-connect).\n");
   if ((s.cluster_connected_voxels || !s.load_base.empty()) && !(s.tv_sigma > 0))
     throw VisfdErr("Error: -connect and -load-progress need tensor voting (-tv).\n");
   return s;
@@ -615,10 +639,33 @@ int main(int argc, char** argv) {
         int64_t max_label = labels[0];
         for (size_t i = 0; i < n; i++)
           if (!mptr || mptr[i] != 0.0f) max_label = std::max(max_label, labels[i]);
+        vector<float> saliency;
+        if (!s.out_normals_file.empty()) saliency.assign(tomo_out.data(), tomo_out.data() + n);   // handlers.cpp:1929-1934
         float* o = tomo_out.data();
         for (size_t i = 0; i < n; i++) {
           o[i] = (float)labels[i];
           if (labels[i] == -1) o[i] = s.undefined_voxels_are_max ? (float)(max_label + 1) : s.undefined_voxel_brightness;
+        }
+        if (!s.out_normals_file.empty()) {   // handlers.cpp:2039-2309
+          float maxd = s.max_distance_to_feature;                     // filter_mrc.cpp:301-307
+          if (maxd < 0.0f) maxd /= -vw[0];
+          else maxd /= (float)bin;
+          int64_t np = 0;
+          hip_detail::check(visfd_hip_surface_points(saliency.data(), o, direction.data(), mptr, size[0], size[1], size[2],
+                                                     s.select_cluster, vw, s.surface_normal_curve_ds, s.surface_find_ridge ? 1 : 0,
+                                                     maxd, nullptr, nullptr, 0, &np));
+          vector<float> crds(3 * (size_t)np + 3), norms(3 * (size_t)np + 3);
+          hip_detail::check(visfd_hip_surface_points(saliency.data(), o, direction.data(), mptr, size[0], size[1], size[2],
+                                                     s.select_cluster, vw, s.surface_normal_curve_ds, s.surface_find_ridge ? 1 : 0,
+                                                     maxd, crds.data(), norms.data(), np, &np));
+          std::ofstream ply(s.out_normals_file.c_str());              // file_io.hpp:501-527
+          if (!ply) throw VisfdErr("Error: unable to open \"" + s.out_normals_file + "\" for writing.\n");
+          ply << "ply\nformat ascii 1.0\ncomment  created by visfd\nelement vertex " << np
+              << "\nproperty float x\nproperty float y\nproperty float z\nproperty float nx\nproperty float ny\n"
+                 "property float nz\nend_header\n";
+          for (int64_t k = 0; k < np; k++)
+            ply << crds[3 * k] << " " << crds[3 * k + 1] << " " << crds[3 * k + 2] << " " << norms[3 * k] << " "
+                << norms[3 * k + 1] << " " << norms[3 * k + 2] << "\n";
         }
       }
     }

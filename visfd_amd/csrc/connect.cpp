@@ -419,3 +419,272 @@ extern "C" int visfd_hip_principal_directions_host(const float* tensor, const fl
   });
   return VISFD_HIP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Oriented surface points (the -normals-file tail of HandleTV, bin/filter_mrc/handlers.cpp:2039-2309).
+// For every unmasked voxel of the selected cluster: follow the (standardized) normal direction forwards and
+// backwards in steps of `curve_ds` while staying inside the cluster, take the saliency-weighted mean arc
+// length as the position of the sheet along that normal, optionally snap it to the ridge of the saliency
+// (one Newton step along the principal Hessian direction), and emit position and normal (normal scaled by the
+// voxel's saliency).  All arithmetic is the reference's float arithmetic, including its 3x3 eigen solver
+// instantiated for float: double literals promote exactly where the reference's expressions have them
+// (eigen3_simple.hpp:47-266), which the tests pin against the compiled reference.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+template <typename R>
+void eig_roots3(const R m[3][3], R roots[3]) {   // eigen3_simple.hpp:47-82
+  const R s_inv3 = (R)(1.0 / 3.0);
+  const R s_sqrt3 = (R)std::sqrt(3.0);
+  const R c0 = (R)(m[0][0] * m[1][1] * m[2][2] + 2.0 * m[1][0] * m[2][0] * m[2][1] - m[0][0] * m[2][1] * m[2][1] -
+                   m[1][1] * m[2][0] * m[2][0] - m[2][2] * m[1][0] * m[1][0]);
+  const R c1 = m[0][0] * m[1][1] - m[1][0] * m[1][0] + m[0][0] * m[2][2] - m[2][0] * m[2][0] + m[1][1] * m[2][2] -
+               m[2][1] * m[2][1];
+  const R c2 = m[0][0] + m[1][1] + m[2][2];
+  const R c2_over_3 = c2 * s_inv3;
+  R a_over_3 = (c2 * c2_over_3 - c1) * s_inv3;
+  a_over_3 = std::max(a_over_3, (R)0.0);
+  const R half_b = (R)(0.5 * (c0 + c2_over_3 * (2.0 * c2_over_3 * c2_over_3 - c1)));
+  R q = a_over_3 * a_over_3 * a_over_3 - half_b * half_b;
+  q = std::max(q, (R)0.0);
+  const R rho = std::sqrt(a_over_3);
+  const R theta = std::atan2(std::sqrt(q), half_b) * s_inv3;
+  const R cos_theta = std::cos(theta), sin_theta = std::sin(theta);
+  roots[0] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
+  roots[1] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
+  roots[2] = (R)(c2_over_3 + 2.0 * rho * cos_theta);
+}
+
+template <typename R>
+void cross3r(const R a[3], const R b[3], R d[3]) {
+  d[2] = a[0] * b[1] - a[1] * b[0];
+  d[0] = a[1] * b[2] - a[2] * b[1];
+  d[1] = a[2] * b[0] - a[0] * b[2];
+}
+template <typename R>
+void normalize3r(R a[3]) {   // lin3_utils.hpp:143-155
+  R L = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+  if (L > 0.0) {
+    L = (R)(1.0 / L);
+    for (int d = 0; d < 3; d++) a[d] *= L;
+  } else { a[0] = 1.0; a[1] = 0.0; a[2] = 0.0; }
+}
+
+template <typename R>
+void eig_kernel3(const R mat[3][3], R res[3], R rep[3]) {   // eigen3_simple.hpp:86-133
+  int i0 = 0;
+  R max_diag = std::abs(mat[0][0]);
+  for (int d = 1; d < 3; d++)
+    if (std::abs(mat[d][d]) > max_diag) { i0 = d; max_diag = std::abs(mat[d][d]); }
+  R col[3][3];
+  for (int c = 0; c < 3; c++)
+    for (int r = 0; r < 3; r++) col[c][r] = mat[r][c];
+  for (int d = 0; d < 3; d++) rep[d] = col[i0][d];
+  R c0[3], c1[3];
+  cross3r(rep, col[(i0 + 1) % 3], c0);
+  cross3r(rep, col[(i0 + 2) % 3], c1);
+  const R n0 = c0[0] * c0[0] + c0[1] * c0[1] + c0[2] * c0[2], n1 = c1[0] * c1[0] + c1[1] * c1[1] + c1[2] * c1[2];
+  if (n0 > n1) {
+    const R s = (R)(1.0 / std::sqrt(n0));
+    for (int d = 0; d < 3; d++) res[d] = c0[d] * s;
+  } else {
+    const R s = (R)(1.0 / std::sqrt(n1));
+    for (int d = 0; d < 3; d++) res[d] = c1[d] * s;
+  }
+}
+
+enum { EIG_INCREASING = 0, EIG_DECREASING = 1, EIG_INCREASING_ABS = 2, EIG_DECREASING_ABS = 3 };   // eigen3_simple.hpp:36-43
+
+template <typename R>
+void diagonalize_sym3(const R mat[3][3], R eivals[3], R eivects[3][3], int order) {   // eigen3_simple.hpp:137-266
+  const R EPS = std::numeric_limits<R>::epsilon();
+  const R shift = (R)((mat[0][0] + mat[1][1] + mat[2][2]) / 3.0);
+  R S[3][3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) S[i][j] = mat[i][j];
+  for (int d = 0; d < 3; d++) S[d][d] -= shift;
+  R scale = -1.0;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      if (std::abs(S[i][j]) > scale) scale = std::abs(S[i][j]);
+  if (scale > 0) {
+    const R inv = (R)(1.0 / scale);
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) S[i][j] *= inv;
+  }
+  eig_roots3(S, eivals);
+  if ((eivals[2] - eivals[0]) <= EPS) {
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) eivects[i][j] = (i == j) ? (R)1.0 : (R)0.0;
+  } else {
+    R d0 = eivals[2] - eivals[1];
+    const R d1 = eivals[1] - eivals[0];
+    int k = 0, l = 2;
+    if (d0 > d1) { d0 = d1; std::swap(k, l); }
+    R T[3][3];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) T[i][j] = S[i][j];
+    for (int d = 0; d < 3; d++) T[d][d] -= eivals[k];
+    eig_kernel3(T, eivects[k], eivects[l]);
+    if (d0 <= 2 * EPS * d1) {
+      const R kl = eivects[k][0] * eivects[l][0] + eivects[k][1] * eivects[l][1] + eivects[k][2] * eivects[l][2];
+      for (int d = 0; d < 3; d++) eivects[l][d] -= kl * eivects[l][d];   // (the reference updates with E[l] on both sides)
+      normalize3r(eivects[l]);
+    } else {
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) T[i][j] = S[i][j];
+      for (int d = 0; d < 3; d++) T[d][d] -= eivals[l];
+      R dummy[3];
+      eig_kernel3(T, eivects[l], dummy);
+    }
+    cross3r(eivects[2], eivects[0], eivects[1]);
+    normalize3r(eivects[1]);
+  }
+  for (int d = 0; d < 3; d++) { eivals[d] *= scale; eivals[d] += shift; }
+  const bool swap = (order == EIG_INCREASING && eivals[0] > eivals[2]) || (order == EIG_DECREASING && eivals[0] < eivals[2]) ||
+                    (order == EIG_INCREASING_ABS && std::abs(eivals[0]) > std::abs(eivals[2])) ||
+                    (order == EIG_DECREASING_ABS && std::abs(eivals[0]) < std::abs(eivals[2]));
+  if (swap) {
+    std::swap(eivals[0], eivals[2]);
+    for (int d = 0; d < 3; d++) std::swap(eivects[0][d], eivects[2][d]);
+  }
+}
+
+inline float length3f(const float* v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }   // visfd_utils.hpp:41-43
+
+}  // namespace
+
+// DiagonalizeSym3<float> (eigen3_simple.hpp:137-266): m9 = 3x3 row-major, eivects9 = eigenvectors as rows;
+// order 0..3 = INCREASING, DECREASING, INCREASING_ABS, DECREASING_ABS eigenvalues.
+extern "C" int visfd_hip_diagonalize_sym3_f32_host(const float* m9, int order, float* eivals3, float* eivects9) {
+  if (!m9 || !eivals3 || !eivects9 || order < 0 || order > 3) return vh::fail(VISFD_HIP_EINVAL, "diagonalize_sym3: bad argument");
+  float M[3][3], E[3][3];
+  for (int i = 0; i < 9; i++) M[i / 3][i % 3] = m9[i];
+  diagonalize_sym3<float>(M, eivals3, E, order);
+  for (int i = 0; i < 9; i++) eivects9[i] = E[i / 3][i % 3];
+  return VISFD_HIP_OK;
+}
+
+extern "C" int visfd_hip_surface_points(const float* saliency, const float* voxel2cluster, const float* direction,
+                                        const float* mask, int64_t nx64, int64_t ny64, int64_t nz64, int select_cluster,
+                                        const float voxel_width[3], float curve_ds, int find_ridge,
+                                        float max_distance_to_feature, float* crds, float* norms, int64_t capacity,
+                                        int64_t* n_points) {
+  if (!saliency || !direction || !voxel_width || !n_points) return vh::fail(VISFD_HIP_EINVAL, "surface_points: null argument");
+  VH_TRY(vh::check_dims(nx64, ny64, nz64));
+  if (nx64 < 3 || ny64 < 3 || nz64 < 3) return vh::fail(VISFD_HIP_EINVAL, "surface_points: the image must be at least 3 voxels wide");
+  if (nx64 * ny64 * nz64 >= (1LL << 31)) return vh::fail(VISFD_HIP_EINVAL, "surface_points: image too large");
+  const Grid g = {(int)nx64, (int)ny64, (int)nz64};
+  const float* S = saliency;
+  const float* V = direction;
+  const float* C = voxel2cluster;   // null: no clustering was done, every unmasked voxel is exported as is
+  const int size[3] = {g.nx, g.ny, g.nz};
+  int64_t count = 0;
+  bool overflow = false;
+  auto emit = [&](const float xyz[3], const float nrm[3]) {
+    if (crds && norms && count < capacity)
+      for (int d = 0; d < 3; d++) { crds[3 * count + d] = xyz[d]; norms[3 * count + d] = nrm[d]; }
+    else if (crds || norms) overflow = true;
+    count++;
+  };
+  auto inside = [&](const int p[3]) { return p[0] >= 0 && p[0] < g.nx && p[1] >= 0 && p[1] < g.ny && p[2] >= 0 && p[2] < g.nz; };
+  std::vector<float> vS, vW, bS, bW;
+  std::vector<std::array<float, 3> > vR, bR;
+  for (int iz = 0; iz < g.nz; iz++)
+    for (int iy = 0; iy < g.ny; iy++)
+      for (int ix = 0; ix < g.nx; ix++) {
+        const i64 c = g.at(ix, iy, iz);
+        if (mask && mask[c] == 0.0f) continue;
+        float xyz[3], normal[3];
+        if (!C) {   // handlers.cpp:2056-2068
+          xyz[0] = ix * voxel_width[0]; xyz[1] = iy * voxel_width[1]; xyz[2] = iz * voxel_width[2];
+          for (int d = 0; d < 3; d++) normal[d] = V[3 * c + d];
+          emit(xyz, normal);
+          continue;
+        }
+        if ((float)select_cluster != C[c]) continue;
+        xyz[0] = (float)ix; xyz[1] = (float)iy; xyz[2] = (float)iz;
+        float norm = length3f(V + 3 * c);
+        for (int d = 0; d < 3; d++) { normal[d] = V[3 * c + d] / norm; normal[d] *= S[c]; }
+        if (curve_ds > 0.0f) {   // handlers.cpp:2098-2217
+          const float ds = curve_ds;
+          vS.clear(); vW.clear(); vR.clear(); bS.clear(); bW.clear(); bR.clear();
+          float s = 0.0f, drds[3];
+          std::array<float, 3> r = {{(float)ix, (float)iy, (float)iz}};
+          int p[3] = {ix, iy, iz};
+          while (inside(p) && (!mask || mask[g.at(p[0], p[1], p[2])] != 0.0f) && C[g.at(p[0], p[1], p[2])] == C[c]) {
+            const i64 cp = g.at(p[0], p[1], p[2]);
+            vS.push_back(s); vR.push_back(r); vW.push_back(S[cp]);
+            norm = length3f(V + 3 * cp);
+            for (int d = 0; d < 3; d++) drds[d] = V[3 * cp + d] / norm;
+            s += ds;
+            for (int d = 0; d < 3; d++) { r[d] += ds * drds[d]; p[d] = (int)std::round(r[d]); }
+          }
+          r = {{(float)ix, (float)iy, (float)iz}};
+          p[0] = ix; p[1] = iy; p[2] = iz;
+          s = 0.0f;
+          for (;;) {
+            const i64 cp = g.at(p[0], p[1], p[2]);
+            norm = length3f(V + 3 * cp);
+            for (int d = 0; d < 3; d++) drds[d] = V[3 * cp + d] / norm;
+            s -= ds;
+            for (int d = 0; d < 3; d++) { r[d] -= ds * drds[d]; p[d] = (int)std::round(r[d]); }
+            if (!inside(p)) break;
+            const i64 cq = g.at(p[0], p[1], p[2]);
+            if (mask && mask[cq] == 0.0f) break;
+            if (C[cq] != C[c]) break;
+            bS.push_back(s); bR.push_back(r); bW.push_back(S[cq]);
+          }
+          vS.insert(vS.begin(), bS.rbegin(), bS.rend());
+          vR.insert(vR.begin(), bR.rbegin(), bR.rend());
+          vW.insert(vW.begin(), bW.rbegin(), bW.rend());
+          float sum_s = 0.0f, sum_w = 0.0f;
+          for (size_t i = 0; i < vS.size(); i++) { sum_s += vW[i] * vS[i]; sum_w += vW[i]; }
+          const float ave_s = sum_s / sum_w;
+          size_t i = 0;
+          while (i + 1 < vS.size()) {
+            i++;
+            if (vS[i - 1] <= ave_s && ave_s <= vS[i]) break;
+          }
+          for (int d = 0; d < 3; d++) p[d] = (int)std::round(vR[i][d]);
+          const i64 cp = g.at(p[0], p[1], p[2]);
+          norm = length3f(V + 3 * cp);
+          for (int d = 0; d < 3; d++) normal[d] = V[3 * cp + d] / norm;
+          for (int d = 0; d < 3; d++) {
+            if (i + 1 < vS.size()) xyz[d] = (vR[i][d] + (vR[i + 1][d] - vR[i][d]) * ((ave_s - vS[i]) / (vS[i + 1] - vS[i])));
+            else xyz[d] = vR[i][d];
+            normal[d] *= S[c];
+          }
+        }
+        if (find_ridge) {   // handlers.cpp:2227-2296
+          const int ix0 = (int)std::round(xyz[0]), iy0 = (int)std::round(xyz[1]), iz0 = (int)std::round(xyz[2]);
+          float H[3][3], grad[3];
+          hessian_fd(g, S, ix0, iy0, iz0, H);
+          {   // visfd_utils.hpp:631-669: clamped central differences
+            int gx = ix0, gy = iy0, gz = iz0;
+            if (gx == 0) gx++; else if (gx == g.nx - 1) gx--;
+            if (gy == 0) gy++; else if (gy == g.ny - 1) gy--;
+            if (gz == 0) gz++; else if (gz == g.nz - 1) gz--;
+            grad[0] = (float)(0.5 * (S[g.at(gx + 1, gy, gz)] - S[g.at(gx - 1, gy, gz)]));
+            grad[1] = (float)(0.5 * (S[g.at(gx, gy + 1, gz)] - S[g.at(gx, gy - 1, gz)]));
+            grad[2] = (float)(0.5 * (S[g.at(gx, gy, gz + 1)] - S[g.at(gx, gy, gz - 1)]));
+          }
+          float ev[3], E[3][3];
+          diagonalize_sym3<float>(H, ev, E, EIG_DECREASING_ABS);
+          float g1 = dot3(grad, E[0]);
+          if (g1 < 0.0f) { g1 = -g1; for (int d = 0; d < 3; d++) E[0][d] = -E[0][d]; }
+          else if (g1 == 0.0f) continue;
+          const float dist = (ev[0] != 0) ? g1 / ev[0] : std::numeric_limits<float>::infinity();
+          if (max_distance_to_feature > 0.0f && std::abs(dist) > max_distance_to_feature) continue;
+          xyz[0] = ix0 - dist * E[0][0];
+          xyz[1] = iy0 - dist * E[0][1];
+          xyz[2] = iz0 - dist * E[0][2];
+          if (xyz[0] < 0.0f || size[0] < xyz[0] || xyz[1] < 0.0f || size[1] < xyz[1] || xyz[2] < 0.0f || size[2] < xyz[2]) continue;
+          for (int d = 0; d < 3; d++) xyz[d] *= voxel_width[d];
+        }
+        emit(xyz, normal);
+      }
+  *n_points = count;
+  if (overflow) return vh::fail(VISFD_HIP_ECAPACITY, "surface_points: output arrays too small");
+  return VISFD_HIP_OK;
+}
