@@ -9,12 +9,15 @@
 //
 // Work decomposition (per workgroup of NT threads):
 //   * an output tile of TX x TY voxels in the XY plane, marched along Z over a chunk of planes;
-//   * Z pass: each thread owns NC columns of the (TX+2H) x (TY+2H) haloed tile and keeps the last
-//     2H+1 source planes of each column in a REGISTER RING (the march is unrolled 2H+1 times so the
-//     ring is statically indexed).  Right after the Z pass the plane needed by the NEXT step is
-//     requested into the slot that just became free, so its HBM latency is covered by the Y and X
-//     passes.  Loads are buffer loads with hardware range checking: columns outside the image use
-//     an out-of-range offset and planes outside the image a zero-length descriptor, both of which
+//   * Z pass: each thread owns NC columns of the (TX+2H) x (TY+2H) haloed tile and keeps, per column, the
+//     2H+1 RUNNING SUMS of the output planes in flight in a register ring (the march is unrolled 2H+1
+//     times so the ring is statically indexed).  The march goes DOWN in z: the reference adds the
+//     terms of an output with j ascending, i.e. source planes in descending order, so each arriving
+//     input plane can add its term to all 2H+1 sums in the reference's order (scatter form).  With
+//     symmetric taps t[j]*f and t[-j]*f are the same IEEE product: H+1 multiplies per input, not 2H+1.
+//     Right after the Z pass the next input plane is requested, so its HBM latency is covered by the
+//     Y and X passes.  Loads are buffer loads with hardware range checking: columns outside the image
+//     use an out-of-range offset and planes outside the image a zero-length descriptor, both of which
 //     return 0.0f -- no branches, no exec masking;
 //   * the Z-filtered haloed plane goes to LDS; Y pass: two adjacent x per lane (ds_read_b64 down a
 //     column), result rows to LDS; X pass: four adjacent outputs per lane from ds_read_b128
@@ -25,6 +28,7 @@
 //
 // This file is compiled once per window half-width (-DVH_FUSED_H=h, see visfd_amd/build.py).
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -54,6 +58,10 @@ struct FusedCfg {
   static constexpr int YV = YV_;                   // adjacent x per lane in the Y pass (1 or 2)
   static constexpr int YTASKS = (HX / YV) * RPW;   // per wave: (x group, row)
   static constexpr int YROUNDS = (YTASKS + 63) / 64;
+  // With column pairs (YV == 2) a last round that is at most half full is run on single columns instead
+  // (two lanes per pair task): half the instructions for the same outputs
+  static constexpr int YREM = YTASKS % 64;
+  static constexpr bool YLAST_SINGLE = (YV == 2) && YREM > 0 && YREM <= 32;
   static constexpr int XV = XV_;                   // outputs per lane in the X pass (2 or 4)
   static constexpr int XTASKS = (TX / XV) * RPW;   // per wave
   static constexpr int XROUNDS = (XTASKS + 63) / 64;
@@ -70,6 +78,15 @@ struct TapsH {
   float t[2 * H + 1];
 };
 
+// compile-time loop: f(std::integral_constant<int, I>) for I = B .. E-1 (ring indices must be constants)
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
 __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)byte_off, 0, 0));
 }
@@ -79,7 +96,7 @@ __global__ void __launch_bounds__(NT)
 gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH<H> tz, TapsH<H> ty_,
                    TapsH<H> tx_, const float* __restrict__ Dx, const float* __restrict__ Dy,
                    const float* __restrict__ Dz, i64 dz_offset, int nx, int ny, int nz, int zchunk,
-                   int tiles_x, int tiles_y, const float* __restrict__ minuend, float log_scale) {
+                   int tiles_x, int tiles_y, const float* __restrict__ minuend, float log_scale, float dz_int) {
   typedef FusedCfg<H, TX, TY, NT, XV_, YV_> C;
   constexpr int W = C::W;
   static_assert(TY % (NT / 64) == 0, "tile rows must divide evenly among the waves");
@@ -106,9 +123,13 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
   const int plane_bytes = (int)(plane * 4);
 
   // ---- per-thread constants -------------------------------------------------------------------
-  float ring[C::NC][W];
+  float ring[C::NC][W];     // running Z sums of the 2H+1 output planes in flight, per column
+#pragma unroll
+  for (int c = 0; c < C::NC; c++)
+#pragma unroll
+    for (int m = 0; m < W; m++) ring[c][m] = 0.0f;
   unsigned col_off[C::NC];  // byte offset of the column inside a plane (OOB outside the image)
-  int lds_off[C::NC];       // where its Z-filtered value goes in sZ (dump area for padding slots)
+  int lds_off[C::NC];       // BYTE offset of its Z-filtered value in sZ (dump area for padding slots)
 #pragma unroll
   for (int c = 0; c < C::NC; c++) {
     const int id = tid + c * NT;
@@ -117,19 +138,21 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
     const bool slot = id < C::NCOL;
     const bool inside = slot && gx >= 0 && gx < nx && gy >= 0 && gy < ny;
     col_off[c] = inside ? (unsigned)(gy * nx + gx) * 4u : OOB;
-    lds_off[c] = slot ? (cy * C::SX + cx) : (C::HY * C::SX + (tid & 63));
+    lds_off[c] = 4 * (slot ? (cy * C::SX + cx) : (C::HY * C::SX + (tid & 63)));
   }
   const int lane = tid & 63, wave = tid >> 6;
-  int y_off[C::YROUNDS];    // LDS float offset of (row y, column pair xp); -1: idle lane
+  int y_off[C::YROUNDS];    // LDS BYTE offset of (row y, column pair xp); -1: idle lane
 #pragma unroll
   for (int r = 0; r < C::YROUNDS; r++) {
-    const int task = lane + r * 64;
+    const bool single = C::YLAST_SINGLE && r == C::YROUNDS - 1;
+    const int task = single ? (r * 64 + (lane >> 1)) : (lane + r * 64);
     const int yy = task / (C::HX / C::YV), xp = task - yy * (C::HX / C::YV);
-    y_off[r] = (task < C::YTASKS) ? ((wave * C::RPW + yy) * C::SX + C::YV * xp) : -1;
+    y_off[r] = (task < C::YTASKS) ? 4 * ((wave * C::RPW + yy) * C::SX + C::YV * xp + (single ? (lane & 1) : 0)) : -1;
   }
   int x_off[C::XROUNDS];
   unsigned o_off[C::XROUNDS];  // byte offset of the output quad inside a plane (OOB outside)
   float dxy[C::XROUNDS][C::XV];
+  float rcp_int[C::XROUNDS][C::XV];   // 1 / ((Dx*Dy)*Dz) for the planes whose Dz is the interior value dz_int
 #pragma unroll
   for (int r = 0; r < C::XROUNDS; r++) {
     const int task = lane + r * 64;
@@ -137,63 +160,83 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
     const int y = wave * C::RPW + yy;
     const int gx = x0 + C::XV * xq, gy = y0 + y;
     const bool ok = (task < C::XTASKS) && gx < nx && gy < ny;  // nx % 4 == 0: the whole quad is inside
-    x_off[r] = (task < C::XTASKS) ? (y * C::SX + C::XV * xq) : 0;
+    x_off[r] = (task < C::XTASKS) ? 4 * (y * C::SX + C::XV * xq) : 0;   // bytes
     o_off[r] = ok ? (unsigned)(gy * nx + gx) * 4u : OOB;
     if (NORMALIZE) {
       const float dy = ok ? Dy[gy] : 1.0f;
 #pragma unroll
-      for (int k = 0; k < C::XV; k++) dxy[r][k] = (ok ? Dx[gx + k] : 1.0f) * dy;  // (Dx*Dy) first, then *Dz (filter3d.hpp:1016-1018)
+      for (int k = 0; k < C::XV; k++) {
+        dxy[r][k] = (ok ? Dx[gx + k] : 1.0f) * dy;  // (Dx*Dy) first, then *Dz (filter3d.hpp:1016-1018)
+        rcp_int[r][k] = 1.0f / (dxy[r][k] * dz_int);  // IEEE division: the correctly rounded reciprocal
+      }
     }
   }
 
-  // preload planes zs-H .. zs+H into ring slots 1..W-1, 0 (slot (1+m)%W holds plane zs-H+m)
-#pragma unroll
-  for (int m = 0; m < W; m++) {
-    const int z = zs - H + m;
-    const bool zin = (z >= 0) && (z < nz);
+  // first input plane of the march (the topmost one, ze-1+H); planes outside the image read as 0.0f
+  const int ktop = ze - 1 + H;
+  const int nout = ze - zs;
+  float xin[C::NC];
+  auto request_plane = [&](int zn, bool wanted) {   // a zero-length descriptor fetches nothing and returns 0.0f
+    const bool zin = wanted && zn >= 0 && zn < nz;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(src + (zin ? (i64)z * plane : 0)), 0, zin ? plane_bytes : 0, 0x00020000);
+        (void*)(src + (zin ? (i64)zn * plane : 0)), 0, zin ? plane_bytes : 0, 0x00020000);
 #pragma unroll
-    for (int c = 0; c < C::NC; c++) ring[c][(1 + m) % W] = buf_load(rs, col_off[c]);
-  }
+    for (int c = 0; c < C::NC; c++) xin[c] = buf_load(rs, col_off[c]);
+  };
+  request_plane(ktop, true);
 
-  // ---- march along z, unrolled W times so that ring indices are compile-time ----------------
-  // At unrolled step u (output plane z): slot (u+1+m) % W holds plane z-H+m, m = 0..W-1
-  // (so the newest plane z+H sits in slot u and the oldest, z-H, in slot (u+1)%W).
-  for (int zbase = zs; zbase < ze; zbase += W) {
+  // ---- march DOWN along z, unrolled W times so that ring indices are compile-time -------------
+  // Z pass in scatter form.  g[i] = sum_j t[j]*f[i-j] with j ascending means: for a fixed output plane i
+  // the source planes contribute in DESCENDING order (i+H first, i-H last).  Marching down, the input
+  // plane k = ktop - step adds its term t[j]*f[k] to the 2H+1 running sums of the outputs i = k+j in
+  // exactly that order; the sum of output k+H is complete after this step.  The taps are symmetric
+  // (checked on the host, bit for bit), so t[j]*f[k] and t[-j]*f[k] are the same IEEE product and only
+  // H+1 multiplies are needed per input instead of 2H+1.  Slot of output i: (ktop + H - i) mod W
+  // = (u + H - j) mod W at step number congruent to u.
+  auto z_scatter = [&](int u) {
 #pragma unroll
-    for (int u = 0; u < W; u++) {
-      const int z = zbase + u;
-      if (z < ze) {  // uniform across the workgroup
-        float* sZ = sZ2[(z - zs) & 1];
-        // Z pass: j ascending <=> plane z-j descending: newest first
+    for (int c = 0; c < C::NC; c++) {
+      float pr[H + 1];
 #pragma unroll
-        for (int c = 0; c < C::NC; c++) {
-          float acc = 0.0f;
+      for (int m = 0; m <= H; m++) pr[m] = tz.t[H + m] * xin[c];
 #pragma unroll
-          for (int jj = 0; jj < W; jj++) {
-            // j = jj-H; plane z-j = z-H+m with m = W-1-jj
-            const float term = tz.t[jj] * ring[c][(u + 1 + (W - 1 - jj)) % W];
-            acc = acc + term;
-          }
-          sZ[lds_off[c]] = acc;   // sZ = sZ2[step parity]
-        }
-        // request the plane of the next step (z+1+H) into the slot the oldest plane just vacated
-        {
-          const int zn = z + 1 + H;
-          const bool zin = zn < nz;
-          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-              (void*)(src + (zin ? (i64)zn * plane : 0)), 0, zin ? plane_bytes : 0, 0x00020000);
+      for (int j = -H; j <= H; j++) {
+        const int s = (u + H - j) % W;
+        if (j == -H) ring[c][s] = 0.0f + pr[H];          // "acc = 0; acc += term" (filter1d.hpp:96-101)
+        else ring[c][s] = ring[c][s] + pr[j < 0 ? -j : j];
+      }
+    }
+  };
+  // warm-up: the first 2H input planes complete no output of this chunk (each step waits for its plane;
+  // a separate code region, so that the main loop below has a single wait state at its step boundaries)
+  static_for<0, W - 1>([&](auto U) {
+    constexpr int u = decltype(U)::value;
+    z_scatter(u);
+    request_plane(ktop - u - 1, true);
+  });
+  // main loop: step W-1+n completes output plane z = ze-1-n; unrolled W times (v), ring phase u = (v+W-1) % W
+  for (int nb = 0; nb < nout; nb += W) {
+    static_for<0, W>([&](auto V) {
+      constexpr int v = decltype(V)::value;
+      constexpr int u = (v + W - 1) % W;
+      const int n = nb + v;
+      if (n < nout) {  // uniform across the workgroup
+        const int z = ze - 1 - n;
+        const int k = z - H;              // this step's input plane
+        float* sZ = sZ2[v & 1];           // static: LDS addresses fold into the DS instructions' offset fields
+        z_scatter(u);
 #pragma unroll
-          for (int c = 0; c < C::NC; c++) ring[c][(u + 1) % W] = buf_load(rs, col_off[c]);
-        }
+        for (int c = 0; c < C::NC; c++)
+          *reinterpret_cast<float*>(reinterpret_cast<char*>(sZ) + lds_off[c]) = ring[c][u];
+        // request the next input plane (k-1); its latency is covered by the Y and X passes
+        request_plane(k - 1, n + 1 < nout);
         __syncthreads();
         // Y pass: two adjacent x per lane; source rows y+2H (j=-H) down to y (j=+H)
 #pragma unroll
         for (int r = 0; r < C::YROUNDS; r++) {
           if (y_off[r] >= 0) {
-            const float* base = &sZ[y_off[r]];
-            if (C::YV == 2) {
+            const float* base = reinterpret_cast<const float*>(reinterpret_cast<const char*>(sZ) + y_off[r]);
+            if (C::YV == 2 && !(C::YLAST_SINGLE && r == C::YROUNDS - 1)) {
               float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll
               for (int jj = 0; jj < W; jj++) {
@@ -204,7 +247,7 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
                 a0 = a0 + p0;
                 a1 = a1 + p1;
               }
-              *reinterpret_cast<float2*>(&sY[y_off[r]]) = make_float2(a0, a1);
+              *reinterpret_cast<float2*>(reinterpret_cast<char*>(sY) + y_off[r]) = make_float2(a0, a1);
             } else {
               float a0 = 0.0f;
 #pragma unroll
@@ -212,7 +255,7 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
                 const float p0 = ty.t[jj] * base[(2 * H - jj) * C::SX];
                 a0 = a0 + p0;
               }
-              sY[y_off[r]] = a0;
+              *reinterpret_cast<float*>(reinterpret_cast<char*>(sY) + y_off[r]) = a0;
             }
           }
         }
@@ -221,19 +264,23 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
         const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(dst + (i64)z * plane), 0, plane_bytes, 0x00020000);
         float dz = 1.0f;
-        if (NORMALIZE) dz = Dz[z + dz_offset];
+        bool dz_is_int = false;
+        if (NORMALIZE) {
+          dz = Dz[z + dz_offset];
+          dz_is_int = (dz == dz_int);   // uniform
+        }
 #pragma unroll
         for (int r = 0; r < C::XROUNDS; r++) {
           float v[C::XV * C::XWINV];
           if (C::XV == 4) {
-            const float4* base = reinterpret_cast<const float4*>(&sY[x_off[r]]);
+            const float4* base = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sY) + x_off[r]);
 #pragma unroll
             for (int k = 0; k < C::XWINV; k++) {
               const float4 q = base[k];
               v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
             }
           } else {
-            const float2* base = reinterpret_cast<const float2*>(&sY[x_off[r]]);
+            const float2* base = reinterpret_cast<const float2*>(reinterpret_cast<const char*>(sY) + x_off[r]);
 #pragma unroll
             for (int k = 0; k < C::XWINV; k++) {
               const float2 q = base[k];
@@ -253,10 +300,39 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
             }
           }
           if (NORMALIZE) {
+            // dest /= (Dx*Dy)*Dz (filter3d.hpp:1016-1018), one correctly rounded division.  On planes with the
+            // interior Dz the divisor is a per-lane constant whose correctly rounded reciprocal y is known, and
+            // the quotient follows from two Newton corrections with exact FMA residuals (Markstein): q1 = q0 +
+            // (a - d q0) y is a faithful quotient, q2 = q1 + (a - d q1) y is the correctly rounded one.  The
+            // residuals are exact only while nothing under- or overflows, hence the range guard; everything
+            // else (first/last H planes, zeros, extreme magnitudes) takes the full-range division.
+            float d[C::XV];
 #pragma unroll
-            for (int k = 0; k < C::XV; k++) {
-              const float d = dxy[r][k] * dz;
-              a[k] = a[k] / d;
+            for (int k = 0; k < C::XV; k++) d[k] = dxy[r][k] * dz;
+            bool fast = dz_is_int;
+            if (fast) {
+              float hi = __builtin_fmaxf(__builtin_fabsf(a[0]), __builtin_fabsf(a[1]));
+              float lo = __builtin_fminf(__builtin_fabsf(a[0]), __builtin_fabsf(a[1]));
+#pragma unroll
+              for (int k = 2; k < C::XV; k++) {
+                hi = __builtin_fmaxf(hi, __builtin_fabsf(a[k]));
+                lo = __builtin_fminf(lo, __builtin_fabsf(a[k]));
+              }
+              fast = __builtin_amdgcn_ballot_w64(!((hi < 0x1p100f) && (lo >= 0x1p-100f))) == 0ull;
+            }
+            if (fast) {
+#pragma unroll
+              for (int k = 0; k < C::XV; k++) {
+                const float y = rcp_int[r][k];
+                const float q0 = a[k] * y;
+                const float r0 = __builtin_fmaf(-d[k], q0, a[k]);
+                const float q1 = __builtin_fmaf(r0, y, q0);
+                const float r1 = __builtin_fmaf(-d[k], q1, a[k]);
+                a[k] = __builtin_fmaf(r1, y, q1);
+              }
+            } else {
+#pragma unroll
+              for (int k = 0; k < C::XV; k++) a[k] = a[k] / d[k];
             }
           }
           typedef float v4f __attribute__((ext_vector_type(4)));
@@ -283,6 +359,13 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
               a[k] = dd * log_scale;
             }
           }
+          // vmcnt counts loads and stores in one queue: make the wait for the next input plane (requested
+          // after the Z pass, long since arrived) happen BEFORE the first output store is issued, so that the
+          // next Z pass does not have to drain that store to see its inputs
+          if (r == 0) {
+#pragma unroll
+            for (int c = 0; c < C::NC; c++) asm volatile("" : "+v"(xin[c]));
+          }
           if (C::XV == 4) {
             v4f out = {a[0], a[1], a[2], a[3]};
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, out), ro, (int)o_off[r], 0, 0);
@@ -291,12 +374,14 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, out), ro, (int)o_off[r], 0, 0);
           }
         }
-        // One workgroup barrier per plane: sZ is double-buffered, so a wave may start the next Z pass
-        // (writing the other buffer) while slower waves still read this one; that buffer's readers
-        // (plane z-1) all finished before they arrived at this step's barrier.  sY rows are private
-        // to a wave.
+        // One workgroup barrier per plane: sZ is double-buffered (buffer v & 1), so a wave may start the
+        // next Z pass (writing the other buffer) while slower waves still read this one; that buffer's
+        // readers (previous step) all finished before they arrived at this step's barrier.  sY rows are
+        // private to a wave.  W is odd: the last step of a block and the first of the next use the same
+        // buffer, hence one more barrier there.
+        if (v == W - 1) __syncthreads();
       }
-    }
+    });
   }
 }
 
@@ -310,6 +395,10 @@ int launch_cfg(visfd_hip_ctx* ctx, const float* src, float* dst, i64 nx, i64 ny,
     a.t[k] = tz.t[k]; b.t[k] = ty.t[k]; c.t[k] = tx.t[k];
     iso = iso && (std::memcmp(&tz.t[k], &ty.t[k], 4) == 0) && (std::memcmp(&tz.t[k], &tx.t[k], 4) == 0);
   }
+  // Dz of a plane at least H away from both faces: the float sum of the Z taps in tap order (what
+  // host_conv_ones produces there); planes with this Dz take the reciprocal-based division
+  float dz_int = 0.0f;
+  for (int k = 0; k < 2 * H + 1; k++) dz_int = dz_int + tz.t[k] * 1.0f;
   const int tiles_x = (int)((nx + TX - 1) / TX), tiles_y = (int)((ny + TY - 1) / TY);
   // z chunks: enough workgroups to fill the chip several times over, but marches long enough
   // to amortise the 2H-plane ring warm-up
@@ -329,7 +418,7 @@ int launch_cfg(visfd_hip_ctx* ctx, const float* src, float* dst, i64 nx, i64 ny,
 #define VH_GO(NORM, ISOV)                                                                        \
   gauss_fused_kernel<H, TX, TY, NT, XV, YV, NORM, ISOV><<<grid, block, 0, ctx->stream>>>(                \
       src, dst, a, b, c, Dx, Dy, Dz, dz_offset, (int)nx, (int)ny, (int)nz, (int)zchunk, tiles_x, tiles_y,  \
-      minuend, log_scale)
+      minuend, log_scale, dz_int)
   if (normalize) { if (iso) VH_GO(true, true); else VH_GO(true, false); }
   else           { if (iso) VH_GO(false, true); else VH_GO(false, false); }
 #undef VH_GO
