@@ -332,6 +332,7 @@ def test_gauss_large_volume_crops_equal_oracle(ctx, oracle):
     sigma, h = (2.0,) * 3, 5
     outs = {}
     dst = torch.empty_like(src)
+    torch.cuda.synchronize()   # the context runs on its own stream: the generated volume must be complete first
     ctx.gauss_dev(src, dst, sigma, (h, h, h))
     ctx.synchronize()      # the library runs on its own stream here: finish before torch copies the result
     outs["fused"] = dst.clone()
@@ -358,6 +359,60 @@ def test_gauss_large_volume_crops_equal_oracle(ctx, oracle):
         a = got[z0:z0 + E, y0:y0 + E, x0:x0 + E].cpu().numpy()
         b = want[z0 - lo[0]:z0 - lo[0] + E, y0 - lo[1]:y0 - lo[1] + E, x0 - lo[2]:x0 - lo[2] + E]
         assert_bits_equal(a, b, "crop at %s" % ((z0, y0, x0),))
+
+
+def test_gauss_2048_cubed_crops_equal_oracle(ctx, oracle):
+    """2048^3 float32 (the north-star target size; 2^33 voxels, beyond 32-bit indexing and beyond what the reference
+    can allocate): single-sweep kernel == three single-axis kernels on the whole 32 GiB volume, and crops in the
+    interior, across the 2^31- and 2^32-voxel marks and at faces equal the CPU restatement run on the crop + halo.
+    The normalised result in the interior is the un-normalised one divided by the constant (Dx*Dy)*Dz."""
+    import torch
+    dev = torch.device("cuda:0")
+    free, _total = torch.cuda.mem_get_info()
+    n = 2048
+    if free < 140 * 2 ** 30:
+        pytest.skip("needs ~130 GiB of free HBM (two 32 GiB volumes + two 32 GiB pass workspaces)")
+    g = torch.Generator(device=dev).manual_seed(2048)
+    src = torch.empty((n, n, n), device=dev, dtype=torch.float32)
+    for z in range(0, n, 256):   # generate in slabs: randn's temporaries stay small
+        src[z:z + 256] = torch.randn((256, n, n), device=dev, generator=g) * 100 + 1000
+    sigma, h = (2.0,) * 3, 5
+    got = torch.empty_like(src)
+    torch.cuda.synchronize()   # the context runs on its own stream: the generated volume must be complete first
+    ctx.gauss_dev(src, got, sigma, (h, h, h), None, False)
+    ctx.synchronize()
+    E = 16
+    corners = [(0, 0, 0), (n - E, n - E, n - E), (511, 2040, 2040), (512, 0, 0), (1023, 2047 - E, 1000),
+               (1024, 3, 2030), (1500, 1000, 7)]
+    for (z0, y0, x0) in corners:
+        lo = [max(0, z0 - h), max(0, y0 - h), max(0, x0 - h)]
+        hi = [min(n, z0 + E + h), min(n, y0 + E + h), min(n, x0 + E + h)]
+        sub = src[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]].cpu().numpy().copy()
+        want, _ = oracle.gauss_hw(sub, sigma, (h, h, h), None, False)
+        a = got[z0:z0 + E, y0:y0 + E, x0:x0 + E].cpu().numpy()
+        b = want[z0 - lo[0]:z0 - lo[0] + E, y0 - lo[1]:y0 - lo[1] + E, x0 - lo[2]:x0 - lo[2] + E]
+        assert_bits_equal(a, b, "2048^3 crop at %s" % ((z0, y0, x0),))
+    # the three single-axis kernels on the same volume
+    os.environ["VISFD_HIP_GAUSS_3PASS"] = "1"
+    try:
+        alt = torch.empty_like(src)
+        ctx.gauss_dev(src, alt, sigma, (h, h, h), None, False)
+        ctx.synchronize()
+    finally:
+        del os.environ["VISFD_HIP_GAUSS_3PASS"]
+    for z in range(0, n, 256):
+        assert torch.equal(got[z:z + 256], alt[z:z + 256]), "fused != 3-pass in slab %d" % z
+    # normalised: interior voxels are divided by one constant (filter3d.hpp:1016-1018)
+    ctx.gauss_dev(src, alt, sigma, (h, h, h))
+    ctx.synchronize()
+    d1 = np.float32(0.0)    # D of an interior line: the 1-D filter applied to ones, summed in tap order
+    for t in np.asarray(oracle.gauss_taps(2.0, h), np.float32):
+        d1 = np.float32(d1 + np.float32(t * np.float32(1.0)))
+    dconst = np.float32(np.float32(d1 * d1) * d1)
+    for (z0, y0, x0) in [(511, 1000, 1000), (1024, 300, 1700), (1500, 1000, 7 + h)]:
+        a = alt[z0:z0 + E, y0:y0 + E, x0:x0 + E].cpu().numpy()
+        b = (got[z0:z0 + E, y0:y0 + E, x0:x0 + E].cpu().numpy() / dconst).astype(np.float32)
+        assert_bits_equal(a, b, "2048^3 normalised crop at %s" % ((z0, y0, x0),))
 
 
 # ------------------------------------------------------------------------------------------ empty / degenerate inputs

@@ -47,7 +47,9 @@ def main():
         import bench
         src = bench.synth_volume(torch, ctx, (n, n, n), dev, seed=12345)
     else:
-        src = torch.randn((n, n, n), device=dev, generator=g) * 100 + 1000
+        src = torch.empty((n, n, n), device=dev, dtype=torch.float32)
+        for z in range(0, n, 128):   # in slabs: randn's temporaries stay small at 2048^3
+            src[z:z + 128] = torch.randn((min(128, n - z), n, n), device=dev, generator=g) * 100 + 1000
     dst = torch.empty_like(src)
     nvox = n ** 3
     stages = a.stages.split(",")
