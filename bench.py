@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--size", type=int, default=1024, help="edge of the per-GPU volume")
     ap.add_argument("--cpu-sample", type=int, default=192)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-2048", action="store_true", help="skip the extra Gaussian timing on a 2048^3 volume")
     args = ap.parse_args()
 
     import torch
@@ -301,6 +302,48 @@ def main():
                                "and packing, which leaves ~39 T scalar fp32 instructions/s to issue: the kernel issues "
                                "~85 % of that (DESIGN.md 4.2)"}
 
+    # ---- the north-star target case: the separable Gaussian on a 2048^3 volume (2^33 voxels, 32 GiB) -------
+    roofline_2048 = None
+    if rank == 0 and world == 1 and not args.no_2048:
+        del dst, sal, dirs, ten
+        torch.cuda.empty_cache()
+        free, _ = torch.cuda.mem_get_info()
+        if free > 140 * 2 ** 30:
+            n2 = 2048
+            big = torch.empty((n2, n2, n2), device=device, dtype=torch.float32)
+            gen = torch.Generator(device=device).manual_seed(12346)
+            for z in range(0, n2, 128):
+                big[z:z + 128] = torch.randn((128, n2, n2), device=device, generator=gen) * 100 + 1000
+            bout = torch.empty_like(big)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+            def timed(reps):
+                pipeline.gauss(ctx, big, bout, GAUSS_SIGMA)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(reps):
+                    pipeline.gauss(ctx, big, bout, GAUSS_SIGMA)
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) / reps
+            f_ms = timed(5)
+            os.environ["VISFD_HIP_GAUSS_3PASS"] = "1"
+            try:
+                p_ms = timed(3) / 3.0
+            finally:
+                del os.environ["VISFD_HIP_GAUSS_3PASS"]
+            nv2 = n2 ** 3
+            roofline_2048 = {
+                "bound": "hbm", "workload": "separable 3-D Gaussian, sigma=2 (h=5), 2048^3 float32 (32 GiB)",
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes": 8 * nv2,
+                "single_sweep": {"kernel": "gauss_fused_kernel<H=5>", "ms_per_launch": round(f_ms, 3),
+                                 "achieved": round(8.0 * nv2 / (f_ms * 1e-3) / 1e9, 1),
+                                 "frac": round(8.0 * nv2 / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                "one_pass": {"kernel": "conv_march_kernel<5> / conv_row_kernel<5> (average of the Z, Y, X launches)",
+                             "ms_per_launch": round(p_ms, 3), "achieved": round(8.0 * nv2 / (p_ms * 1e-3) / 1e9, 1),
+                             "frac": round(8.0 * nv2 / (p_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+            del big, bout
+
     if rank == 0:
         out = {
             "metric": "Mvoxels/s (Gauss+DoG+TV pipeline) on %d^3 float32; %% HBM roofline" % S,
@@ -317,6 +360,7 @@ def main():
             "roofline": roofline,
             "roofline_pass": roofline_pass,
             "roofline_tv": roofline_tv,
+            "roofline_2048": roofline_2048,
         }
         if not args.no_cpu and world == 1:  # the CPU baseline is an N=1 line only
             try:

@@ -65,13 +65,13 @@ def test_gauss_dog_log_seeded(ctx, oracle):
     assert_bits_equal(o, g["dog_nomask"], "dog")
 
 
-@pytest.mark.parametrize("shape", [(40, 50, 70), (33, 17, 129), (7, 9, 200), (64, 64, 64)])
+@pytest.mark.parametrize("shape", [(40, 50, 70), (33, 17, 129), (7, 9, 200), (64, 64, 64), (20, 45, 136)])
 @pytest.mark.parametrize("h", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12])
 def test_gauss_fused_vs_oracle(ctx, oracle, shape, h):
-    """Every fused-kernel instantiation (isotropic window h=1..10) and the 3-pass path (h=12),
-    on shapes with ragged tiles, against the oracle, with and without normalisation."""
-    if h > 6 and shape != (40, 50, 70):
-        pytest.skip("wide windows: one shape is enough")
+    """Every single-sweep instantiation (isotropic window h=1..8; nx a multiple of 4) and the 3-pass path (other
+    widths, h > 8), on shapes with ragged tiles, against the oracle, with and without normalisation."""
+    if h > 6 and shape not in ((40, 50, 70), (20, 45, 136)):
+        pytest.skip("wide windows: two shapes (3-pass and single-sweep) are enough")
     src = volgen.noise_volume(shape, seed=1000 + h)
     sigma = (h / 2.6,) * 3
     for norm in (True, False):
@@ -79,6 +79,70 @@ def test_gauss_fused_vs_oracle(ctx, oracle, shape, h):
         b, B = oracle.gauss_hw(src, sigma, (h, h, h), None, norm)
         assert_bits_equal(a, b, "gauss h=%d shape=%s norm=%d" % (h, shape, norm))
         assert A == B
+
+
+@pytest.mark.parametrize("h", [2, 5, 7])
+def test_gauss_fused_extreme_magnitudes(ctx, oracle, h):
+    """The single-sweep kernel divides by the boundary normaliser through a reciprocal with exact residual
+    corrections where that is provably the IEEE quotient and through the full-range division elsewhere (zeros,
+    denormals, huge and tiny magnitudes, the first/last h planes): every mixture must give the reference's bits."""
+    rng = np.random.default_rng(900 + h)
+    shape = (48, 40, 136)
+    n = int(np.prod(shape))
+    cases = {
+        "wide": (rng.choice([-1.0, 1.0], n) * 10.0 ** rng.uniform(-37.0, 37.0, n)),
+        "tiny": (rng.choice([-1.0, 1.0], n) * 10.0 ** rng.uniform(-44.0, -28.0, n)),       # denormals included
+        "huge": (rng.choice([-1.0, 1.0], n) * 10.0 ** rng.uniform(28.0, 37.5, n)),
+        "sparse": np.where(rng.random(n) < 0.97, 0.0, rng.normal(0.0, 50.0, n)),
+        "neg": -np.abs(rng.normal(1000.0, 100.0, n)),
+    }
+    sigma = (h / 2.6,) * 3
+    with np.errstate(over="ignore", under="ignore"):
+        for name, v in cases.items():
+            src = np.ascontiguousarray(v.astype(np.float32).reshape(shape))
+            src[~np.isfinite(src)] = 0.0
+            a, _ = ctx.gauss_hw(src, sigma, (h, h, h), None, True)
+            b, _ = oracle.gauss_hw(src, sigma, (h, h, h), None, True)
+            fin = np.isfinite(b)    # sums of huge values may overflow: NaN/Inf voxels are out of contract
+            assert_bits_equal(np.where(fin, a, 0).astype(np.float32), np.where(fin, b, 0).astype(np.float32),
+                              "gauss h=%d %s magnitudes" % (h, name))
+
+
+def _oracle_separable(oracle, src, taps, normalize):
+    import ctypes as C
+    fp = C.POINTER(C.c_float)
+    nz, ny, nx = src.shape
+    out = np.empty_like(src)
+    oracle.lib.vo_separable3d.restype = C.c_float
+    oracle.lib.vo_separable3d.argtypes = [fp, fp, fp, C.c_int, C.c_int, C.c_int, fp, C.c_int, fp, C.c_int, fp,
+                                          C.c_int, C.c_int]
+    h = [(len(t) - 1) // 2 for t in taps]
+    A = oracle.lib.vo_separable3d(src.ctypes.data_as(fp), out.ctypes.data_as(fp), None, nx, ny, nz,
+                                  taps[0].ctypes.data_as(fp), h[0], taps[1].ctypes.data_as(fp), h[1],
+                                  taps[2].ctypes.data_as(fp), h[2], int(normalize))
+    return out, A
+
+
+def test_separable_symmetric_signed_taps(ctx, oracle):
+    """Symmetric taps with negative lobes and zero samples through the single-sweep kernel (its Z pass shares the
+    products of the taps +j and -j); Z taps that are not symmetric take the three single-axis kernels; a positive
+    non-Gaussian window also with the boundary normaliser."""
+    rng = np.random.default_rng(31)
+    shape = (30, 44, 72)
+    src = volgen.noise_volume(shape, seed=77)
+    src[rng.random(shape) < 0.3] = 0.0
+    for h in (3, 6):
+        half = rng.normal(0.0, 1.0, h + 1).astype(np.float32)
+        sym = np.ascontiguousarray(np.concatenate([half[:0:-1], half]), np.float32)
+        asym = rng.normal(0.0, 1.0, 2 * h + 1).astype(np.float32)
+        tri = np.ascontiguousarray(np.concatenate([np.arange(1, h + 1), [h + 1], np.arange(h, 0, -1)]), np.float32)
+        tri /= np.float32(tri.sum() * 1.01)
+        for taps, norm in (([sym, asym, sym], False), ([sym, sym, asym], False), ([tri, sym, tri], False),
+                           ([tri, tri, tri], True)):
+            a, A = ctx.separable3d(src, taps, None, norm)
+            b, B = _oracle_separable(oracle, src, taps, norm)
+            assert_bits_equal(a, b, "generic taps h=%d norm=%d" % (h, norm))
+            assert A == B
 
 
 def test_gauss_masked_vs_oracle(ctx, oracle):
