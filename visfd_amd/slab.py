@@ -160,6 +160,35 @@ def membrane_detect_slab(ops, layout, src, sal, dirs, tensor, sigma, tv_sigma_ra
     return thr
 
 
+def _all_gather_rows(like, arrays, group=None):
+    """Concatenate, on every rank, the ranks' float32 row lists (one all-gather of the row counts, one of a
+    padded row block; device tensors over RCCL, host tensors over gloo -- no pickling of multi-megabyte lists)."""
+    world = dist.get_world_size(group)
+    on_dev = like.is_cuda and dist.get_backend(group) == "nccl"
+    dev = like.device if on_dev else torch.device("cpu")
+    ncol = arrays[0].shape[1]
+    counts = torch.tensor([a.shape[0] for a in arrays], dtype=torch.int64, device=dev)
+    all_counts = [torch.empty_like(counts) for _ in range(world)]
+    dist.all_gather(all_counts, counts, group=group)
+    all_counts = [c.cpu().numpy() for c in all_counts]
+    rows_max = max(int(c.sum()) for c in all_counts)
+    block = torch.zeros((max(rows_max, 1), ncol), dtype=torch.float32, device=dev)
+    mine = np.concatenate([np.ascontiguousarray(a, np.float32).reshape(-1, ncol) for a in arrays], 0)
+    if mine.shape[0]:
+        block[:mine.shape[0]] = torch.from_numpy(mine).to(dev)
+    blocks = [torch.empty_like(block) for _ in range(world)]
+    dist.all_gather(blocks, block, group=group)
+    blocks = [b.cpu().numpy() for b in blocks]
+    out = []
+    for i in range(len(arrays)):
+        parts = []
+        for r in range(world):
+            start = int(all_counts[r][:i].sum())
+            parts.append(blocks[r][start:start + int(all_counts[r][i])])
+        out.append(np.concatenate(parts, 0))
+    return out
+
+
 def blob_detect_slab(ops, layout, src, sigmas, truncate_threshold=0.03, delta=0.02, minima_threshold=np.inf,
                      maxima_threshold=-np.inf, use_ratios=False, group=None, cap=1 << 22):
     """BlobDog (feature.hpp:53-427) on one slab: LoG volumes are computed on the stored planes, the
@@ -181,10 +210,7 @@ def blob_detect_slab(ops, layout, src, sigmas, truncate_threshold=0.03, delta=0.
 
     mins, maxs = own(mins), own(maxs)
     if L.world > 1:
-        gathered = [None] * L.world
-        dist.all_gather_object(gathered, (mins, maxs), group=group)
-        mins = np.concatenate([g[0] for g in gathered], 0)
-        maxs = np.concatenate([g[1] for g in gathered], 0)
+        mins, maxs = _all_gather_rows(src, (mins, maxs), group)
     inf = np.float32(np.inf)
     tmin, tmax = np.float32(minima_threshold), np.float32(maxima_threshold)
     if use_ratios:  # feature.hpp:369-372 with the global best scores
