@@ -57,7 +57,7 @@ int visfd_hip_synchronize(visfd_hip_ctx* ctx);
 /* release the cached workspace (it otherwise persists between calls) */
 int visfd_hip_trim(visfd_hip_ctx* ctx);
 const char* visfd_hip_last_error(void);
-int visfd_hip_abi_version(void);   /* 2: entry points only get added between versions */
+int visfd_hip_abi_version(void);   /* 3: entry points only get added between versions */
 /* bytes of device workspace currently held by the context */
 int64_t visfd_hip_workspace_bytes(visfd_hip_ctx* ctx);
 
@@ -209,6 +209,13 @@ int visfd_hip_principal_directions_host(const float* tensor, const float* mask, 
 int visfd_hip_tensor_saliency_host(const float* tensor, const float* mask, int64_t nvox, int order,
                                    float* saliency);
 
+/* DiagonalizeFlatSym3 (lib/visfd/eigen3_simple.hpp:271-342) of n interleaved flat matrices [n][6] ->
+ * [n][lambda0,lambda1,lambda2, shoemake0..2] on the HOST, bit-identical to the reference (the form a caller uses
+ * per voxel inside their own loops; visfd_hip_diagonalize_flat_sym3 is the device batch). order 0/1. */
+int visfd_hip_diagonalize_flat_sym3_host(const float* m6, float* out6, int64_t n, int eival_order);
+/* ConvertFlatSym2Evects3<float> (lib/visfd/eigen3_simple.hpp:392-405; decode lib/visfd/lin3_utils.hpp:566-584):
+ * one flat symmetric matrix -> eigenvalues and eigenvectors as rows (row-major 3x3), host. */
+int visfd_hip_convert_flat_sym2_evects3_host(const float* m6, int eival_order, float* eivals3, float* eivects9);
 /* DiagonalizeSym3<float> (lib/visfd/eigen3_simple.hpp:137-266) on the host: m9 = symmetric 3x3, row-major;
  * eivects9 = eigenvectors as rows; order 0..3 = INCREASING, DECREASING, INCREASING_ABS, DECREASING_ABS_EIVALS. */
 int visfd_hip_diagonalize_sym3_f32_host(const float* m9, int order, float* eivals3, float* eivects9);

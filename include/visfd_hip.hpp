@@ -490,7 +490,43 @@ typedef enum eEigenOrderType {
   INCREASING_EIVALS = VISFD_HIP_INCREASING_EIVALS,
   DECREASING_EIVALS = VISFD_HIP_DECREASING_EIVALS
 } EigenOrderType;
+
+// ---- DiagonalizeFlatSym3: lib/visfd/eigen3_simple.hpp:271-275 (one flat matrix, on the host) -------------
+// source = {xx,yy,zz,xy,yz,xz}; dest = {lambda0,lambda1,lambda2, shoemake0..2}.  For whole volumes use the batch
+// entry points of the C ABI (visfd_hip_diagonalize_flat_sym3 / visfd_hip_ridge_saliency) instead of a voxel loop.
+inline void DiagonalizeFlatSym3(const float* source, float* dest, EigenOrderType eival_order = INCREASING_EIVALS) {
+  hip_detail::check(visfd_hip_diagonalize_flat_sym3_host(source, dest, 1, (int)eival_order));
+}
+
+// ---- ConvertFlatSym2Evects3: lib/visfd/eigen3_simple.hpp:392-405 -----------------------------------------
+inline void ConvertFlatSym2Evects3(const float m[6], float eivals[3], float eivects[3][3],
+                                   EigenOrderType eival_order = INCREASING_EIVALS) {
+  hip_detail::check(visfd_hip_convert_flat_sym2_evects3_host(m, (int)eival_order, eivals, &eivects[0][0]));
+}
 }  // namespace selfadjoint_eigen3
+
+// ---- a11 scores of a diagonalised matrix: lib/visfd/feature.hpp:1526-1561, :1570-1581, :1591-1598, :1608-1612
+template <typename TensorContainer, typename VectorContainer = const float*>
+inline double ScoreHessianPlanar(TensorContainer diagonalizedHessian, VectorContainer = nullptr) {
+  const double lambda1 = diagonalizedHessian[0], lambda2 = diagonalizedHessian[1];
+  double N = lambda1 * lambda1 - lambda2 * lambda2;
+  N *= N;
+  return N;
+}
+template <typename TensorContainer, typename VectorContainer = const float*>
+inline double ScoreHessianLinear(TensorContainer diagonalizedHessian, VectorContainer = nullptr) {
+  const double lambda1 = diagonalizedHessian[0], lambda2 = diagonalizedHessian[1], lambda3 = diagonalizedHessian[2];
+  return lambda1 * lambda2 - lambda3 * lambda3;
+}
+template <typename TensorContainer>
+inline double ScoreTensorPlanar(const TensorContainer diagonalizedMatrix3) {
+  const double lambda1 = diagonalizedMatrix3[0], lambda2 = diagonalizedMatrix3[1];
+  return lambda1 - lambda2;
+}
+template <typename TensorContainer>
+inline double ScoreTensorLinear(const TensorContainer diagonalizedMatrix3) {
+  return ScoreHessianLinear(diagonalizedMatrix3, (const float*)nullptr);   // feature.hpp:1608-1612
+}
 
 // ---- CalcHessian: lib/visfd/feature.hpp:1203-1219 --------------------------------------------------------
 // Containers as HandleTV instantiates them (bin/filter_mrc/handlers.cpp:1547-1565): gradient as

@@ -75,6 +75,7 @@ class CpuLib:
                                                 C.c_int64]),
                 "trace_product_sym3": (C.c_float, [_fp, _fp]),
                 "diagonalize_sym3_f32": (None, [_fp, C.c_int, _fp, _fp]),
+                "convert_flat_sym2_evects3": (None, [_fp, C.c_int, _fp, _fp]),
                 "sphere_overlap": (C.c_float, [C.c_float, C.c_float, C.c_float]),
                 "sort_blobs": (None, [_fp, _fp, _fp, C.c_int64, C.c_int, C.c_int, _up]),
                 "discard_masked_blobs": (C.c_int64, [_fp, _fp, _fp, C.c_int64, _fp, C.c_int, C.c_int, C.c_int]),
@@ -256,6 +257,15 @@ class CpuLib:
         mf, vf, ef = m.reshape(-1, 9), vals.reshape(-1, 3), vecs.reshape(-1, 9)
         for i in range(len(mf)):
             self._fn["diagonalize_sym3_f32"](_f(mf[i]), int(order), _f(vf[i]), _f(ef[i]))
+        return vals, vecs
+
+    def convert_flat_sym2_evects3(self, m6, order):
+        m6 = np.ascontiguousarray(m6, np.float32)
+        vals = np.empty(m6.shape[:-1] + (3,), np.float32)
+        vecs = np.empty(m6.shape[:-1] + (3, 3), np.float32)
+        mf, vf, ef = m6.reshape(-1, 6), vals.reshape(-1, 3), vecs.reshape(-1, 9)
+        for i in range(len(mf)):
+            self._fn["convert_flat_sym2_evects3"](_f(mf[i]), int(order), _f(vf[i]), _f(ef[i]))
         return vals, vecs
 
     def trace_product_sym3(self, a, b):

@@ -402,6 +402,13 @@ void vr_diagonalize_sym3_f32(const float* m9, int order, float* eivals3, float* 
   for (int i = 0; i < 9; i++) eivects9[i] = E[i / 3][i % 3];
 }
 
-int vr_version() { return 5; }
+// eigen3_simple.hpp:392-405 instantiated for float: eigenvalues + eigenvectors (rows) of a flat symmetric matrix
+void vr_convert_flat_sym2_evects3(const float* m6, int order, float* eivals3, float* eivects9) {
+  float E[3][3];
+  selfadjoint_eigen3::ConvertFlatSym2Evects3(m6, eivals3, E, (selfadjoint_eigen3::EigenOrderType)order);
+  for (int i = 0; i < 9; i++) eivects9[i] = E[i / 3][i % 3];
+}
+
+int vr_version() { return 6; }
 
 }  // extern "C"

@@ -1,5 +1,6 @@
 // Compiled and run by tests/test_abi.py: the C++11 shim (include/visfd_hip.hpp) must compile with -Wall under g++ and
 // its host-side entry points (no GPU needed) must work through the reference's own signatures.
+#include <cmath>
 #include <cstdio>
 
 #include "visfd_hip.hpp"
@@ -45,6 +46,20 @@ int main() {
   std::vector<size_t> perm;
   SortBlobs(crds, diam, score, SORT_DECREASING, false, &perm);   // descending by signed score
   if (!(score[0] == -2.0f && perm.size() == 2 && perm[0] == 1)) return 3;
+  // per-voxel eigen helpers (eigen3_simple.hpp:271, :392; feature.hpp:1526-1612): a diagonal matrix has its
+  // entries as eigenvalues, decreasing order puts the largest first, and the eigenvector rows are orthonormal
+  const float m6[6] = {2.0f, 5.0f, -1.0f, 0.0f, 0.0f, 0.0f};
+  float d6[6], ev[3], E[3][3];
+  selfadjoint_eigen3::DiagonalizeFlatSym3(m6, d6, selfadjoint_eigen3::DECREASING_EIVALS);
+  selfadjoint_eigen3::ConvertFlatSym2Evects3(m6, ev, E, selfadjoint_eigen3::DECREASING_EIVALS);
+  std::printf("eigen %g %g %g planar %g stick %g\n", d6[0], d6[1], d6[2], ScoreHessianPlanar(d6), ScoreTensorPlanar(d6));
+  if (!(d6[0] == 5.0f && d6[1] == 2.0f && d6[2] == -1.0f && ev[0] == 5.0f)) return 4;
+  if (!(ScoreHessianPlanar(d6) == 441.0 && ScoreTensorPlanar(d6) == 3.0 && ScoreTensorLinear(d6) == 9.0)) return 5;
+  for (int a = 0; a < 3; a++)
+    for (int b = 0; b < 3; b++) {
+      float dot = E[a][0] * E[b][0] + E[a][1] * E[b][1] + E[a][2] * E[b][2];
+      if (std::fabs(dot - (a == b ? 1.0f : 0.0f)) > 1e-5f) return 6;
+    }
   Dealloc3D(sal);
   Dealloc3D(lab);
   return 0;

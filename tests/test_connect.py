@@ -149,3 +149,29 @@ def test_diagonalize_sym3_float_equals_reference(ref):
         wv, we = ref.diagonalize_sym3_f32(m, order)
         assert np.array_equal(gv.view(np.uint32), wv.view(np.uint32)), "eigenvalues, order %d" % order
         assert np.array_equal(ge.view(np.uint32), we.view(np.uint32)), "eigenvectors, order %d" % order
+
+
+def test_flat_sym3_host_helpers_match_reference(ref):
+    """DiagonalizeFlatSym3 / ConvertFlatSym2Evects3 on the host: eigenvalues, Shoemake triple and all
+    three eigenvector rows bit for bit against the compiled reference, both orders, including diagonal,
+    degenerate and rank-one matrices."""
+    from visfd_amd import api
+    rng = np.random.default_rng(77)
+    m = rng.normal(0.0, 1.0, (300, 6)).astype(np.float32)
+    m[200:220, 3:] = 0.0                                     # diagonal matrices
+    m[220:240] = 0.0
+    m[220:240, :3] = rng.normal(0.0, 1.0, (20, 1)).astype(np.float32)   # multiples of the identity
+    v = rng.normal(0.0, 1.0, (20, 3)).astype(np.float32)
+    for k in range(20):                                      # rank one: two equal eigenvalues
+        o = np.outer(v[k], v[k]).astype(np.float32)
+        m[240 + k] = [o[0, 0], o[1, 1], o[2, 2], o[0, 1], o[1, 2], o[0, 2]]
+    m[260:280] *= np.float32(1e12)
+    m[280:300] *= np.float32(1e-12)
+    for order in (0, 1):
+        want = ref.diagonalize(m, order)
+        got = api.diagonalize_flat_sym3_host(m, order)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "DiagonalizeFlatSym3, order %d" % order
+        gv, ge = api.convert_flat_sym2_evects3_host(m, order)
+        wv, we = ref.convert_flat_sym2_evects3(m, order)
+        assert np.array_equal(gv.view(np.uint32), wv.view(np.uint32)), "eigenvalues, order %d" % order
+        assert np.array_equal(ge.view(np.uint32), we.view(np.uint32)), "eigenvector rows, order %d" % order

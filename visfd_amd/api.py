@@ -104,6 +104,8 @@ _SIGS = {
     "visfd_hip_principal_directions_host": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp]),
     "visfd_hip_tensor_saliency_host": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp]),
     "visfd_hip_diagonalize_sym3_f32_host": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "visfd_hip_diagonalize_flat_sym3_host": (C.c_int, [_vp, _vp, _i64, C.c_int]),
+    "visfd_hip_convert_flat_sym2_evects3_host": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "visfd_hip_surface_points": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, C.c_int, _fp, C.c_float, C.c_int, C.c_float,
                                            _vp, _vp, _i64, C.POINTER(_i64)]),
     "visfd_hip_sphere_overlap": (C.c_float, [C.c_float, C.c_float, C.c_float]),
@@ -253,6 +255,28 @@ def diagonalize_sym3_f32_host(m, order):
     mf, vf, ef = m.reshape(-1, 9), vals.reshape(-1, 3), vecs.reshape(-1, 9)
     for i in range(len(mf)):
         _chk_host(L, L.visfd_hip_diagonalize_sym3_f32_host(mf[i].ctypes.data, int(order), vf[i].ctypes.data, ef[i].ctypes.data))
+    return vals, vecs
+
+
+def diagonalize_flat_sym3_host(m6, order):
+    """DiagonalizeFlatSym3 (eigen3_simple.hpp:271-342) of [..., 6] flat matrices on the host -> [..., 6]."""
+    L = load_library()
+    m6 = np.ascontiguousarray(m6, np.float32)
+    out = np.empty_like(m6)
+    _chk_host(L, L.visfd_hip_diagonalize_flat_sym3_host(m6.ctypes.data, out.ctypes.data, int(m6.size // 6), int(order)))
+    return out
+
+
+def convert_flat_sym2_evects3_host(m6, order):
+    """ConvertFlatSym2Evects3<float> of [..., 6] flat matrices -> (eivals [..., 3], eivects [..., 3, 3] rows)."""
+    L = load_library()
+    m6 = np.ascontiguousarray(m6, np.float32)
+    vals = np.empty(m6.shape[:-1] + (3,), np.float32)
+    vecs = np.empty(m6.shape[:-1] + (3, 3), np.float32)
+    mf, vf, ef = m6.reshape(-1, 6), vals.reshape(-1, 3), vecs.reshape(-1, 9)
+    for i in range(len(mf)):
+        _chk_host(L, L.visfd_hip_convert_flat_sym2_evects3_host(mf[i].ctypes.data, int(order), vf[i].ctypes.data,
+                                                               ef[i].ctypes.data))
     return vals, vecs
 
 

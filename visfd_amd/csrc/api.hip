@@ -205,7 +205,7 @@ using namespace vh;
 
 extern "C" {
 
-int visfd_hip_abi_version(void) { return 2; }   // 2: + blob post-processing, binning, LabelConnected and its host helpers
+int visfd_hip_abi_version(void) { return 3; }   // 2: + blob post-processing, binning, LabelConnected and its host helpers; 3: + host DiagonalizeFlatSym3 / ConvertFlatSym2Evects3
 const char* visfd_hip_last_error(void) { return g_last_error.c_str(); }
 
 int visfd_hip_create(int device, void* stream, visfd_hip_ctx** out) {

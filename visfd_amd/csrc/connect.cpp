@@ -420,6 +420,32 @@ extern "C" int visfd_hip_principal_directions_host(const float* tensor, const fl
   return VISFD_HIP_OK;
 }
 
+// DiagonalizeFlatSym3 (eigen3_simple.hpp:271-342) of n flat matrices on the HOST, bit-identical to the reference
+// (the per-voxel call a library user makes inside their own loops; the device batch is visfd_hip_diagonalize_flat_sym3).
+extern "C" int visfd_hip_diagonalize_flat_sym3_host(const float* m6, float* out6, int64_t n, int order) {
+  if (!m6 || !out6 || n < 0 || order < 0 || order > 1) return vh::fail(VISFD_HIP_EINVAL, "diagonalize_flat_sym3_host: bad argument");
+  parallel_voxels(n, [&](int64_t lo, int64_t hi) {
+    for (int64_t i = lo; i < hi; i++) {
+      float d6[6];
+      vh::eig::diagonalize_flat(m6 + 6 * i, order, d6);
+      for (int c = 0; c < 6; c++) out6[6 * i + c] = d6[c];
+    }
+  });
+  return VISFD_HIP_OK;
+}
+
+// ConvertFlatSym2Evects3<float> (eigen3_simple.hpp:392-405): flat symmetric matrix -> eigenvalues and the
+// eigenvectors as rows, through the same float Shoemake round trip as the reference (host).
+extern "C" int visfd_hip_convert_flat_sym2_evects3_host(const float* m6, int order, float* eivals3, float* eivects9) {
+  if (!m6 || !eivals3 || !eivects9 || order < 0 || order > 1) return vh::fail(VISFD_HIP_EINVAL, "convert_flat_sym2_evects3_host: bad argument");
+  float d6[6], M[3][3];
+  vh::eig::diagonalize_flat(m6, order, d6);
+  vh::eig::shoemake_frame(d6 + 3, M);
+  for (int c = 0; c < 3; c++) eivals3[c] = d6[c];
+  for (int c = 0; c < 9; c++) eivects9[c] = M[c / 3][c % 3];
+  return VISFD_HIP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Oriented surface points (the -normals-file tail of HandleTV, bin/filter_mrc/handlers.cpp:2039-2309).
 // For every unmasked voxel of the selected cluster: follow the (standardized) normal direction forwards and

@@ -226,5 +226,34 @@ VH_HD void shoemake_row0(const float sm[3], float row0[3]) {
   row0[2] = 2 * (q1 * q3 + q2 * q0);
 }
 
+// The whole frame (eigenvectors as rows) recovered from the float Shoemake triple: Shoemake2Quaternion and
+// Quaternion2Matrix instantiated for float (lin3_utils.hpp:310-337, :279-305), where the double literal 1.0
+// promotes the diagonal entries only.  Row 0 is shoemake_row0.
+VH_HD void shoemake_frame(const float sm[3], float M[3][3]) {
+  const float two_pi = 6.283185307179586f;
+  const float X0 = sm[0];
+  const float th1 = two_pi * sm[1], th2 = two_pi * sm[2];
+  const float r1 = (float)sqrt(1.0 - (double)X0);
+  const float r2 = sqrtf(X0);
+  float s1, c1, s2, c2;
+#if defined(__HIP_DEVICE_COMPILE__)
+  sincosf(th1, &s1, &c1);
+  sincosf(th2, &s2, &c2);
+#else
+  s1 = std::sin(th1); c1 = std::cos(th1);
+  s2 = std::sin(th2); c2 = std::cos(th2);
+#endif
+  const float q0 = s1 * r1, q1 = c1 * r1, q2 = s2 * r2, q3 = c2 * r2;
+  M[0][0] = (float)(1.0 - (double)(2 * (q2 * q2)) - (double)(2 * (q3 * q3)));
+  M[1][1] = (float)(1.0 - (double)(2 * (q1 * q1)) - (double)(2 * (q3 * q3)));
+  M[2][2] = (float)(1.0 - (double)(2 * (q1 * q1)) - (double)(2 * (q2 * q2)));
+  M[0][1] = 2 * (q1 * q2 - q3 * q0);
+  M[1][0] = 2 * (q1 * q2 + q3 * q0);
+  M[1][2] = 2 * (q2 * q3 - q1 * q0);
+  M[2][1] = 2 * (q2 * q3 + q1 * q0);
+  M[0][2] = 2 * (q1 * q3 + q2 * q0);
+  M[2][0] = 2 * (q1 * q3 - q2 * q0);
+}
+
 }  // namespace eig
 }  // namespace vh
