@@ -88,6 +88,21 @@ int visfd_hip_apply_gauss_dev(visfd_hip_ctx*, const float* src, float* dst, cons
 /* halfwidth[d] = max(1, floor(sigma[d]*ratio)), lib/visfd/filter3d.hpp:1240-1247 */
 int visfd_hip_gauss_halfwidths(const float sigma[3], float truncate_ratio, int halfwidth_out[3]);
 
+/* ---- f4: LocalFluctuations (lib/visfd/filter3d.hpp:1698-1853) ---------------------------------- */
+/* dst = sqrt(max(A * G((src - G(src))^2), 0)), G = ApplyGauss(sigma[3], truncate_ratio) with the same mask and
+ * normalize flag, A = the central value of GenFilterGenGauss3D(sigma, exponent, truncate_ratio)
+ * (filter3d.hpp:546-640, :1725, :1836).  Only exponent == 2 (the separable case) is provided; src != dst. */
+int visfd_hip_local_fluctuations(visfd_hip_ctx*, const float* src, float* dst, const float* mask,
+                                 int64_t nx, int64_t ny, int64_t nz, const float sigma[3], float exponent,
+                                 float truncate_ratio, int normalize);
+int visfd_hip_local_fluctuations_dev(visfd_hip_ctx*, const float* src, float* dst, const float* mask,
+                                     int64_t nx, int64_t ny, int64_t nz, const float sigma[3], float exponent,
+                                     float truncate_ratio, int normalize);
+/* LocalFluctuationsByRadius (filter3d.hpp:1897-1926; bin/filter_mrc/filter3d_variants.hpp:651-681), host arithmetic:
+ * sigma = radius / (9 pi / 2)^(1/6); a negative truncate_ratio is replaced by (-log threshold)^(1/exponent). */
+int visfd_hip_fluctuation_sigmas(const float radius[3], float exponent, float truncate_ratio,
+                                 float truncate_threshold, float sigma_out[3], float* ratio_out);
+
 /* ---- a6: ApplyDog, lib/visfd/filter3d.hpp:1338-1402 -------------------------------------------- */
 int visfd_hip_apply_dog(visfd_hip_ctx*, const float* src, float* dst, const float* mask,
                         int64_t nx, int64_t ny, int64_t nz, const float sigma_a[3],

@@ -228,6 +228,41 @@ inline void ApplyLog(const int image_size[3], float const* const* const* src, fl
   ApplyLog(image_size, src, dest, mask, s, delta_sigma_over_sigma, truncate_ratio, pA, pB, pReportProgress);
 }
 
+// ---- LocalFluctuations: lib/visfd/filter3d.hpp:1698-1711 (Gaussian weights: exponent must be 2) -------
+inline void LocalFluctuations(const int image_size[3], float const* const* const* src, float*** dest,
+                              float const* const* const* mask, const float sigma[3],
+                              float template_background_exponent = 2, float filter_truncate_ratio = 2.5,
+                              bool normalize = true, std::ostream* = nullptr) {
+  hip_detail::require_contiguous(src, image_size);
+  hip_detail::require_contiguous(dest, image_size);
+  hip_detail::require_contiguous(mask, image_size);
+  hip_detail::check(visfd_hip_local_fluctuations(hip_detail::context(), hip_detail::flat(src), hip_detail::flat(dest),
+                                                 hip_detail::flat(mask), image_size[0], image_size[1], image_size[2],
+                                                 sigma, template_background_exponent, filter_truncate_ratio,
+                                                 normalize ? 1 : 0));
+}
+// ---- LocalFluctuationsByRadius: lib/visfd/filter3d.hpp:1897-1926 and the variant with a decay threshold,
+//      bin/filter_mrc/filter3d_variants.hpp:651-681 (a negative ratio selects the threshold) --------------
+inline void LocalFluctuationsByRadius(const int image_size[3], float const* const* const* src, float*** dest,
+                                      float const* const* const* mask, const float radius[3],
+                                      float template_background_exponent, float filter_truncate_ratio,
+                                      float filter_truncate_threshold, bool normalize = true,
+                                      std::ostream* pReportProgress = nullptr) {
+  float sigma[3], ratio;
+  hip_detail::check(visfd_hip_fluctuation_sigmas(radius, template_background_exponent, filter_truncate_ratio,
+                                                 filter_truncate_threshold, sigma, &ratio));
+  LocalFluctuations(image_size, src, dest, mask, sigma, template_background_exponent, ratio, normalize,
+                    pReportProgress);
+}
+inline void LocalFluctuationsByRadius(const int image_size[3], float const* const* const* src, float*** dest,
+                                      float const* const* const* mask, const float radius[3],
+                                      float template_background_exponent = 2, float filter_truncate_ratio = 2.5,
+                                      bool normalize = true, std::ostream* pReportProgress = nullptr) {
+  // a non-negative ratio is taken as is (the threshold argument is then unused)
+  LocalFluctuationsByRadius(image_size, src, dest, mask, radius, template_background_exponent,
+                            filter_truncate_ratio < 0 ? 0.0f : filter_truncate_ratio, 0.02f, normalize, pReportProgress);
+}
+
 // ---- BlobDog: lib/visfd/feature.hpp:53-77 --------------------------------------------------------------
 // The optional preallocated-images argument of the reference (aaaafI) is accepted and ignored: the
 // rolling LoG volumes live in HBM.

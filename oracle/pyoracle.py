@@ -63,6 +63,7 @@ class CpuLib:
             "tv_dense_stick": (None, [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
                                       C.c_float, C.c_int, C.c_int]),
             "tensor_saliency": (None, [_fp, _fp, C.c_int64, C.c_int, _fp]),
+            "local_fluctuations": (None, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, C.c_float, C.c_float, C.c_int]),
             "bin_array3d": (C.c_int, [_fp, _ip, _fp, _ip, _ip]),
             "unbin_array3d": (C.c_int, [_fp, _ip, _fp, _ip, _ip]),
         }
@@ -104,6 +105,14 @@ class CpuLib:
         dst = np.empty_like(src)
         A = self._fn["apply_gauss_hw"](_f(src), _f(dst), _f(mask), nx, ny, nz, _f3(sigma), _i3(hw), int(normalize))
         return dst, float(A)
+
+    def local_fluctuations(self, src, sigma, ratio, mask=None, normalize=True, exponent=2.0):
+        nz, ny, nx = src.shape
+        dst = np.empty_like(src)
+        sg = np.asarray(sigma, np.float32)
+        self._fn["local_fluctuations"](_f(src), _f(dst), _f(mask), nx, ny, nz, _f(sg), float(exponent), float(ratio),
+                                       int(normalize))
+        return dst
 
     def gauss_ratio(self, src, sigma, ratio, mask=None, normalize=True):
         nz, ny, nx = src.shape

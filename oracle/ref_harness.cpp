@@ -409,6 +409,16 @@ void vr_convert_flat_sym2_evects3(const float* m6, int order, float* eivals3, fl
   for (int i = 0; i < 9; i++) eivects9[i] = E[i / 3][i % 3];
 }
 
-int vr_version() { return 6; }
+// filter3d.hpp:1698-1853
+void vr_local_fluctuations(const float* src, float* dst, const float* mask, int nx, int ny, int nz,
+                           const float sigma[3], float exponent, float ratio, int normalize) {
+  int size[3] = {nx, ny, nz};
+  View3<float> s(const_cast<float*>(src), nx, ny, nz), d(dst, nx, ny, nz),
+      m(const_cast<float*>(mask), nx, ny, nz);
+  float sg[3] = {sigma[0], sigma[1], sigma[2]};
+  LocalFluctuations<float>(size, (cf3)s.p, d.p, (cf3)m.p, sg, exponent, ratio, normalize != 0, nullptr);
+}
+
+int vr_version() { return 7; }
 
 }  // extern "C"

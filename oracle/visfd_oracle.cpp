@@ -487,6 +487,43 @@ float vo_apply_gauss_ratio(const float* src, float* dst, const float* mask, int 
   return gauss_hw(src, dst, mask, nx, ny, nz, sigma, hw, normalize != 0);
 }
 
+// lib/visfd/filter3d.hpp:1698-1853 (LocalFluctuations, Gaussian weights) with the peak value of the generalised
+// Gaussian window of :546-640 restated: dst = sqrt(max(A * G((src - G src)^2), 0))
+void vo_local_fluctuations(const float* src, float* dst, const float* mask, int nx, int ny, int nz,
+                           const float sigma[3], float exponent, float ratio, int normalize) {
+  const i64 n = (i64)nx * ny * nz;
+  int hw3[3];
+  for (int d = 0; d < 3; d++) hw3[d] = (int)std::floor(sigma[d] * ratio);
+  float cut = 1.0f;
+  for (int d = 0; d < 3; d++) {
+    const float e = (sigma[d] > 0) ? std::exp(-std::pow(hw3[d] / sigma[d], exponent)) : 1.0f;
+    if (e < cut) cut = e;
+  }
+  float total = 0;
+  for (int iz = -hw3[2]; iz <= hw3[2]; iz++)
+    for (int iy = -hw3[1]; iy <= hw3[1]; iy++)
+      for (int ix = -hw3[0]; ix <= hw3[0]; ix++) {
+        const float x = (sigma[0] == 0.0f && ix == 0) ? 0.0f : ix / sigma[0];
+        const float y = (sigma[1] == 0.0f && iy == 0) ? 0.0f : iy / sigma[1];
+        const float z = (sigma[2] == 0.0f && iz == 0) ? 0.0f : iz / sigma[2];
+        const float r = std::sqrt(x * x + y * y + z * z);
+        float v = (r > 0) ? std::exp(-std::pow(r, exponent)) : 1.0f;
+        if (std::fabs(v) < cut) v = 0.0f;
+        total += v;
+      }
+  const float wpeak = 1.0f / total;
+  std::vector<float> p(n);
+  vo_apply_gauss_ratio(src, p.data(), mask, nx, ny, nz, sigma, ratio, normalize);
+  for (i64 i = 0; i < n; i++) p[i] = src[i] - p[i];
+  for (i64 i = 0; i < n; i++) p[i] *= p[i];
+  vo_apply_gauss_ratio(p.data(), dst, mask, nx, ny, nz, sigma, ratio, normalize);
+  for (i64 i = 0; i < n; i++) {
+    float v = dst[i] * wpeak;
+    if (v < 0.0f) v = 0.0f;
+    dst[i] = std::sqrt(v);
+  }
+}
+
 // lib/visfd/filter3d.hpp:1338-1402
 void vo_apply_dog(const float* src, float* dst, const float* mask, int nx, int ny, int nz,
                   const float sigma_a[3], const float sigma_b[3], const int hw[3], float* pA,
@@ -854,6 +891,6 @@ int vo_unbin_array3d(const float* src, const int* ssz, float* dst, const int* ds
   return 0;
 }
 
-int vo_version() { return 2; }
+int vo_version() { return 3; }
 
 }  // extern "C"

@@ -231,6 +231,10 @@ def both(cli, ref_cli, tmp_path, args, out_name="out.rec"):
     ["-dog", 30, 48, "-w", 19.6],
     ["-log-d", 120, "-w", 19.6, "-mask", os.path.join(GOLDEN, "test_blob_detect_mask.rec")],
     ["-gauss", 60, "-w", 19.6, "-bin", 2],
+    ["-fluct", 80, "-w", 19.6],
+    ["-fluct", 4, "-w", 1, "-mask", os.path.join(GOLDEN, "test_blob_detect_mask.rec")],
+    ["-fluct-aniso", 60, 90, 50, "-w", 19.6, "-truncate", 2.2],
+    ["-fluctuations", 70, "-w", 19.6, "-truncate-threshold", 0.1, "-normalize-filters", "no"],
 ])
 def test_cli_filters_equal_reference_program(cli, ref_cli, tmp_path, flags):
     mine, ref = both(cli, ref_cli, tmp_path, ["-in", os.path.join(GOLDEN, "test_blob_detect.rec")] + flags)

@@ -49,6 +49,9 @@ _SIGS = {
     "visfd_hip_workspace_bytes": (_i64, [_vp]),
     "visfd_hip_gauss_taps": (C.c_int, [C.c_float, C.c_int, _fp]),
     "visfd_hip_ratio_from_threshold": (C.c_float, [C.c_float]),
+    "visfd_hip_local_fluctuations": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _fp, C.c_float, C.c_float, C.c_int]),
+    "visfd_hip_local_fluctuations_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _fp, C.c_float, C.c_float, C.c_int]),
+    "visfd_hip_fluctuation_sigmas": (C.c_int, [_fp, C.c_float, C.c_float, C.c_float, _fp, C.POINTER(C.c_float)]),
     "visfd_hip_gauss_halfwidths": (C.c_int, [_fp, C.c_float, _ip]),
     "visfd_hip_separable3d": (C.c_int, [_vp] + _VOL + [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, _fp]),
     "visfd_hip_separable3d_dev": (C.c_int, [_vp] + _VOL + [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, _fp]),
@@ -183,6 +186,16 @@ def gauss_halfwidths(sigma, ratio):
     hw = (C.c_int * 3)()
     load_library().visfd_hip_gauss_halfwidths(_f3(sigma), float(ratio), hw)
     return tuple(hw)
+
+
+def fluctuation_sigmas(radius, exponent=2.0, truncate_ratio=-1.0, truncate_threshold=0.03):
+    """LocalFluctuationsByRadius' parameter arithmetic (filter3d.hpp:1908-1914, filter3d_variants.hpp:663-669):
+    -> (sigma[3], ratio)."""
+    sg = (C.c_float * 3)()
+    r = C.c_float()
+    load_library().visfd_hip_fluctuation_sigmas(_f3(radius), float(exponent), float(truncate_ratio),
+                                                float(truncate_threshold), sg, C.byref(r))
+    return tuple(sg), r.value
 
 
 def tv_tables(sigma_tv, cutoff):
@@ -423,6 +436,14 @@ class Context:
     def gauss_ratio(self, src, sigma, ratio, mask=None, normalize=True):
         return self.gauss_hw(src, sigma, gauss_halfwidths(sigma, ratio), mask, normalize)
 
+    def local_fluctuations(self, src, sigma, ratio, mask=None, normalize=True, exponent=2.0):
+        """LocalFluctuations (filter3d.hpp:1698-1853), Gaussian weights."""
+        nz, ny, nx = src.shape
+        dst = np.empty_like(src)
+        self._chk(self._L.visfd_hip_local_fluctuations(self._h, _np(src), _np(dst), _np(mask), nx, ny, nz, _f3(sigma),
+                                                       float(exponent), float(ratio), int(normalize)))
+        return dst
+
     def dog(self, src, sigma_a, sigma_b, hw, mask=None):
         nz, ny, nx = src.shape
         dst = np.empty_like(src)
@@ -546,6 +567,11 @@ class Context:
         self._chk(self._L.visfd_hip_apply_gauss_dev(self._h, _dev(src), _dev(dst), _dev(mask), nx, ny, nz,
                                                     _f3(sigma), _i3(hw), int(normalize), C.byref(A)))
         return A.value
+
+    def local_fluctuations_dev(self, src, dst, sigma, ratio, mask=None, normalize=True, exponent=2.0):
+        nz, ny, nx = src.shape
+        self._chk(self._L.visfd_hip_local_fluctuations_dev(self._h, _dev(src), _dev(dst), _dev(mask), nx, ny, nz,
+                                                           _f3(sigma), float(exponent), float(ratio), int(normalize)))
 
     def gauss_slab_dev(self, src, dst, z_lo, nz_global, sigma, hw, normalize=True):
         nz, ny, nx = src.shape

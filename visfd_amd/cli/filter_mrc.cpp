@@ -139,8 +139,10 @@ struct Settings {
   int bin = 0;                 // settings.cpp:48-49: 0 = not specified (automatic), else the factor
   bool bin_explicit = false;
   float masked_voxel_brightness = 0.0f;   // settings.cpp:41-42: voxels with mask == 0 get this value in the output
-  enum { NONE, GAUSS, DOG, LOG, BLOB, BLOB_NONMAX, SURFACE_RIDGE } type = NONE;
+  enum { NONE, GAUSS, DOG, LOG, BLOB, BLOB_NONMAX, SURFACE_RIDGE, LOCAL_FLUCTUATIONS } type = NONE;
   float width_a[3] = {0, 0, 0}, width_b[3] = {0, 0, 0}, log_width[3] = {0, 0, 0};
+  float template_background_radius[3] = {-1, -1, -1};        // settings.cpp:222-225 (-fluct)
+  float template_background_exponent = 2.0f;
   float truncate_ratio = -1.0f, truncate_threshold = 0.03f;   // settings.cpp:81,88
   float delta = 0.02f;                                        // settings.cpp:95
   bool normalize = true;
@@ -205,6 +207,16 @@ Settings parse(int argc, char** argv) {
       i += 2;
     }
     else if (f == "-gauss") { need(1); s.width_a[0] = s.width_a[1] = s.width_a[2] = num(v, i + 1, f); s.type = Settings::GAUSS; i += 2; }
+    else if (f == "-fluct" || f == "-fluctuation" || f == "-fluctuations") {     // settings.cpp:2170-2186
+      need(1);
+      s.template_background_radius[0] = s.template_background_radius[1] = s.template_background_radius[2] = num(v, i + 1, f);
+      s.type = Settings::LOCAL_FLUCTUATIONS; s.masked_voxel_brightness = 0.0f; i += 2;
+    }
+    else if (f == "-fluct-aniso" || f == "-fluctuation-aniso" || f == "-fluctuations-aniso") {   // settings.cpp:2138-2156
+      need(3);
+      for (int d = 0; d < 3; d++) s.template_background_radius[d] = num(v, i + 1 + d, f);
+      s.type = Settings::LOCAL_FLUCTUATIONS; s.masked_voxel_brightness = 0.0f; i += 4;
+    }
     else if (f == "-gauss-aniso") { need(3); for (int d = 0; d < 3; d++) s.width_a[d] = num(v, i + 1 + d, f); s.type = Settings::GAUSS; i += 4; }
     else if (f == "-dog") {
       need(2);
@@ -519,7 +531,7 @@ int main(int argc, char** argv) {
       else for (int d = 0; d < 3; d++) vw[d] = tomo_in.cella[d] / size[d];
     }
     cerr << "voxel width = " << vw[0] << "\n";
-    for (int d = 0; d < 3; d++) { s.width_a[d] /= vw[d]; s.width_b[d] /= vw[d]; s.log_width[d] /= vw[d]; }
+    for (int d = 0; d < 3; d++) { s.width_a[d] /= vw[d]; s.width_b[d] /= vw[d]; s.log_width[d] /= vw[d]; s.template_background_radius[d] /= vw[d]; }
     s.tv_sigma /= vw[0];
     for (size_t k = 0; k < s.blob_diameters.size(); k++) s.blob_diameters[k] /= vw[0];
 
@@ -535,6 +547,10 @@ int main(int argc, char** argv) {
       cerr << " Filter Used: A discrete Gaussian kernel, approximately equal to\n"
               " h(x,y,z)   ≈ A*exp(-0.5*((x/σ_x)^2 + (y/σ_y)^2 + (z/σ_z)^2))\n"
               " ... where  A = " << A << "\n";
+    } else if (s.type == Settings::LOCAL_FLUCTUATIONS) {
+      // HandleLocalFluctuations, handlers.cpp:1254-1271
+      LocalFluctuationsByRadius(size, tomo_in.a, tomo_out.a, M, s.template_background_radius,
+                                s.template_background_exponent, s.truncate_ratio, s.truncate_threshold, s.normalize, &cerr);
     } else if (s.type == Settings::DOG) {
       cerr << "filter_type = Difference of Gaussians (DoG)\n";
       // bin/filter_mrc/filter3d_variants.hpp:542-597: each Gaussian has its own window

@@ -344,6 +344,56 @@ int visfd_hip_apply_gauss(visfd_hip_ctx* ctx, const float* src, float* dst, cons
   return download(ctx, dst, dd, n);
 }
 
+// ---- f4: LocalFluctuations (lib/visfd/filter3d.hpp:1698-1853), Gaussian weights only -------
+int visfd_hip_local_fluctuations_dev(visfd_hip_ctx* ctx, const float* src, float* dst, const float* mask,
+                                     int64_t nx, int64_t ny, int64_t nz, const float sigma[3], float exponent,
+                                     float truncate_ratio, int normalize) {
+  VH_REQUIRE(ctx && src && dst && sigma, "null argument");
+  VH_REQUIRE(src != dst, "LocalFluctuations cannot run in place");
+  VH_REQUIRE(exponent == 2.0f, "LocalFluctuations: only the Gaussian case (exponent 2) is provided");
+  VH_HIP(hipSetDevice(ctx->device));
+  VH_TRY(check_dims(nx, ny, nz));
+  const i64 n = nx * ny * nz;
+  int hw[3];
+  VH_TRY(halfwidths_from_ratio(sigma, truncate_ratio, hw));    // ApplyGauss(sigma[3], ratio), filter3d.hpp:1240-1247
+  const float wpeak = host_gengauss3d_peak(sigma, exponent, truncate_ratio);
+  const SlabInfo whole = {0, nz};
+  float* p2 = nullptr;
+  VH_TRY(ws(ctx, WS_C, (size_t)n, &p2));
+  VH_TRY(gauss_dev(ctx, src, dst, mask, nx, ny, nz, sigma, hw, normalize != 0, whole, nullptr));   // local average
+  VH_TRY(dev_sub_square(ctx, src, dst, p2, n));                                                      // (src - avg)^2
+  VH_TRY(gauss_dev(ctx, p2, dst, mask, nx, ny, nz, sigma, hw, normalize != 0, whole, nullptr));    // its local average
+  return dev_scale_clamp_sqrt(ctx, dst, n, wpeak);
+}
+
+int visfd_hip_local_fluctuations(visfd_hip_ctx* ctx, const float* src, float* dst, const float* mask,
+                                 int64_t nx, int64_t ny, int64_t nz, const float sigma[3], float exponent,
+                                 float truncate_ratio, int normalize) {
+  VH_REQUIRE(ctx && src && dst, "null argument");
+  VH_HIP(hipSetDevice(ctx->device));
+  VH_TRY(check_dims(nx, ny, nz));
+  const size_t n = (size_t)(nx * ny * nz);
+  float *ds, *dm, *dd;
+  VH_TRY(upload(ctx, WS_H2D_0, src, n, &ds));
+  VH_TRY(upload(ctx, WS_H2D_1, mask, n, &dm));
+  VH_TRY(ws(ctx, WS_H2D_2, n, &dd));
+  VH_TRY(visfd_hip_local_fluctuations_dev(ctx, ds, dd, dm, nx, ny, nz, sigma, exponent, truncate_ratio, normalize));
+  return download(ctx, dst, dd, n);
+}
+
+// sigma = radius / (9 pi / 2)^(1/6) (filter3d.hpp:1908-1914) and, for a negative ratio, the window from the decay
+// threshold: ratio = (-log thr)^(1/exponent) (bin/filter_mrc/filter3d_variants.hpp:663-669); host arithmetic
+int visfd_hip_fluctuation_sigmas(const float radius[3], float exponent, float truncate_ratio, float truncate_threshold,
+                                 float sigma_out[3], float* ratio_out) {
+  VH_REQUIRE(radius && sigma_out && ratio_out, "null argument");
+  const float r_over_sigma = (float)std::pow((9.0 / 2) * M_PI, 1.0 / 6);
+  for (int d = 0; d < 3; d++) sigma_out[d] = radius[d] / r_over_sigma;
+  float ratio = truncate_ratio;
+  if (ratio < 0.0f) ratio = (float)std::pow((double)(-std::log(truncate_threshold)), 1.0 / (double)exponent);
+  *ratio_out = ratio;
+  return VISFD_HIP_OK;
+}
+
 // ---- a6 ------------------------------------------------------------------------------------
 int visfd_hip_apply_dog_dev(visfd_hip_ctx* ctx, const float* src, float* dst, const float* mask,
                             int64_t nx, int64_t ny, int64_t nz, const float sa[3], const float sb[3],

@@ -92,6 +92,7 @@ void host_gauss_taps(float sigma, int h, float* t);
 void host_conv_ones(i64 n, const float* t, int h, float* out);  // filter applied to a line of ones
 int host_tv_halfwidth(float sigma, float cutoff);
 void host_tv_tables(float sigma, int h, float* w, float* rhat);
+float host_gengauss3d_peak(const float width[3], float m_exp, float ratio);
 
 // ---- device stages (each in its own .hip; all asynchronous on ctx->stream) -------------------
 struct SlabInfo {   // Z-slab placement for multi-GPU runs; whole volume: z_lo=0, nz_global=nz
@@ -107,6 +108,9 @@ int dev_separable3d(visfd_hip_ctx* ctx, const float* src, float* dst, const floa
                     const float* minuend = nullptr, float log_scale = 1.0f, bool* epilogue_done = nullptr);
 // dst = (a - b) * scale  with two roundings (filter3d.hpp:1387-1390,1495-1498); scale==1: no multiply
 int dev_sub_scale(visfd_hip_ctx* ctx, float* a_inout, const float* b, i64 n, float scale, bool do_scale);
+// LocalFluctuations element-wise steps (filter3d.hpp:1776-1790 and :1819-1846)
+int dev_sub_square(visfd_hip_ctx* ctx, const float* a, const float* b, float* out, i64 n);   // out = (a-b)*(a-b)
+int dev_scale_clamp_sqrt(visfd_hip_ctx* ctx, float* a_inout, i64 n, float scale);           // a = sqrt(max(a*scale, 0))
 
 int dev_blob_scan(visfd_hip_ctx* ctx, const float* lo, const float* mid, const float* hi,
                   const float* mask, i64 nx, i64 ny, i64 nz, int scale_index, float sigma,

@@ -240,6 +240,29 @@ sub_scale_kernel(float* __restrict__ a, const float* __restrict__ b, i64 n, floa
   }
 }
 
+// LocalFluctuations, filter3d.hpp:1776-1790: P = source - average; P *= P (two roundings)
+__global__ void __launch_bounds__(BLOCK)
+sub_square_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, i64 n) {
+  i64 i = (i64)blockIdx.x * BLOCK + threadIdx.x;
+  const i64 step = (i64)gridDim.x * BLOCK;
+  for (; i < n; i += step) {
+    const float d = a[i] - b[i];
+    out[i] = d * d;
+  }
+}
+
+// LocalFluctuations, filter3d.hpp:1819-1846: variance *= wpeak; negative -> 0; sqrt (correctly rounded)
+__global__ void __launch_bounds__(BLOCK)
+scale_clamp_sqrt_kernel(float* __restrict__ a, i64 n, float scale) {
+  i64 i = (i64)blockIdx.x * BLOCK + threadIdx.x;
+  const i64 step = (i64)gridDim.x * BLOCK;
+  for (; i < n; i += step) {
+    float v = a[i] * scale;
+    if (v < 0.0f) v = 0.0f;
+    a[i] = sqrtf(v);   // correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt; __fsqrt_rn is not)
+  }
+}
+
 int fill_taps(Taps* T, const float* t, int h) {
   if (h < 0 || h > MAX_HALFWIDTH)
     return fail(VISFD_HIP_EINVAL, "filter halfwidth must be in [0, 64]");
@@ -422,6 +445,20 @@ int dev_separable3d(visfd_hip_ctx* ctx, const float* src, float* dst, const floa
 int dev_sub_scale(visfd_hip_ctx* ctx, float* a, const float* b, i64 n, float scale, bool do_scale) {
   const unsigned g = grid_for(n, BLOCK, (i64)ctx->num_cus * 16);
   sub_scale_kernel<<<dim3(g), dim3(BLOCK), 0, ctx->stream>>>(a, b, n, scale, do_scale ? 1 : 0);
+  VH_HIP(hipGetLastError());
+  return VISFD_HIP_OK;
+}
+
+int dev_sub_square(visfd_hip_ctx* ctx, const float* a, const float* b, float* out, i64 n) {
+  const unsigned g = grid_for(n, BLOCK, (i64)ctx->num_cus * 16);
+  sub_square_kernel<<<dim3(g), dim3(BLOCK), 0, ctx->stream>>>(a, b, out, n);
+  VH_HIP(hipGetLastError());
+  return VISFD_HIP_OK;
+}
+
+int dev_scale_clamp_sqrt(visfd_hip_ctx* ctx, float* a, i64 n, float scale) {
+  const unsigned g = grid_for(n, BLOCK, (i64)ctx->num_cus * 16);
+  scale_clamp_sqrt_kernel<<<dim3(g), dim3(BLOCK), 0, ctx->stream>>>(a, n, scale);
   VH_HIP(hipGetLastError());
   return VISFD_HIP_OK;
 }

@@ -88,4 +88,31 @@ void host_tv_tables(float sigma, int h, float* w, float* rhat) {
   for (size_t k = 0; k < m; k++) w[k] /= total;
 }
 
+// Central value A of the normalised generalised-Gaussian window GenFilterGenGauss3D(width, m, ratio)
+// (reference lib/visfd/filter3d.hpp:546-640): window half-widths floor(width*ratio), entries exp(-r^m) with
+// r = sqrt((x/wx)^2+(y/wy)^2+(z/wz)^2), entries below the smallest face value zeroed, divided by their float sum
+// accumulated in z,y,x order.  LocalFluctuations multiplies its variance by this number (filter3d.hpp:1725,1836).
+float host_gengauss3d_peak(const float width[3], float m_exp, float ratio) {
+  int hw[3];
+  for (int d = 0; d < 3; d++) hw[d] = (int)std::floor(width[d] * ratio);
+  float cut = 1.0f;
+  for (int d = 0; d < 3; d++) {
+    const float e = (width[d] > 0) ? std::exp(-std::pow(hw[d] / width[d], m_exp)) : 1.0f;
+    if (e < cut) cut = e;
+  }
+  float total = 0;
+  for (int iz = -hw[2]; iz <= hw[2]; iz++)
+    for (int iy = -hw[1]; iy <= hw[1]; iy++)
+      for (int ix = -hw[0]; ix <= hw[0]; ix++) {
+        const float x = (width[0] == 0.0f && ix == 0) ? 0.0f : ix / width[0];
+        const float y = (width[1] == 0.0f && iy == 0) ? 0.0f : iy / width[1];
+        const float z = (width[2] == 0.0f && iz == 0) ? 0.0f : iz / width[2];
+        const float r = std::sqrt(x * x + y * y + z * z);
+        float v = (r > 0) ? std::exp(-std::pow(r, m_exp)) : 1.0f;
+        if (std::fabs(v) < cut) v = 0.0f;
+        total += v;
+      }
+  return 1.0f / total;   // the centre entry is 1 before the division by the sum
+}
+
 }  // namespace vh
