@@ -48,6 +48,7 @@ enum Slot {
   WS_HIST,                         // radix-select histograms
   WS_TVTAB,                        // tensor-voting lookup table
   WS_TVAUX,                        // tensor-voting auxiliaries
+  WS_TVSCRATCH,                    // tensor voting: per-workgroup rings of compacted sender planes
   WS_H2D_0, WS_H2D_1, WS_H2D_2, WS_H2D_3, WS_H2D_4,  // staging for the host-pointer face
   WS_NSLOTS
 };

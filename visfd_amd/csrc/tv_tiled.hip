@@ -80,7 +80,7 @@ __device__ __forceinline__ const __attribute__((address_space(3))) T* lds_ptr(un
 
 struct TiledParams {
   int nx, ny, nz;
-  int z_out0;
+  int z_out0, z_out1;    // receiver planes [z_out0, z_out1)
   int h, hp1;            // halfwidth, h+1
   int rw, rh;            // region width/height = TILE + 2h
   int band_rows, nbands;
@@ -88,6 +88,7 @@ struct TiledParams {
   int slice_f4;          // float4 entries of the LDS slice area
   int tiles_x, tiles_y;
   int exponent, curves;
+  int zrun;              // receiver planes per unit of work
 };
 
 __device__ __forceinline__ void acc(float& t, float x) {
@@ -143,7 +144,8 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MODE !=
 tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, float* __restrict__ ten,
                 const float* __restrict__ mask_src, const float* __restrict__ mask_dst,
                 const float4* __restrict__ table /* [(2h+1)^3] : w, rhat_x, rhat_y, rhat_z at j */,
-                TiledParams p, unsigned* __restrict__ tile_counter, unsigned ntiles) {
+                TiledParams p, unsigned* __restrict__ tile_counter, unsigned ntiles,
+                unsigned char* __restrict__ scratch /* per-workgroup rings of compacted sender planes, or null */) {
   // Static LDS (compile-time addresses fold into the DS instructions' immediate offsets):
   // list entry e (32 bytes): float4 {sal, n0, n1, n2} | int e16 | float mask value | pad.
   // Entry CAP is a permanent dummy (zero saliency and normal): lanes that have run out of hits vote
@@ -152,7 +154,8 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
   // address arithmetic)
   constexpr int OFF_POS = ENT_BYTES * (CAP + 1), OFF_HITW = OFF_POS + 4 * CAP, OFF_TOT = OFF_HITW + 4 * (NWORDS + 1) * NT;
   constexpr int OFF_TILE = OFF_TOT + 2 * (NT / 64) * 4;
-  __shared__ __attribute__((aligned(16))) unsigned char lds_static[OFF_TILE + 16];
+  constexpr int OFF_PCNT = OFF_TILE + 16;       // entries per cached sender plane, [2h+1] ints (h <= 40)
+  __shared__ __attribute__((aligned(16))) unsigned char lds_static[OFF_PCNT + 4 * 84];
   unsigned char* l_ent = lds_static;
   // distance-test operand of the listed senders (see phase A): packed signed bytes
   // (e'x, e'y, -(|e'|^2 >> 7), |e'|^2 & 127) with e' = sender position relative to the tile centre
@@ -160,6 +163,7 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
   unsigned char* hitw = lds_static + OFF_HITW;                                    // [NWORDS + sentinel][NT]
   int (*wave_tot)[NT / 64] = reinterpret_cast<int (*)[NT / 64]>(lds_static + OFF_TOT);
   unsigned* claimed_tile = reinterpret_cast<unsigned*>(lds_static + OFF_TILE);
+  int* plane_cnt = reinterpret_cast<int*>(lds_static + OFF_PCNT);
   // dynamic LDS: the table slices of the current plane group, [group][(2h+1)^2] float4
   extern __shared__ __attribute__((aligned(16))) unsigned char slices[];
 
@@ -193,7 +197,9 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
   const int tile_x = b % p.tiles_x;
   b /= p.tiles_x;
   const int tile_y = b % p.tiles_y;
-  const int rz = p.z_out0 + (int)(b / p.tiles_y);
+  // a unit of work: one 16 x 16 tile over a run of consecutive receiver planes [z_run0, z_run1)
+  const int z_run0 = p.z_out0 + (int)(b / p.tiles_y) * p.zrun;
+  const int z_run1 = min(z_run0 + p.zrun, p.z_out1);
   const int x0 = tile_x * TILE, y0 = tile_y * TILE;
   const int h = p.h;
   const int S = 2 * h + 1;       // table row length
@@ -206,8 +212,8 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
   const int lx = (wave & 1) * 8 + (lane & 7), ly = (wave >> 1) * 8 + (lane >> 3);
   const int rx = x0 + lx, ry = y0 + ly;
   const bool r_in = rx < p.nx && ry < p.ny;
-  const i64 rc = (i64)rz * plane + (i64)ry * p.nx + rx;
-  const bool r_live = r_in && !(mask_dst && mask_dst[r_in ? rc : 0] == 0.0f);
+  i64 rc = 0;             // this thread's receiver voxel and whether it takes votes: set per receiver plane
+  bool r_live = false;
   const int h2 = h * h;
   // Distance test  |r - e|^2 <= h^2  as ONE dot product per (receiver, sender): with coordinates
   // relative to the tile centre (r' = (lx-8, ly-8, 0), e' = (ex-h-8, ey-h-8, ez-h)) and
@@ -227,10 +233,6 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
   const unsigned r16s = lds_addr(slices) + (unsigned)r16;
 
   float T[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-
-  const int sz_hi = min(rz + h, p.nz - 1), sz_lo = max(rz - h, 0);
-  const int nplanes = sz_hi - sz_lo + 1;
-  const int nsteps = nplanes * p.nbands;
 
   // region voxels owned by this thread inside a band: VPT consecutive positions, (row << 8) | column
   int rc_[VPT];
@@ -253,10 +255,7 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
     const bool ok = er < rows && sx >= 0 && sx < p.nx && sy >= 0 && sy < p.ny;
     return ok ? (unsigned)(sy * p.nx + sx) * 4u : OOB;
   };
-  float pre[VPT];
-  auto fetch = [&](int step, float out[VPT]) {
-    const int sz = sz_hi - step / p.nbands;
-    const int band = p.nbands - 1 - (step % p.nbands);   // bands visited from the last rows down
+  auto fetch = [&](int sz, int band, float out[VPT]) {
     const int row0 = band * p.band_rows;
     const int rows = min(p.band_rows, p.rh - row0);
     const __amdgpu_buffer_rsrc_t rs = plane_rsrc(sal, sz);
@@ -344,7 +343,6 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
         atomicAdd(&g_tv_stats[2], (unsigned long long)n * 64ull);       // distance tests
         atomicAdd(&g_tv_stats[3], 1ull);                                // wave-flushes
         atomicMax(&g_tv_stats[4], (unsigned long long)niter);
-        wave_tot[0][wave] = niter;   // (free between flushes) for the cross-wave figure below
       }
     }
 #endif
@@ -392,25 +390,39 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
     }
   };
 
+  // ---- the unit's receiver planes, bottom up --------------------------------------------------------------
+  // Consecutive receiver planes share 2h of their 2h+1 sender planes.  The compacted sender list of a plane
+  // (entries in vote order) is therefore written to a per-workgroup scratch ring in global memory when the plane
+  // is first met, and REPLAYED from there for the following receiver planes: only the plane rz+h is read from
+  // the volume and compacted per receiver plane (all 2h+1 for the first plane of the run).
+  // scratch entry (32 bytes): float4 {sal, n0, n1, n2} | ex + 256 ey | mask value | pad.  Ring slot of plane
+  // sz: sz mod (2h+1); cached planes: [cached_lo, cached_hi].
+  const int P = 2 * h + 1;
+  const size_t plane_stride = (size_t)p.rw * p.rh * ENT_BYTES;
+  unsigned char* const ring = scratch ? scratch + (size_t)blockIdx.x * plane_stride * P : nullptr;
+  int cached_lo = 1, cached_hi = 0;     // empty
+  int npar = 0;                         // parity of the wave-total buffers
+  for (int rz = z_run0; rz < z_run1; rz++) {
+  rc = (i64)rz * plane + (i64)ry * p.nx + rx;
+  r_live = r_in && !(mask_dst && mask_dst[r_in ? rc : 0] == 0.0f);
+#pragma unroll
+  for (int k = 0; k < 6; k++) T[k] = 0.0f;
+  const int sz_hi = min(rz + h, p.nz - 1), sz_lo = max(rz - h, 0);
+  const int nplanes = sz_hi - sz_lo + 1;
+
   int n_list = 0;         // entries currently in the LDS list
   int ez_first = 0;       // region-relative z of the first plane of the current group
-  if (nsteps > 0) fetch(0, pre);
-  for (int step = 0; step < nsteps; step++) {
-    const int par = step & 1;
-    const int pl = step / p.nbands;                         // plane counter, 0 = z+h side
+  auto flush_full = [&]() {
+    __syncthreads();   // list complete
+    flush(n_list, ez_first);
+    n_list = 0;
+    __syncthreads();   // everyone done reading before the list is refilled
+  };
+  for (int pl = 0; pl < nplanes; pl++) {                    // plane counter, 0 = z+h side
     const int sz = sz_hi - pl;
-    const int band = p.nbands - 1 - (step % p.nbands);
-    const int row0 = band * p.band_rows;
-    const int rows = min(p.band_rows, p.rh - row0);
     const int ez = sz - (rz - h);                           // 0..2h
-    const bool new_group = (step % p.nbands == 0) && (pl % p.group == 0);
-    float cur[VPT];
-#pragma unroll
-    for (int v = 0; v < VPT; v++) cur[v] = pre[v];
-    if (step + 1 < nsteps) fetch(step + 1, pre);   // in flight while this band is processed
-
-    if (new_group) {
-      // previous group completely flushed (n_list == 0, barrier at the end of flush block below):
+    if (pl % p.group == 0) {
+      // previous group completely flushed (n_list == 0, barrier at the end of the flush block below):
       // copy the table slices of this group's planes (plane s of the group: ez = ez_first - s, jz = h - ez)
       ez_first = ez;
       const int g_planes = min(p.group, nplanes - pl);
@@ -421,93 +433,123 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
         sl4[i] = table[(i64)(jz + h) * nsl + r];
       }
     }
+    unsigned char* const ring_plane = ring ? ring + (size_t)(sz % P) * plane_stride : nullptr;
+    const int epz = ez - h;
+    const int e16_plane = (ez_first - ez) * nsl;
 
-    // ---- ordered compaction of the band's salient senders ------------------------------------
-    int cnt = 0;
-#pragma unroll
-    for (int v = 0; v < VPT; v++) cnt += (cur[v] != 0.0f) ? 1 : 0;
-    int incl = cnt;   // inclusive scan over the wave
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int o = __shfl_up(incl, d);
-      if (lane >= d) incl += o;
-    }
-    if (lane == 63) wave_tot[par][wave] = incl;
-    __syncthreads();   // (1) wave totals (and new slices) visible
-    int base = 0, len = 0;
-#pragma unroll
-    for (int w = 0; w < NT / 64; w++) {
-      const int t = wave_tot[par][w];
-      base += (w < wave) ? t : 0;
-      len += t;
-    }
-    // vote order inside a band is DESCENDING position: entry with ascending rank r gets q = len-1-r
-    const int first_q = len - 1 - (base + incl - cnt);     // q of this thread's first sender; next ones q-1, ...
-
-    const __amdgpu_buffer_rsrc_t rd0 = plane_rsrc(dir, sz);
-    const __amdgpu_buffer_rsrc_t rd1 = plane_rsrc(dir + nvox, sz);
-    const __amdgpu_buffer_rsrc_t rd2 = plane_rsrc(dir + 2 * nvox, sz);
-    int done = 0;
-    while (done < len) {   // uniform
-      const int take = min(CAP - n_list, len - done);
-      int q = first_q;
-#pragma unroll
-      for (int v = 0; v < VPT; v++) {
-        if (cur[v] != 0.0f) {
-          if (q >= done && q < done + take) {
-            const unsigned off = voff_of(v, row0, rows);
-            const int slot = n_list + (q - done);
-            unsigned char* ent = l_ent + ENT_BYTES * slot;
-            *reinterpret_cast<float4*>(ent) =
-                make_float4(cur[v], buf_load(rd0, off), buf_load(rd1, off), buf_load(rd2, off));
-            const int ex = rc_[v] & 0xff, ey = row0 + (rc_[v] >> 8);
-            const int epx = ex - h - 8, epy = ey - h - 8, epz = ez - h;
-            const int e2 = epx * epx + epy * epy + epz * epz;
-            l_pos[slot] = (unsigned)(epx & 0xff) | ((unsigned)(epy & 0xff) << 8) | ((unsigned)((-(e2 >> 7)) & 0xff) << 16) |
-                          ((unsigned)(e2 & 127) << 24);
-            *reinterpret_cast<int*>(ent + 16) = 16 * (ey * S + ex - (ez_first - ez) * nsl);
-            if (MASKED_SRC) *reinterpret_cast<float*>(ent + 20) = buf_load(plane_rsrc(mask_src, sz), off);
-          }
-          q--;
+    if (ring && sz >= cached_lo && sz <= cached_hi) {
+      // ---- replay the plane's compacted list from the scratch ring ---------------------------------------
+      const int cnt = plane_cnt[sz % P];
+      int done = 0;
+      while (done < cnt) {   // uniform
+        const int take = min(CAP - n_list, cnt - done);
+        for (int i = tid; i < take; i += NT) {
+          const unsigned char* src_e = ring_plane + (size_t)(done + i) * ENT_BYTES;
+          const float4 a = *reinterpret_cast<const float4*>(src_e);
+          const uint2 m = *reinterpret_cast<const uint2*>(src_e + 16);
+          const int slot = n_list + i;
+          unsigned char* ent = l_ent + ENT_BYTES * slot;
+          *reinterpret_cast<float4*>(ent) = a;
+          const int ex = (int)(m.x & 0xffu), ey = (int)(m.x >> 8);
+          const int epx = ex - h - 8, epy = ey - h - 8;
+          const int e2 = epx * epx + epy * epy + epz * epz;
+          l_pos[slot] = (unsigned)(epx & 0xff) | ((unsigned)(epy & 0xff) << 8) | ((unsigned)((-(e2 >> 7)) & 0xff) << 16) |
+                        ((unsigned)(e2 & 127) << 24);
+          *reinterpret_cast<int*>(ent + 16) = 16 * (ey * S + ex - e16_plane);
+          if (MASKED_SRC) *reinterpret_cast<unsigned*>(ent + 20) = m.y;
         }
+        n_list += take;
+        done += take;
+        if (n_list == CAP) flush_full();
       }
-      n_list += take;
-      done += take;
-      if (n_list == CAP) {
-        __syncthreads();   // list complete
-        flush(n_list, ez_first);
-        n_list = 0;
-        __syncthreads();   // everyone done reading before the list is refilled
-#ifdef VH_TV_STATS
-        if (tid == 0) {
-          int mxw = 0, sm = 0;
-          for (int w = 0; w < NT / 64; w++) { mxw = max(mxw, wave_tot[0][w]); sm += wave_tot[0][w]; }
-          atomicAdd(&g_tv_stats[5], (unsigned long long)mxw * (NT / 64));
-          atomicAdd(&g_tv_stats[6], (unsigned long long)sm);
+    } else {
+      // ---- read the plane from the volume: ordered compaction of its salient senders, band by band -------
+      int plane_fill = 0;   // entries of this plane written so far (uniform)
+      for (int bi = 0; bi < p.nbands; bi++) {
+        const int band = p.nbands - 1 - bi;                 // bands visited from the last rows down
+        const int row0 = band * p.band_rows;
+        const int rows = min(p.band_rows, p.rh - row0);
+        const int par = (npar++) & 1;
+        float cur[VPT];
+        fetch(sz, band, cur);
+        int cnt = 0;
+#pragma unroll
+        for (int v = 0; v < VPT; v++) cnt += (cur[v] != 0.0f) ? 1 : 0;
+        int incl = cnt;   // inclusive scan over the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int o = __shfl_up(incl, d);
+          if (lane >= d) incl += o;
         }
-        __syncthreads();
-#endif
+        if (lane == 63) wave_tot[par][wave] = incl;
+        __syncthreads();   // (1) wave totals (and new slices) visible
+        int base = 0, len = 0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; w++) {
+          const int t = wave_tot[par][w];
+          base += (w < wave) ? t : 0;
+          len += t;
+        }
+        // vote order inside a band is DESCENDING position: entry with ascending rank r gets q = len-1-r
+        const int first_q = len - 1 - (base + incl - cnt);     // q of this thread's first sender; next ones q-1, ...
+
+        const __amdgpu_buffer_rsrc_t rd0 = plane_rsrc(dir, sz);
+        const __amdgpu_buffer_rsrc_t rd1 = plane_rsrc(dir + nvox, sz);
+        const __amdgpu_buffer_rsrc_t rd2 = plane_rsrc(dir + 2 * nvox, sz);
+        int done = 0;
+        while (done < len) {   // uniform
+          const int take = min(CAP - n_list, len - done);
+          int q = first_q;
+#pragma unroll
+          for (int v = 0; v < VPT; v++) {
+            if (cur[v] != 0.0f) {
+              if (q >= done && q < done + take) {
+                const unsigned off = voff_of(v, row0, rows);
+                const int slot = n_list + (q - done);
+                unsigned char* ent = l_ent + ENT_BYTES * slot;
+                const float4 a = make_float4(cur[v], buf_load(rd0, off), buf_load(rd1, off), buf_load(rd2, off));
+                *reinterpret_cast<float4*>(ent) = a;
+                const int ex = rc_[v] & 0xff, ey = row0 + (rc_[v] >> 8);
+                const int epx = ex - h - 8, epy = ey - h - 8;
+                const int e2 = epx * epx + epy * epy + epz * epz;
+                l_pos[slot] = (unsigned)(epx & 0xff) | ((unsigned)(epy & 0xff) << 8) | ((unsigned)((-(e2 >> 7)) & 0xff) << 16) |
+                              ((unsigned)(e2 & 127) << 24);
+                *reinterpret_cast<int*>(ent + 16) = 16 * (ey * S + ex - e16_plane);
+                unsigned mv = 0u;
+                if (MASKED_SRC) {
+                  mv = __float_as_uint(buf_load(plane_rsrc(mask_src, sz), off));
+                  *reinterpret_cast<unsigned*>(ent + 20) = mv;
+                }
+                if (ring_plane) {
+                  unsigned char* dst_e = ring_plane + (size_t)(plane_fill + q) * ENT_BYTES;
+                  *reinterpret_cast<float4*>(dst_e) = a;
+                  *reinterpret_cast<uint2*>(dst_e + 16) = make_uint2((unsigned)ex | ((unsigned)ey << 8), mv);
+                }
+              }
+              q--;
+            }
+          }
+          n_list += take;
+          done += take;
+          if (n_list == CAP) flush_full();
+        }
+        plane_fill += len;
+      }
+      if (ring) {
+        if (tid == 0) plane_cnt[sz % P] = plane_fill;
+        if (cached_lo > cached_hi) { cached_lo = sz; cached_hi = sz; }
+        else if (sz == cached_hi + 1) cached_hi = sz;
+        else if (sz == cached_lo - 1) cached_lo = sz;
+        else { cached_lo = sz; cached_hi = sz; }            // (not reached: planes arrive adjacent to the range)
+        if (cached_hi - cached_lo + 1 > P) cached_lo = cached_hi - P + 1;   // the slot of the oldest plane was reused
       }
     }
     // end of group (or of all planes): flush what is left
-    const bool last_of_group = (band == 0) && (((pl + 1) % p.group == 0) || (pl + 1 == nplanes));
-    if (last_of_group) {
+    if (((pl + 1) % p.group == 0) || (pl + 1 == nplanes)) {
       __syncthreads();
-#ifdef VH_TV_STATS
-      const bool had = n_list > 0;
-#endif
       if (n_list > 0) flush(n_list, ez_first);
       n_list = 0;
       __syncthreads();     // list and slices free for the next group
-#ifdef VH_TV_STATS
-      if (tid == 0 && had) {
-        int mxw = 0, sm = 0;
-        for (int w = 0; w < NT / 64; w++) { mxw = max(mxw, wave_tot[0][w]); sm += wave_tot[0][w]; }
-        atomicAdd(&g_tv_stats[5], (unsigned long long)mxw * (NT / 64));
-        atomicAdd(&g_tv_stats[6], (unsigned long long)sm);
-      }
-      __syncthreads();
-#endif
     }
   }
 
@@ -515,6 +557,7 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
 #pragma unroll
     for (int k = 0; k < 6; k++) ten[k * nvox + rc] = T[k];
   }
+  }   // next receiver plane of the run
   }   // next tile
 }
 
@@ -541,7 +584,7 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
 
   TiledParams p;
   p.nx = (int)nx; p.ny = (int)ny; p.nz = (int)nz;
-  p.z_out0 = (int)z_out0;
+  p.z_out0 = (int)z_out0; p.z_out1 = (int)z_out1;
   p.h = h; p.hp1 = hp1;
   p.rw = TILE + 2 * h; p.rh = TILE + 2 * h;
   p.band_rows = BAND_CAP / p.rw;
@@ -556,7 +599,13 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
   p.tiles_y = (int)((ny + TILE - 1) / TILE);
   p.exponent = exponent;
   p.curves = curves ? 1 : 0;
-  const i64 nblk = (i64)p.tiles_x * p.tiles_y * (z_out1 - z_out0);
+  // units of work: a tile over a run of receiver planes (the kernel replays compacted sender planes within a run)
+  p.zrun = 32;   // sweep at 1024^3: 16: 853 ms, 24-64: 820-833 ms, 128: 838 ms
+  if (const char* e = getenv("VISFD_HIP_TV_ZRUN")) { const int v = atoi(e); if (v >= 1 && v <= 4096) p.zrun = v; }   // tuning aid
+  if ((i64)p.zrun > z_out1 - z_out0) p.zrun = (int)(z_out1 - z_out0);
+  if (p.zrun < 1) p.zrun = 1;
+  const i64 nruns = (z_out1 - z_out0 + p.zrun - 1) / p.zrun;
+  const i64 nblk = (i64)p.tiles_x * p.tiles_y * nruns;
   if (nblk > 0x7fffffffLL) return fail(VISFD_HIP_EINVAL, "volume too large for one launch");
   // slice area: the group's slices, and at least the span the dummy entry's table reads can touch
   size_t slice_f4 = (size_t)p.group * n * n;
@@ -564,7 +613,7 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
   if (slice_f4 < dummy_span) slice_f4 = dummy_span;
   p.slice_f4 = (int)slice_f4;
   const size_t lds = sizeof(float4) * slice_f4;   // dynamic part
-  const size_t lds_static = (size_t)ENT_BYTES * (CAP + 1) + (size_t)4 * CAP + (size_t)4 * (NWORDS + 1) * NT + 64 + 16;
+  const size_t lds_static = (size_t)ENT_BYTES * (CAP + 1) + (size_t)4 * CAP + (size_t)4 * (NWORDS + 1) * NT + 64 + 16 + 4 * 84;
   if (lds + lds_static > 150 * 1024) return VISFD_HIP_OK;   // window too wide for the LDS slices: baseline kernel
   const int mode = curves ? 1 : (exponent == 4 ? 0 : (exponent == 2 ? 2 : 1));
   // persistent workgroups (see the kernel): as many as the chip holds at once -- LDS allows 160 KB / (static +
@@ -577,13 +626,22 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
   if (wg_per_cu < 1) wg_per_cu = 1;
   i64 ngrid = (i64)ctx->num_cus * (i64)wg_per_cu;
   if (ngrid > nblk) ngrid = nblk;
+  // scratch rings: (2h+1) planes x (TILE+2h)^2 entries of 32 bytes per workgroup (1.3 GB for h = 12 on 256 CUs);
+  // beyond 16 GB (very wide windows) the kernel runs without them and compacts every plane from the volume
+  unsigned char* scratch = nullptr;
+  {
+    const size_t per_wg = (size_t)n * p.rw * p.rh * ENT_BYTES;
+    const size_t total = per_wg * (size_t)ngrid;
+    const char* off = getenv("VISFD_HIP_TV_NO_REPLAY");
+    if (total <= ((size_t)16 << 30) && p.zrun > 1 && !(off && off[0] == '1')) VH_TRY(ws(ctx, WS_TVSCRATCH, total, &scratch));
+  }
 #define VH_TV_LAUNCH(MSK, MD)                                                                        \
   do {                                                                                               \
     VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tv_tiled_kernel<MSK, MD>),             \
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
     tv_tiled_kernel<MSK, MD><<<dim3((unsigned)ngrid), dim3(NT), lds, st>>>(sal, dir, ten, mask_src,  \
                                                                           mask_dst, dtab, p, counter, \
-                                                                          (unsigned)nblk);           \
+                                                                          (unsigned)nblk, scratch);  \
   } while (0)
   if (mask_src) { if (mode == 0) VH_TV_LAUNCH(true, 0); else if (mode == 2) VH_TV_LAUNCH(true, 2); else VH_TV_LAUNCH(true, 1); }
   else          { if (mode == 0) VH_TV_LAUNCH(false, 0); else if (mode == 2) VH_TV_LAUNCH(false, 2); else VH_TV_LAUNCH(false, 1); }
