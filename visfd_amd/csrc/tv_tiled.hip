@@ -5,13 +5,16 @@
 // saliency is zero (typically 95 % of them, feature.hpp:1704-1709).  Here the skipping is done
 // once per workgroup instead of once per receiver:
 //
-//   * a workgroup owns a 16 x 16 x 1 tile of receivers (one per thread; each wave an 8 x 8 patch);
-//   * sender planes are visited from z+h down to z-h (= jz ascending), in groups of up to G planes
-//     whose signed (2h+1)^2 table slices fit in LDS.  For each plane the workgroup reads the
-//     (16+2h)^2 region of saliencies around the tile (buffer loads, next band prefetched in
-//     registers) and appends the salient, unmasked senders -- distance-test operand, saliency,
-//     normal, table offset, mask value -- to an LDS list IN VOTE ORDER (ordered block-wide prefix
-//     sum: deterministic);
+//   * workgroups are PERSISTENT: as many as the chip holds, each claiming units of work -- a 16 x 16 tile of
+//     receivers (one per thread; each wave an 8 x 8 patch) over a run of 32 consecutive receiver planes -- from
+//     a global counter until it is exhausted (a plain grid left wave slots empty on volumes whose sender
+//     density varies, see the kernel);
+//   * for a receiver plane z, sender planes are visited from z+h down to z-h (= jz ascending), in groups of up
+//     to G planes whose signed (2h+1)^2 table slices fit in LDS.  The salient, unmasked senders of the
+//     (16+2h)^2 region of a plane -- distance-test operand, saliency, normal, table offset, mask value -- are
+//     appended to an LDS list IN VOTE ORDER (ordered block-wide prefix sum: deterministic).  A plane is read
+//     from the volume and compacted only the first time the run meets it; its list then lives in a
+//     per-workgroup scratch ring in global memory and is replayed for the next 2h receiver planes;
 //   * when the list is full (or the group ends) it is flushed.  Phase A: every lane tests all
 //     listed senders against its own receiver -- sender operands from uniform-address LDS reads,
 //     jx^2+jy^2+jz^2 <= h^2 as ONE v_dot4_i32_i8 on signed bytes (see the kernel), an exact superset
