@@ -276,7 +276,7 @@ def main():
                          "ms_per_launch": round(p_ms, 4), "voxels_per_launch": nv,
                          "note": "average of the three pass launches; a device copy on this box runs at ~5.0 TB/s"}
 
-        # the tensor-voting kernel (84 % of the step): a VALU-bound stencil, priced against the FP32 vector peak as
+        # the tensor-voting kernel (80 % of the step): a VALU-bound stencil, priced against the FP32 vector peak as
         # SURVEY.md 8d asks -- 45 flop per evaluated vote (feature.hpp:2312-2377), votes = salient senders x non-zero taps
         # (boundary clipping ignored: < 4 % at this size)
         order = api.DECREASING_EIVALS
@@ -299,8 +299,8 @@ def main():
                        "traffic": None, "ms_per_launch": round(tv_ms, 2), "votes_per_launch": votes,
                        "flop_per_vote": 45, "salient_senders": n_salient, "nonzero_taps": n_taps,
                        "note": "peak = nominal FP32 vector rate (packed FMA); the reference's operation order forbids FMA "
-                               "and packing, which leaves ~39 T scalar fp32 instructions/s to issue: the kernel issues "
-                               "~85 % of that (DESIGN.md 4.2)"}
+                               "and packing, which leaves ~39 T scalar fp32 instructions/s to issue: rocprofv3 VALUBusy of "
+                               "this kernel is 95-108 % (profiles/r01_pmc_occupancy_valu.txt, DESIGN.md 4.2)"}
 
     # ---- the north-star target case: the separable Gaussian on a 2048^3 volume (2^33 voxels, 32 GiB) -------
     roofline_2048 = None
