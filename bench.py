@@ -122,6 +122,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=1024, help="edge of the per-GPU volume")
+    ap.add_argument("--nz", type=int, default=0, help="planes per GPU (default: --size); e.g. --size 2048 --nz 512 is one "
+                                                       "slab of BASELINE config 5")
     ap.add_argument("--cpu-sample", type=int, default=192)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-2048", action="store_true", help="skip the extra Gaussian timing on a 2048^3 volume")
@@ -156,16 +158,17 @@ def main():
     ctx = api.Context(dev_index, stream.cuda_stream)
 
     S = args.size
-    nvox_rank = S * S * S
+    NZ = args.nz if args.nz > 0 else S
+    nvox_rank = S * S * NZ
     sig = pipeline.cli_blob_sigmas(*BLOB)
     sigma_tv = float(np.float32(MEMBRANE["tv_sigma_ratio"]) * np.float32(MEMBRANE["sigma"]))
     h_tv = int(math.floor(np.float32(sigma_tv) * np.float32(math.sqrt(2.0))))
-    layout = slab.SlabLayout(S * world, rank, world, ghost=max(h_tv, 12))
+    layout = slab.SlabLayout(NZ * world, rank, world, ghost=max(h_tv, 12))
     shape = (layout.nz_local, S, S)
 
     src = torch.empty(shape, device=device, dtype=torch.float32)
     own = synth_volume(torch, ctx, (layout.z1 - layout.z0, S, S), device, seed=12345, z_offset=layout.z0,
-                       nz_global=S * world)
+                       nz_global=NZ * world)
     layout.owned(src).copy_(own)
     del own
     dst = torch.empty(shape, device=device, dtype=torch.float32)
@@ -193,9 +196,9 @@ def main():
         if record:
             ev[2].record()
         if world > 1:
-            thr = slab.membrane_detect_slab(ctx, layout, src, sal, dirs, ten, **MEMBRANE)
+            thr = slab.membrane_detect_slab(ctx, layout, src, sal, dirs, ten, scratch=dst, **MEMBRANE)
         else:
-            thr = pipeline.membrane_detect(ctx, src, sal, dirs, ten, **MEMBRANE)
+            thr = pipeline.membrane_detect(ctx, src, sal, dirs, ten, scratch=dst, **MEMBRANE)
         if record:
             ev[3].record()
             torch.cuda.synchronize()
@@ -346,12 +349,13 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "Mvoxels/s (Gauss+DoG+TV pipeline) on %d^3 float32; %% HBM roofline" % S,
+            "metric": "Mvoxels/s (Gauss+DoG+TV pipeline) on %s float32; %% HBM roofline" % (
+                "%d^3" % S if NZ == S else "%dx%dx%d per GPU" % (S, S, NZ)),
             "value": round(value, 3), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "gauss(sigma=2) + blob-dog(12 scales, sigma 2..4) + membrane/TV(sigma=1.732, "
-                                   "sigma_tv=8.66, top 5%%) on %dx%dx%d float32" % (S, S, S * world),
+                                   "sigma_tv=8.66, top 5%%) on %dx%dx%d float32" % (S, S, NZ * world),
                        "per_gpu_voxels": nvox_rank, "decomposition": "z-slabs, ghost %d" % layout.ghost,
                        "halo_transport": "none" if world == 1 else ("rccl" if own_gpu else "gloo-staged (shared GPU rehearsal)")},
             "stages_ms": {"gauss": round(stage_ms[0] / args.steps, 3), "blob_dog": round(stage_ms[1] / args.steps, 3),

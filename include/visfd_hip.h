@@ -57,7 +57,7 @@ int visfd_hip_synchronize(visfd_hip_ctx* ctx);
 /* release the cached workspace (it otherwise persists between calls) */
 int visfd_hip_trim(visfd_hip_ctx* ctx);
 const char* visfd_hip_last_error(void);
-int visfd_hip_abi_version(void);   /* 3: entry points only get added between versions */
+int visfd_hip_abi_version(void);   /* 4: entry points only get added between versions */
 /* bytes of device workspace currently held by the context */
 int64_t visfd_hip_workspace_bytes(visfd_hip_ctx* ctx);
 
@@ -295,6 +295,16 @@ int visfd_hip_ridge_saliency_dev(visfd_hip_ctx*, const float* src, const float* 
                                  int64_t nx, int64_t ny, int64_t nz, float sigma,
                                  float truncate_ratio, int eival_order, float* saliency,
                                  float* direction);
+/* The same in two steps, for callers that threshold the saliency before they need directions (HandleTV,
+ * handlers.cpp:1751-1797): visfd_hip_ridge_scores_dev smooths and scores every voxel and hands back the smoothed
+ * volume (`smoothed`: caller's buffer of nvox floats, distinct from src and saliency);
+ * visfd_hip_ridge_directions_dev writes the principal direction (3 planes) of the voxels whose saliency is non-zero
+ * and leaves the others untouched.  Scores and directions are bit-identical to visfd_hip_ridge_saliency_dev's. */
+int visfd_hip_ridge_scores_dev(visfd_hip_ctx*, const float* src, const float* mask, int64_t nx, int64_t ny,
+                               int64_t nz, float sigma, float truncate_ratio, int eival_order, float* saliency,
+                               float* smoothed);
+int visfd_hip_ridge_directions_dev(visfd_hip_ctx*, const float* smoothed, int64_t nx, int64_t ny, int64_t nz,
+                                   float sigma, int eival_order, const float* saliency, float* direction);
 
 /* ---- a12 (second half): global top-fraction threshold, handlers.cpp:1751-1797 -------------------- */
 /* threshold = (floor(n_unmasked*fraction))-th largest unmasked saliency; every voxel with

@@ -383,6 +383,53 @@ def test_tensor_voting_dense_saliency(ctx, oracle):
 
 
 
+def test_ridge_two_step_equals_fused(ctx, oracle):
+    """Scores for every voxel + directions of the thresholded survivors (what the pipeline runs) against the fused
+    kernel that computes both everywhere: identical scores, identical directions where the score survives, nothing
+    written elsewhere; masked and unmasked, both eigenvalue orders, ragged sizes."""
+    import torch
+    from visfd_amd import api
+    dev = torch.device("cuda:0")
+    for shape, masked, order in (((37, 45, 70), False, api.DECREASING_EIVALS), ((20, 33, 41), True, api.INCREASING_EIVALS)):
+        src = torch.from_numpy(volgen.membrane_volume(shape, seed=91)).to(dev)
+        mask = torch.from_numpy(volgen.block_mask(shape, seed=92)).to(dev) if masked else None
+        r = api.ratio_from_threshold(0.03)
+        sal1 = torch.empty_like(src); dirs1 = torch.zeros((3,) + shape, device=dev)
+        ctx.ridge_saliency_dev(src, sal1, dirs1, 1.5, r, order, mask)
+        sal2 = torch.empty_like(src); smoothed = torch.empty_like(src)
+        dirs2 = torch.full((3,) + shape, 7.0, device=dev)
+        ctx.ridge_scores_dev(src, sal2, smoothed, 1.5, r, order, mask)
+        ctx.synchronize()
+        assert torch.equal(sal1.view(torch.int32), sal2.view(torch.int32)), "scores"
+        thr = ctx.threshold_fraction_dev(sal2, 0.1, mask)
+        ctx.ridge_directions_dev(smoothed, sal2, dirs2, 1.5, order)
+        ctx.synchronize()
+        assert thr > 0
+        keep = (sal2 != 0)
+        assert 0 < int(keep.sum()) < keep.numel()
+        for c in range(3):
+            assert torch.equal(dirs2[c][keep].view(torch.int32), dirs1[c][keep].view(torch.int32)), "directions"
+            assert bool((dirs2[c][~keep] == 7.0).all()), "voxels below the threshold must stay untouched"
+
+
+def test_tensor_voting_unit_shapes_agree(ctx, oracle, monkeypatch):
+    """The voting kernel's units of work (runs of receiver planes with replayed sender planes) must not show in the
+    result: runs of 1, 5 and 32 planes, and the path without scratch rings, give the same bits as the CPU
+    restatement -- unmasked and masked, with a window (h = 4) much shorter than the volume."""
+    shape = (45, 40, 52)
+    sal, dirs = _sparse_field(shape, seed=81)
+    mask = volgen.block_mask(shape, seed=82)
+    want = oracle.tv_dense_stick(sal, dirs, 3.0, 4, 2.0 ** 0.5)
+    want_m = oracle.tv_dense_stick(sal, dirs, 3.0, 4, 2.0 ** 0.5, mask, mask)
+    for env in ({}, {"VISFD_HIP_TV_ZRUN": "1"}, {"VISFD_HIP_TV_ZRUN": "5"}, {"VISFD_HIP_TV_NO_REPLAY": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        assert_bits_equal(ctx.tv_dense_stick(sal, dirs, 3.0, 4, 2.0 ** 0.5), want, "tensor %s" % env)
+        assert_bits_equal(ctx.tv_dense_stick(sal, dirs, 3.0, 4, 2.0 ** 0.5, mask, mask), want_m, "masked tensor %s" % env)
+        for k in env:
+            monkeypatch.delenv(k)
+
+
 # ------------------------------------------------------------------------------------------ BASELINE-size volumes
 def test_gauss_large_volume_crops_equal_oracle(ctx, oracle):
     """1024 x 1024 x 256 (the BASELINE plane size): the filter is local, so the result inside a crop equals the

@@ -78,6 +78,8 @@ _SIGS = {
     "visfd_hip_hessian_saliency_dev": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, _vp, _vp]),
     "visfd_hip_ridge_saliency_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, C.c_float, C.c_float, C.c_int,
                                                _vp, _vp]),
+    "visfd_hip_ridge_scores_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, C.c_float, C.c_float, C.c_int, _vp, _vp]),
+    "visfd_hip_ridge_directions_dev": (C.c_int, [_vp, _vp, _i64, _i64, _i64, C.c_float, C.c_int, _vp, _vp]),
     "visfd_hip_threshold_fraction": (C.c_int, [_vp, _vp, _vp, _i64, C.c_float, _fp]),
     "visfd_hip_threshold_fraction_dev": (C.c_int, [_vp, _vp, _vp, _i64, C.c_float, _fp]),
     "visfd_hip_select_histogram_dev": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_uint32,
@@ -604,6 +606,18 @@ class Context:
         nz, ny, nx = src.shape
         self._chk(self._L.visfd_hip_ridge_saliency_dev(self._h, _dev(src), _dev(mask), nx, ny, nz, float(sigma),
                                                        float(ratio), int(order), _dev(sal), _dev(dirs)))
+
+    def ridge_scores_dev(self, src, sal, smoothed, sigma, ratio, order, mask=None):
+        """Smoothing + Hessian + eigenvalues + score for every voxel; `smoothed` receives the smoothed volume."""
+        nz, ny, nx = src.shape
+        self._chk(self._L.visfd_hip_ridge_scores_dev(self._h, _dev(src), _dev(mask), nx, ny, nz, float(sigma),
+                                                     float(ratio), int(order), _dev(sal), _dev(smoothed)))
+
+    def ridge_directions_dev(self, smoothed, sal, dirs, sigma, order):
+        """Principal directions of the voxels with sal != 0 (the others keep what dirs held)."""
+        nz, ny, nx = smoothed.shape
+        self._chk(self._L.visfd_hip_ridge_directions_dev(self._h, _dev(smoothed), nx, ny, nz, float(sigma), int(order),
+                                                         _dev(sal), _dev(dirs)))
 
     def threshold_fraction_dev(self, sal, fraction, mask=None):
         thr = C.c_float()

@@ -205,7 +205,7 @@ using namespace vh;
 
 extern "C" {
 
-int visfd_hip_abi_version(void) { return 3; }   // 2: + blob post-processing, binning, LabelConnected and its host helpers; 3: + host DiagonalizeFlatSym3 / ConvertFlatSym2Evects3
+int visfd_hip_abi_version(void) { return 4; }   // 2: + blob post-processing, binning, LabelConnected and its host helpers; 3: + host DiagonalizeFlatSym3 / ConvertFlatSym2Evects3; 4: + LocalFluctuations, two-step ridge (scores / directions)
 const char* visfd_hip_last_error(void) { return g_last_error.c_str(); }
 
 int visfd_hip_create(int device, void* stream, visfd_hip_ctx** out) {
@@ -598,6 +598,33 @@ int visfd_hip_ridge_saliency_dev(visfd_hip_ctx* ctx, const float* src, const flo
   return dev_ridge_saliency_fused(ctx, S, mask, nx, ny, nz, sigma, order, sal, dir);
 }
 
+// The same in two steps for callers that threshold in between (HandleTV does: handlers.cpp:1751-1797): scores for
+// every voxel (the smoothed volume is handed back), then directions of the voxels whose score survived.
+int visfd_hip_ridge_scores_dev(visfd_hip_ctx* ctx, const float* src, const float* mask, int64_t nx, int64_t ny,
+                               int64_t nz, float sigma, float ratio, int order, float* sal, float* smoothed) {
+  VH_REQUIRE(ctx && src && sal && smoothed, "null argument");
+  VH_REQUIRE(smoothed != src && smoothed != sal, "the smoothed volume needs its own buffer");
+  VH_REQUIRE(order == 0 || order == 1, "unsupported eigenvalue order");
+  VH_HIP(hipSetDevice(ctx->device));
+  VH_TRY(check_dims(nx, ny, nz));
+  const int hwv = (int)std::floor(sigma * ratio);
+  VH_REQUIRE(hwv >= 0 && hwv <= MAX_HALFWIDTH, "filter halfwidth must be in [0, 64]");
+  const float sg[3] = {sigma, sigma, sigma};
+  const int hw[3] = {hwv, hwv, hwv};
+  const SlabInfo whole = {0, nz};
+  VH_TRY(gauss_dev(ctx, src, smoothed, mask, nx, ny, nz, sg, hw, true, whole, nullptr));
+  return dev_ridge_score(ctx, smoothed, mask, nx, ny, nz, sigma, order, sal);
+}
+
+int visfd_hip_ridge_directions_dev(visfd_hip_ctx* ctx, const float* smoothed, int64_t nx, int64_t ny, int64_t nz,
+                                   float sigma, int order, const float* sal, float* dir) {
+  VH_REQUIRE(ctx && smoothed && sal && dir, "null argument");
+  VH_REQUIRE(order == 0 || order == 1, "unsupported eigenvalue order");
+  VH_HIP(hipSetDevice(ctx->device));
+  VH_TRY(check_dims(nx, ny, nz));
+  return dev_ridge_directions(ctx, smoothed, sal, nx, ny, nz, sigma, order, dir);
+}
+
 // ---- a12 (threshold) -------------------------------------------------------------------------
 int visfd_hip_threshold_fraction_dev(visfd_hip_ctx* ctx, float* sal, const float* mask, int64_t nvox,
                                      float fraction, float* thr_out) {
@@ -741,11 +768,17 @@ int visfd_hip_membrane_detect_dev(visfd_hip_ctx* ctx, const float* src, const fl
   const i64 n = nx * ny * nz;
   float* d = dir;
   if (!d) VH_TRY(ws(ctx, WS_TVAUX, (size_t)(3 * n), &d));
-  VH_TRY(visfd_hip_ridge_saliency_dev(ctx, src, mask, nx, ny, nz, sigma, ratio, order, sal, d));
+  float* smoothed = nullptr;
+  VH_TRY(ws(ctx, WS_D, (size_t)n, &smoothed));
+  VH_TRY(visfd_hip_ridge_scores_dev(ctx, src, mask, nx, ny, nz, sigma, ratio, order, sal, smoothed));
   float thr = threshold_abs;
   if (best_fraction >= 0.0f) VH_TRY(dev_threshold_fraction(ctx, sal, mask, n, best_fraction, &thr));
   else VH_TRY(dev_apply_threshold(ctx, sal, n, thr));
   if (thr_out) *thr_out = thr;
+  // directions only where the score survived: nothing else is read downstream (a caller-supplied `dir`
+  // receives zeros elsewhere)
+  if (dir) VH_HIP(hipMemsetAsync(dir, 0, sizeof(float) * 3 * (size_t)n, ctx->stream));
+  VH_TRY(dev_ridge_directions(ctx, smoothed, sal, nx, ny, nz, sigma, order, d));
   if (sigma_tv > 0.0f) {
     float* t = ten;
     if (!t) VH_TRY(ws(ctx, WS_B, (size_t)(6 * n), &t));

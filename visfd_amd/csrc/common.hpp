@@ -125,6 +125,10 @@ int dev_hessian_saliency(visfd_hip_ctx* ctx, const float* hess_planar, const flo
 int dev_ridge_saliency_fused(visfd_hip_ctx* ctx, const float* smoothed, const float* mask, i64 nx,
                              i64 ny, i64 nz, float sigma, int order, float* saliency,
                              float* dir_planar);
+int dev_ridge_score(visfd_hip_ctx* ctx, const float* smoothed, const float* mask, i64 nx, i64 ny, i64 nz,
+                    float sigma, int order, float* saliency);
+int dev_ridge_directions(visfd_hip_ctx* ctx, const float* smoothed, const float* saliency, i64 nx, i64 ny, i64 nz,
+                         float sigma, int order, float* dir_planar);
 int dev_diagonalize(visfd_hip_ctx* ctx, const float* m6_planar, float* out6_planar, i64 n, int order);
 int dev_tensor_saliency(visfd_hip_ctx* ctx, const float* tensor_planar, const float* mask, i64 nvox,
                         int order, float* saliency);

@@ -129,6 +129,84 @@ ridge_fused_kernel(const float* __restrict__ S, const float* __restrict__ mask, 
   dir[2 * nvox + v] = d[2];
 }
 
+// The two halves of ridge_fused_kernel for pipelines that threshold the saliency before they need directions
+// (handlers.cpp:1751-1797 zeroes 95 % of the voxels; tensor voting reads the direction of the others only):
+// eigenvalues and score for every voxel ...
+__global__ void __launch_bounds__(BLOCK)
+ridge_score_kernel(const float* __restrict__ S, const float* __restrict__ mask, int nx, int ny, int nz,
+                   float sigma, int order, float* __restrict__ sal) {
+  int ix, iy, iz;
+  if (!voxel_of_block(nx, ny, ix, iy, iz)) return;
+  const i64 v = ((i64)iz * ny + iy) * nx + ix;
+  if (mask && mask[v] == 0.0f) { sal[v] = 0.0f; return; }
+  const Stencil f = clamped_stencil(S, ix, iy, iz, nx, ny, nz);
+  float h6[6];
+  hessian_at(f, sigma * sigma, h6);
+  double lam[3];
+  eig::D3 E[3];
+  eig::eig_sym3(h6, order, lam, E, false);      // the eigenvalues do not depend on the eigenvector branch
+  const double l1 = (float)lam[0], l2 = (float)lam[1];   // stored as float by DiagonalizeFlatSym3, re-read as double
+  double N = l1 * l1 - l2 * l2;
+  N *= N;
+  sal[v] = (float)N;
+}
+
+// ... and the principal direction of the voxels whose saliency is non-zero.  A workgroup scans DIR_CHUNK
+// consecutive voxels, compacts the survivors into an LDS list, and spends the eigenvector work (fp64 null
+// vectors, quaternion, Shoemake round trip) on full lanes only: with 5 % survivors one wave-round instead of 16.
+constexpr int DIR_CHUNK = 4 * BLOCK;
+__global__ void __launch_bounds__(BLOCK)
+ridge_directions_kernel(const float* __restrict__ S, const float* __restrict__ sal, int nx, int ny, int nz,
+                        float sigma, int order, float* __restrict__ dir) {
+  __shared__ unsigned short list[DIR_CHUNK];
+  __shared__ int wave_tot[BLOCK / 64];
+  const i64 nvox = (i64)nx * ny * nz;
+  const i64 base = (i64)blockIdx.x * DIR_CHUNK;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  bool keep[4];
+  int cnt = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const i64 v = base + k * BLOCK + tid;
+    keep[k] = v < nvox && sal[v] != 0.0f;
+    cnt += keep[k] ? 1 : 0;
+  }
+  int incl = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(incl, d);
+    if (lane >= d) incl += o;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  int off = incl - cnt, total = 0;
+#pragma unroll
+  for (int w = 0; w < BLOCK / 64; w++) {
+    const int t = wave_tot[w];
+    off += (w < wave) ? t : 0;
+    total += t;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (keep[k]) list[off++] = (unsigned short)(k * BLOCK + tid);
+  __syncthreads();
+  const i64 plane = (i64)nx * ny;
+  for (int i = tid; i < total; i += BLOCK) {
+    const i64 v = base + list[i];
+    const int iz = (int)(v / plane);
+    const i64 r = v - (i64)iz * plane;
+    const int iy = (int)(r / nx), ix = (int)(r - (i64)iy * nx);
+    const Stencil f = clamped_stencil(S, ix, iy, iz, nx, ny, nz);
+    float h6[6];
+    hessian_at(f, sigma * sigma, h6);
+    float s, d[3];
+    saliency_dir(h6, order, s, d);
+    dir[v] = d[0];
+    dir[nvox + v] = d[1];
+    dir[2 * nvox + v] = d[2];
+  }
+}
+
 __global__ void __launch_bounds__(BLOCK)
 diagonalize_kernel(const float* __restrict__ m, float* __restrict__ out, i64 n, int order) {
   const i64 v = (i64)blockIdx.x * BLOCK + threadIdx.x;
@@ -225,6 +303,30 @@ int dev_ridge_saliency_fused(visfd_hip_ctx* ctx, const float* S, const float* ma
   VH_TRY(voxel_grid(nx, ny, nz, &g));
   ridge_fused_kernel<<<dim3(g), dim3(BLOCK), 0, ctx->stream>>>(S, mask, (int)nx, (int)ny, (int)nz, sigma,
                                                               order, sal, dir);
+  VH_HIP(hipGetLastError());
+  return VISFD_HIP_OK;
+}
+
+int dev_ridge_score(visfd_hip_ctx* ctx, const float* S, const float* mask, i64 nx, i64 ny, i64 nz, float sigma,
+                    int order, float* sal) {
+  if (nx < 3 || ny < 3 || nz < 3)
+    return fail(VISFD_HIP_EINVAL, "ridge detection requires an image at least 3 voxels wide in x,y,z");
+  unsigned g;
+  VH_TRY(voxel_grid(nx, ny, nz, &g));
+  ridge_score_kernel<<<dim3(g), dim3(BLOCK), 0, ctx->stream>>>(S, mask, (int)nx, (int)ny, (int)nz, sigma, order, sal);
+  VH_HIP(hipGetLastError());
+  return VISFD_HIP_OK;
+}
+
+int dev_ridge_directions(visfd_hip_ctx* ctx, const float* S, const float* sal, i64 nx, i64 ny, i64 nz, float sigma,
+                         int order, float* dir) {
+  if (nx < 3 || ny < 3 || nz < 3)
+    return fail(VISFD_HIP_EINVAL, "ridge detection requires an image at least 3 voxels wide in x,y,z");
+  if (nx >= (1LL << 31) || ny >= (1LL << 31) || nz >= (1LL << 31)) return fail(VISFD_HIP_EINVAL, "dimension too large");
+  const i64 nb = (nx * ny * nz + DIR_CHUNK - 1) / DIR_CHUNK;
+  if (nb > 0x7fffffffLL) return fail(VISFD_HIP_EINVAL, "volume too large for one launch");
+  ridge_directions_kernel<<<dim3((unsigned)nb), dim3(BLOCK), 0, ctx->stream>>>(S, sal, (int)nx, (int)ny, (int)nz, sigma,
+                                                                             order, dir);
   VH_HIP(hipGetLastError());
   return VISFD_HIP_OK;
 }

@@ -125,7 +125,7 @@ def distributed_threshold_fraction(ops, sal_owned, fraction, layout, mask_owned=
 
 def membrane_detect_slab(ops, layout, src, sal, dirs, tensor, sigma, tv_sigma_ratio, tv_exponent=4,
                          best_fraction=0.05, truncate_threshold=0.03, tv_truncate_ratio=math.sqrt(2.0),
-                         minima=True, group=None):
+                         minima=True, group=None, scratch=None):
     """HandleTV (handlers.cpp:1501-1892) on one slab.  `src` holds the owned planes (ghosts are
     filled here); all tensors have the local shape [nz_local, ny, nx] (dirs: [3, ...], tensor: [6, ...]).
     Valid results are the owned planes of `sal` (post-voting saliency) and `tensor`."""
@@ -140,10 +140,21 @@ def membrane_detect_slab(ops, layout, src, sal, dirs, tensor, sigma, tv_sigma_ra
     exchange_halos(src, L, min(L.ghost, h_gauss + 1), group)
     # 2. saliency/direction on every stored plane; planes closer than h_gauss+1 to an interior
     #    array end are garbage, owned planes are exact
-    ops.ridge_saliency_dev(src, sal, dirs, sigma, ratio, order)
+    #    (scores first; directions only for the voxels that survive the threshold -- `scratch`: a tensor of the
+    #    local shape for the smoothed image, allocated here when the caller has none to lend)
+    two_step = hasattr(ops, "ridge_scores_dev")
+    if two_step:
+        smoothed = scratch if scratch is not None else src.new_empty(src.shape)
+        ops.ridge_scores_dev(src, sal, smoothed, sigma, ratio, order)
+    else:
+        ops.ridge_saliency_dev(src, sal, dirs, sigma, ratio, order)
     # 3. global top-fraction threshold over owned voxels
     thr = distributed_threshold_fraction(ops, L.owned(sal), best_fraction, L, None, group)
     ops.apply_threshold_dev(L.owned(sal), thr)
+    if two_step:
+        # ghost planes keep their unthresholded scores here: their directions are overwritten by the halo exchange
+        # below, and planes beyond the voting halo are zeroed before voting
+        ops.ridge_directions_dev(smoothed, sal, dirs, sigma, order)
     # 4. (saliency, direction) halo for the voting window
     exchange_halos(sal, L, min(L.ghost, h_tv), group)
     for c in range(3):
