@@ -137,6 +137,47 @@ __device__ __forceinline__ void vote_acc(float T[6], float bse, float m0, float 
   acc(T[2], b2 * m2);
 }
 
+// VH_TV_PK=1 (tools/build_variant.py) builds the vote with two-wide float operations: 9 packed + 14 scalar
+// instead of 32 scalar instructions, bit-identical results -- and 6 % SLOWER on MI355X (877 vs 827 ms at 1024^3):
+// a v_pk_mul/add_f32 costs more than two scalar operations here (profiles/r01_microbench_valu.txt).  Kept as the
+// measured alternative; the product builds with 0.
+#ifndef VH_TV_PK
+#define VH_TV_PK 0
+#endif
+#if VH_TV_PK
+// The same vote with two-wide float operations (v_pk_mul_f32 / v_pk_add_f32: IEEE per component, no FMA), for the
+// surface modes.  d = {n0, n1, n2, sal}, tw = {r0, r1, r2, w}; sums T01 = (T0, T1), T54 = (T5, T4), and T3, T2.
+typedef float v2f __attribute__((ext_vector_type(2)));
+template <int MODE>
+__device__ __forceinline__ void vote_pk(const f4v& d, const f4v& tw, float mv, bool masked, v2f& T01, v2f& T54, float& T3,
+                                        float& T2) {
+  const v2f r01 = {tw.x, tw.y}, n01 = {d.x, d.y};
+  const v2f r2w = {tw.z, tw.w}, n2s = {d.z, d.w};
+  const v2f p01 = r01 * n01;             // (r0 n0, r1 n1)
+  v2f p2s;
+  if (masked) {                          // fv = w * mask value first (feature.hpp:2262-2275), then sal * fv
+    const float fv = tw.w * mv;
+    p2s = v2f{tw.z, fv} * n2s;
+  } else {
+    p2s = r2w * n2s;                     // (r2 n2, w sal)
+  }
+  const float u = (p01.x + p01.y) + p2s.x;
+  const float ux2 = u * 2.0f;
+  const float u2 = u * u;
+  const float c2 = 1.0f - u2;
+  const float dec = (MODE == 0) ? c2 * c2 : c2;
+  const float bse = p2s.y * dec;
+  const v2f m01 = v2f{ux2, ux2} * r01 - n01;
+  const float m2 = ux2 * tw.z - d.z;
+  const v2f b01 = v2f{bse, bse} * m01;
+  const float b2 = bse * m2;
+  T01 = T01 + b01 * m01;                 // (b0 m0, b1 m1)
+  T54 = T54 + b01 * v2f{m2, m2};         // (b0 m2, b1 m2)
+  T3 = T3 + b01.x * m01.y;
+  T2 = T2 + b2 * m2;
+}
+#endif
+
 // magnitude m (>= 0) with the sign of the integer j; j == 0 keeps +m (rhat components are +0.0 there)
 __device__ __forceinline__ float with_sign_of(float m, int j) {
   return __uint_as_float(__float_as_uint(m) | ((unsigned)j & 0x80000000u));
@@ -365,15 +406,39 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
     // A zero weight (taps on the rim of the spherical support, feature.hpp:2276) needs no branch: the
     // vote is then (+-0)*m*m and adding +-0 leaves the accumulators bit-for-bit unchanged.
     auto half1 = [&](const f4v& d, const f4v& tw, float mv, float& bse, float& m0, float& m1, float& m2) {
+#if VH_TV_PK
+      float fv = tw.w;
+      if (MASKED_SRC) fv = fv * mv;
+      vote_dir<MODE>(d.w, fv, tw.x, tw.y, tw.z, d.x, d.y, d.z, p.exponent, p.curves, bse, m0, m1, m2);
+#else
       float fv = tw.x;
       if (MASKED_SRC) fv = fv * mv;
       vote_dir<MODE>(d.x, fv, tw.y, tw.z, tw.w, d.y, d.z, d.w, p.exponent, p.curves, bse, m0, m1, m2);
+#endif
     };
     refill();
     read_entry(next_ent(), dA, eA, mvA);
     refill();
     twA = read_table(eA);
     const int npairs = (niter + 1) >> 1;
+#if VH_TV_PK
+    if (MODE != 1) {
+      v2f T01 = {T[0], T[1]}, T54 = {T[5], T[4]};
+      float T3 = T[3], T2 = T[2];
+      for (int it = 0; it < npairs; it++) {
+        read_entry(next_ent(), dB, eB, mvB);
+        refill();
+        twB = read_table(eB);
+        vote_pk<MODE>(dA, twA, mvA, MASKED_SRC, T01, T54, T3, T2);
+        read_entry(next_ent(), dA, eA, mvA);
+        refill();
+        twA = read_table(eA);
+        vote_pk<MODE>(dB, twB, mvB, MASKED_SRC, T01, T54, T3, T2);
+      }
+      T[0] = T01.x; T[1] = T01.y; T[5] = T54.x; T[4] = T54.y; T[3] = T3; T[2] = T2;
+      return;
+    }
+#endif
     for (int it = 0; it < npairs; it++) {
       float bse, m0, m1, m2;
       read_entry(next_ent(), dB, eB, mvB);
@@ -510,7 +575,11 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
                 const unsigned off = voff_of(v, row0, rows);
                 const int slot = n_list + (q - done);
                 unsigned char* ent = l_ent + ENT_BYTES * slot;
+#if VH_TV_PK
+                const float4 a = make_float4(buf_load(rd0, off), buf_load(rd1, off), buf_load(rd2, off), cur[v]);
+#else
                 const float4 a = make_float4(cur[v], buf_load(rd0, off), buf_load(rd1, off), buf_load(rd2, off));
+#endif
                 *reinterpret_cast<float4*>(ent) = a;
                 const int ex = rc_[v] & 0xff, ey = row0 + (rc_[v] >> 8);
                 const int epx = ex - h - 8, epy = ey - h - 8;
@@ -578,7 +647,11 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
   // feature.hpp:2470-2478)
   const size_t m = (size_t)n * n * n;
   std::vector<float4> tab(m);
+#if VH_TV_PK
+  for (size_t k = 0; k < m; k++) tab[k] = make_float4(rhat[3 * k], rhat[3 * k + 1], rhat[3 * k + 2], w[k]);
+#else
   for (size_t k = 0; k < m; k++) tab[k] = make_float4(w[k], rhat[3 * k], rhat[3 * k + 1], rhat[3 * k + 2]);
+#endif
   float4* dtab = nullptr;
   VH_TRY(ws(ctx, WS_TVTAB, tab.size(), &dtab));
   hipStream_t st = ctx->stream;
