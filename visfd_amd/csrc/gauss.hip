@@ -341,7 +341,7 @@ VH_DECL_FUSED(6) VH_DECL_FUSED(7) VH_DECL_FUSED(8)
 #undef VH_DECL_FUSED
 
 // The single-sweep kernel covers the unmasked case with equal half-widths 1..8 on the three axes (any sigma
-// per axis), nx a multiple of 4, and planes below 2 GiB; everything else takes the 3-pass path.  (Beyond h = 8
+// per axis) and planes below 2 GiB; everything else takes the 3-pass path.  (Beyond h = 8
 // the register ring no longer fits 128 VGPRs: the spilling single-sweep kernels ran at 10 and 16 ms for
 // h = 9 and 10 at 1024^3, three bandwidth-bound passes take 5.3 ms.)
 static int dev_gauss_fused(visfd_hip_ctx* ctx, const float* src, float* dst, i64 nx, i64 ny, i64 nz,
@@ -351,7 +351,7 @@ static int dev_gauss_fused(visfd_hip_ctx* ctx, const float* src, float* dst, i64
   *handled = false;
   const int H = tx.h;
   if (ty.h != H || tz.h != H || H < 1 || H > 8) return VISFD_HIP_OK;
-  if ((nx & 3) || nx * ny >= (1LL << 29) || nz >= (1LL << 31)) return VISFD_HIP_OK;
+  if (nx * ny >= (1LL << 29) || nz >= (1LL << 31)) return VISFD_HIP_OK;
   if (src == dst) return VISFD_HIP_OK;  // in place: 3-pass path through scratch volumes
   // the single-sweep kernel's Z pass shares the product of a sample with the taps +j and -j: the Z taps must be
   // symmetric bit for bit (every Gaussian is; arbitrary filters take the 3-pass path)

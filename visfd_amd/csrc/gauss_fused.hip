@@ -91,7 +91,7 @@ __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rs, unsigned by
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)byte_off, 0, 0));
 }
 
-template <int H, int TX, int TY, int NT, int XV_, int YV_, bool NORMALIZE, bool ISO>
+template <int H, int TX, int TY, int NT, int XV_, int YV_, bool NORMALIZE, bool ISO, bool RAGGED>
 __global__ void __launch_bounds__(NT)
 gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH<H> tz, TapsH<H> ty_,
                    TapsH<H> tx_, const float* __restrict__ Dx, const float* __restrict__ Dy,
@@ -151,6 +151,8 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
   }
   int x_off[C::XROUNDS];
   unsigned o_off[C::XROUNDS];  // byte offset of the output quad inside a plane (OOB outside)
+  unsigned e_off[RAGGED ? C::XROUNDS : 1];   // the same for a group cut by the end of its row (RAGGED only)
+  int e_n[RAGGED ? C::XROUNDS : 1];          // and the number of its elements inside the row
   float dxy[C::XROUNDS][C::XV];
   float rcp_int[C::XROUNDS][C::XV];   // 1 / ((Dx*Dy)*Dz) for the planes whose Dz is the interior value dz_int
 #pragma unroll
@@ -159,14 +161,22 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
     const int yy = task / (TX / C::XV), xq = task - yy * (TX / C::XV);
     const int y = wave * C::RPW + yy;
     const int gx = x0 + C::XV * xq, gy = y0 + y;
-    const bool ok = (task < C::XTASKS) && gx < nx && gy < ny;  // nx % 4 == 0: the whole quad is inside
+    const bool ok = (task < C::XTASKS) && gx < nx && gy < ny;
     x_off[r] = (task < C::XTASKS) ? 4 * (y * C::SX + C::XV * xq) : 0;   // bytes
-    o_off[r] = ok ? (unsigned)(gy * nx + gx) * 4u : OOB;
+    // nx a multiple of XV (RAGGED == false): an output group is inside the row or outside it as a whole.
+    // Otherwise the group that straddles the end of a row is written (and its minuend read) element by element:
+    // e_off/e_n describe it, and its vector offset is out of range like that of groups outside the image.
+    const int nval = ok ? min(C::XV, nx - gx) : 0;
+    o_off[r] = (nval == C::XV) ? (unsigned)(gy * nx + gx) * 4u : OOB;
+    if (RAGGED) {
+      e_n[r] = (nval < C::XV) ? nval : 0;
+      e_off[r] = (nval > 0 && nval < C::XV) ? (unsigned)(gy * nx + gx) * 4u : OOB;
+    }
     if (NORMALIZE) {
       const float dy = ok ? Dy[gy] : 1.0f;
 #pragma unroll
       for (int k = 0; k < C::XV; k++) {
-        dxy[r][k] = (ok ? Dx[gx + k] : 1.0f) * dy;  // (Dx*Dy) first, then *Dz (filter3d.hpp:1016-1018)
+        dxy[r][k] = ((ok && gx + k < nx) ? Dx[gx + k] : 1.0f) * dy;  // (Dx*Dy) first, then *Dz (filter3d.hpp:1016-1018)
         rcp_int[r][k] = 1.0f / (dxy[r][k] * dz_int);  // IEEE division: the correctly rounded reciprocal
       }
     }
@@ -353,6 +363,13 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
               const v2f mv = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rm, (int)o_off[r], 0, 0));
               m[0] = mv[0]; m[1] = mv[1];
             }
+            if (RAGGED) {
+#pragma unroll
+              for (int k = 0; k < C::XV - 1; k++) {
+                const float e = buf_load(rm, k < e_n[r] ? e_off[r] + 4u * k : OOB);
+                if (k < e_n[r]) m[k] = e;
+              }
+            }
 #pragma unroll
             for (int k = 0; k < C::XV; k++) {
               const float dd = m[k] - a[k];
@@ -372,6 +389,12 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
           } else {
             v2f out = {a[0], a[1]};
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, out), ro, (int)o_off[r], 0, 0);
+          }
+          if (RAGGED) {
+#pragma unroll
+            for (int k = 0; k < C::XV - 1; k++)
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, a[k]), ro,
+                                                    (int)(k < e_n[r] ? e_off[r] + 4u * k : OOB), 0, 0);
           }
         }
         // One workgroup barrier per plane: sZ is double-buffered (buffer v & 1), so a wave may start the
@@ -415,12 +438,14 @@ int launch_cfg(visfd_hip_ctx* ctx, const float* src, float* dst, i64 nx, i64 ny,
   const i64 nblk = tiles * nchunks;
   if (nblk > 0x7fffffffLL) return fail(VISFD_HIP_EINVAL, "volume too large for one launch");
   dim3 grid((unsigned)nblk), block(NT);
-#define VH_GO(NORM, ISOV)                                                                        \
-  gauss_fused_kernel<H, TX, TY, NT, XV, YV, NORM, ISOV><<<grid, block, 0, ctx->stream>>>(                \
+#define VH_GO(NORM, ISOV, RAG)                                                                   \
+  gauss_fused_kernel<H, TX, TY, NT, XV, YV, NORM, ISOV, RAG><<<grid, block, 0, ctx->stream>>>(           \
       src, dst, a, b, c, Dx, Dy, Dz, dz_offset, (int)nx, (int)ny, (int)nz, (int)zchunk, tiles_x, tiles_y,  \
       minuend, log_scale, dz_int)
-  if (normalize) { if (iso) VH_GO(true, true); else VH_GO(true, false); }
-  else           { if (iso) VH_GO(false, true); else VH_GO(false, false); }
+  // anisotropic taps share the ragged-row instantiation (both are the uncommon cases)
+  const bool ragged = (nx % XV) != 0;
+  if (normalize) { if (iso && !ragged) VH_GO(true, true, false); else VH_GO(true, false, true); }
+  else           { if (iso && !ragged) VH_GO(false, true, false); else VH_GO(false, false, true); }
 #undef VH_GO
   VH_HIP(hipGetLastError());
   return VISFD_HIP_OK;
