@@ -301,6 +301,8 @@ def main():
                        "achieved": round(tv_tflops, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tv_tflops / 157.3, 4),
                        "traffic": None, "ms_per_launch": round(tv_ms, 2), "votes_per_launch": votes,
                        "flop_per_vote": 45, "salient_senders": n_salient, "nonzero_taps": n_taps,
+                       "algorithmic_bytes": 40 * nv, "hbm_achieved_gbs": round(40.0 * nv / (tv_ms * 1e-3) / 1e9, 1),
+                       "hbm_frac": round(40.0 * nv / (tv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                        "note": "peak = nominal FP32 vector rate (packed FMA); the reference's operation order forbids FMA "
                                "and packing, which leaves ~39 T scalar fp32 instructions/s to issue: rocprofv3 VALUBusy of "
                                "this kernel is 95-108 % (profiles/r01_pmc_occupancy_valu.txt, DESIGN.md 4.2)"}
