@@ -296,10 +296,17 @@ def main():
         torch.cuda.synchronize()
         tv_ms = e0.elapsed_time(e1)
         votes = float(n_salient) * n_taps
+        tv_traffic = None   # HBM bytes per launch from PMC counters, measured offline (profiles/r01_tv_traffic.json)
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_tv_traffic.json")))
+            if list(tr["shape"]) == [shape[0], shape[1], shape[2]]:
+                tv_traffic = tr["traffic_bytes"]
+        except Exception:
+            pass
         tv_tflops = 45.0 * votes / (tv_ms * 1e-3) / 1e12
         roofline_tv = {"bound": "valu", "kernel": "tv_tiled_kernel (dense stick tensor voting, sigma_tv=8.66, h=12)",
                        "achieved": round(tv_tflops, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tv_tflops / 157.3, 4),
-                       "traffic": None, "ms_per_launch": round(tv_ms, 2), "votes_per_launch": votes,
+                       "traffic": tv_traffic, "ms_per_launch": round(tv_ms, 2), "votes_per_launch": votes,
                        "flop_per_vote": 45, "salient_senders": n_salient, "nonzero_taps": n_taps,
                        "algorithmic_bytes": 40 * nv, "hbm_achieved_gbs": round(40.0 * nv / (tv_ms * 1e-3) / 1e9, 1),
                        "hbm_frac": round(40.0 * nv / (tv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
