@@ -391,8 +391,7 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
     }
 #endif
     // Software pipeline, unrolled twice (A/B): while vote i is computed, the entry of vote i+1 is
-    // being read, and its table entry is requested half-way through.  An odd count ends with one
-    // extra dummy vote (every lane is at the sentinel by then).
+    // being read, and its table entry is requested half-way through.
     f4v dA, dB, twA, twB;
     int eA, eB;
     float mvA = 1.0f, mvB = 1.0f;
@@ -420,7 +419,8 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
     read_entry(next_ent(), dA, eA, mvA);
     refill();
     twA = read_table(eA);
-    const int npairs = (niter + 1) >> 1;
+    const int npairs = niter >> 1;   // an odd count ends with the single vote after the loop (the pair loop's
+                                     // prefetches beyond the last hit read the dummy entry: harmless)
 #if VH_TV_PK
     if (MODE != 1) {
       v2f T01 = {T[0], T[1]}, T54 = {T[5], T[4]};
@@ -435,6 +435,7 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
         twA = read_table(eA);
         vote_pk<MODE>(dB, twB, mvB, MASKED_SRC, T01, T54, T3, T2);
       }
+      if (niter & 1) vote_pk<MODE>(dA, twA, mvA, MASKED_SRC, T01, T54, T3, T2);
       T[0] = T01.x; T[1] = T01.y; T[5] = T54.x; T[4] = T54.y; T[3] = T3; T[2] = T2;
       return;
     }
@@ -454,6 +455,11 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
       __builtin_amdgcn_sched_barrier(0);
       twA = read_table(eA);
       __builtin_amdgcn_sched_barrier(0);
+      vote_acc(T, bse, m0, m1, m2);
+    }
+    if (niter & 1) {   // uniform
+      float bse, m0, m1, m2;
+      half1(dA, twA, mvA, bse, m0, m1, m2);
       vote_acc(T, bse, m0, m1, m2);
     }
   };
