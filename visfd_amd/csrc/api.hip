@@ -150,12 +150,46 @@ int blob_dog_dev(visfd_hip_ctx* ctx, const float* src, const float* mask, i64 nx
   // ratio mode keeps every candidate and prunes at the end (feature.hpp:362-417), see header.
   const float scan_min = use_ratios ? inf : min_thr;
   const float scan_max = use_ratios ? -inf : max_thr;
-  for (int ir = 0; ir < n_sigma; ir++) {
+  // The scan of scale k-1 is queued right behind the filters of scale k, and its list is fetched (auxiliary stream)
+  // and sorted on the host while the GPU already filters scale k+1: the device never waits for the host.
+  const bool can_scan = nx >= 3 && ny >= 3 && nz >= 3;
+  if (can_scan && (nx >= (1LL << 31) || ny >= (1LL << 31) || nz >= (1LL << 31))) return fail(VISFD_HIP_EINVAL, "dimension too large");
+  if (!ctx->aux_stream) VH_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  for (int k = 0; k < 2; k++) VH_HIP(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+  int rc_loop = VISFD_HIP_OK;
+  bool redo = false;
+  int pending = -1;   // middle scale whose scan is queued but not collected yet (buffer set: pending & 1)
+  auto collect = [&](int scale) -> int {
+    bool overflow = false;
+    VH_TRY(blob_scan_collect(ctx, scale & 1, ev[scale & 1], ctx->aux_stream, nx, ny, scale, blob_sigma[scale], &mins,
+                             &maxs, &overflow));
+    if (overflow) redo = true;
+    return VISFD_HIP_OK;
+  };
+  for (int ir = 0; ir < n_sigma && rc_loop == VISFD_HIP_OK; ir++) {
     const float sg[3] = {blob_sigma[ir] * asp[0], blob_sigma[ir] * asp[1], blob_sigma[ir] * asp[2]};
-    VH_TRY(log_dev(ctx, src, vol[ir % 3], tmp, mask, nx, ny, nz, sg, delta, ratio, nullptr, nullptr));
-    if (ir < 2) continue;
-    VH_TRY(dev_blob_scan(ctx, vol[(ir - 2) % 3], vol[(ir - 1) % 3], vol[ir % 3], mask, nx, ny, nz, ir - 1,
-                         blob_sigma[ir - 1], scan_min, scan_max, true, true, &mins, &maxs));
+    rc_loop = log_dev(ctx, src, vol[ir % 3], tmp, mask, nx, ny, nz, sg, delta, ratio, nullptr, nullptr);
+    if (rc_loop != VISFD_HIP_OK || ir < 2 || !can_scan) continue;
+    rc_loop = blob_scan_launch(ctx, (ir - 1) & 1, ev[(ir - 1) & 1], vol[(ir - 2) % 3], vol[(ir - 1) % 3], vol[ir % 3], mask,
+                               nx, ny, nz, scan_min, scan_max);
+    if (rc_loop != VISFD_HIP_OK) continue;
+    if (pending >= 0) rc_loop = collect(pending);
+    pending = ir - 1;
+  }
+  if (rc_loop == VISFD_HIP_OK && pending >= 0) rc_loop = collect(pending);
+  for (int k = 0; k < 2; k++) (void)hipEventDestroy(ev[k]);
+  VH_TRY(rc_loop);
+  if (redo) {
+    // a candidate or survivor buffer overflowed (dense extrema): repeat scale by scale with buffers that grow
+    mins.clear(); maxs.clear();
+    for (int ir = 0; ir < n_sigma; ir++) {
+      const float sg[3] = {blob_sigma[ir] * asp[0], blob_sigma[ir] * asp[1], blob_sigma[ir] * asp[2]};
+      VH_TRY(log_dev(ctx, src, vol[ir % 3], tmp, mask, nx, ny, nz, sg, delta, ratio, nullptr, nullptr));
+      if (ir < 2) continue;
+      VH_TRY(dev_blob_scan(ctx, vol[(ir - 2) % 3], vol[(ir - 1) % 3], vol[ir % 3], mask, nx, ny, nz, ir - 1,
+                           blob_sigma[ir - 1], scan_min, scan_max, true, true, &mins, &maxs));
+    }
   }
   if ((min_thr != inf) || (max_thr != -inf)) {
     float tmin = min_thr, tmax = max_thr;
@@ -251,6 +285,7 @@ int visfd_hip_trim(visfd_hip_ctx* ctx) {
 int visfd_hip_destroy(visfd_hip_ctx* ctx) {
   if (!ctx) return VISFD_HIP_OK;
   int rc = visfd_hip_trim(ctx);
+  if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return rc;

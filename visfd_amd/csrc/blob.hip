@@ -174,12 +174,17 @@ blob_candidates_kernel(const float* __restrict__ mid, const float* __restrict__ 
 }
 
 __global__ void __launch_bounds__(BLOCK)
-blob_verify_kernel(const unsigned long long* __restrict__ cand_idx, unsigned long long n_cand,
+blob_verify_kernel(const unsigned long long* __restrict__ cand_idx, const unsigned long long* __restrict__ n_cand_ptr,
+                   unsigned long long cand_capacity,
                    const float* __restrict__ lo, const float* __restrict__ mid, const float* __restrict__ hi,
                    const float* __restrict__ mask, int nx, int ny, int nz, float min_thr, float max_thr,
                    Cand* __restrict__ out, unsigned long long capacity, unsigned long long* __restrict__ counter) {
-  const unsigned long long t = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
-  if (t >= n_cand) return;
+  // the number of candidates is read on the device (no host round trip between the two kernels); an overflowed
+  // candidate list is cut at its capacity here and reported by the host afterwards
+  unsigned long long n_cand = *n_cand_ptr;
+  if (n_cand > cand_capacity) n_cand = cand_capacity;
+  for (unsigned long long t = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; t < n_cand;
+       t += (unsigned long long)gridDim.x * BLOCK) {
   const i64 c = (i64)cand_idx[t];
   const i64 plane = (i64)nx * ny;
   const int iz = (int)(c / plane);
@@ -221,10 +226,136 @@ blob_verify_kernel(const unsigned long long* __restrict__ cand_idx, unsigned lon
       out[slot] = cd;
     }
   }
+  }   // next candidate of this thread
 }
 
 }  // namespace
 
+// The scan of one scale in two halves, so that a caller can queue the next scale's filters before it waits for
+// this scale's list (BlobDog runs a dozen scales back to back): blob_scan_launch only enqueues the two kernels on
+// the context's stream (buffer set 0 or 1: candidate codes, survivors, counters) and records an event;
+// blob_scan_collect waits for that event on an auxiliary stream, copies the survivors to the host there (the main
+// stream keeps running), sorts them and appends them to the lists.  Returns 1 when a buffer overflowed (the caller
+// then repeats the scale with dev_blob_scan, which grows the buffers).
+struct ScanBufs {
+  unsigned long long* idx = nullptr;
+  Cand* cand = nullptr;
+  unsigned long long* counters = nullptr;   // [0]: candidates, [1]: verified
+  size_t cap_idx = 0, cap_out = 0;
+};
+
+static int scan_bufs(visfd_hip_ctx* ctx, int set, ScanBufs* B) {
+  size_t cap_idx = ctx->slot_bytes[WS_TVAUX] / sizeof(unsigned long long) / 2;
+  if (cap_idx < (1u << 22)) cap_idx = 1u << 22;
+  size_t cap_out = ctx->slot_bytes[WS_CAND] / sizeof(Cand) / 2;
+  if (cap_out < (1u << 20)) cap_out = 1u << 20;
+  unsigned long long* idx = nullptr;
+  Cand* cand = nullptr;
+  unsigned long long* counters = nullptr;
+  VH_TRY(ws(ctx, WS_TVAUX, 2 * cap_idx, &idx));
+  VH_TRY(ws(ctx, WS_CAND, 2 * cap_out, &cand));
+  VH_TRY(ws(ctx, WS_COUNTER, 8, &counters));
+  B->idx = idx + (size_t)set * cap_idx;
+  B->cand = cand + (size_t)set * cap_out;
+  B->counters = counters + 2 * set;
+  B->cap_idx = cap_idx;
+  B->cap_out = cap_out;
+  return VISFD_HIP_OK;
+}
+
+static void sort_and_append(std::vector<Cand>& h, i64 nx, i64 ny, int scale_index, float sigma,
+                            std::vector<visfd_hip_blob>* minima, std::vector<visfd_hip_blob>* maxima) {
+  // deterministic order (the device appends in arrival order): by (iz, iy, ix), i.e. by linear voxel index.
+  // LSD radix sort of (index, position) pairs: lists reach 250 k entries per scale at 1024^3, where a
+  // comparison sort of the records cost 12 ms.
+  const size_t m = h.size();
+  std::vector<unsigned long long> key(m), key2(m);
+  std::vector<unsigned int> pos(m), pos2(m);
+  unsigned long long maxkey = 0;
+  for (size_t i = 0; i < m; i++) {
+    key[i] = (unsigned long long)(((i64)h[i].iz * ny + h[i].iy) * nx + h[i].ix);
+    pos[i] = (unsigned int)i;
+    if (key[i] > maxkey) maxkey = key[i];
+  }
+  constexpr int RB = 11;
+  for (int shift = 0; shift < 64 && (maxkey >> shift) != 0; shift += RB) {
+    size_t hist[(1 << RB) + 1] = {0};
+    for (size_t i = 0; i < m; i++) hist[((key[i] >> shift) & ((1u << RB) - 1)) + 1]++;
+    for (int b = 0; b < (1 << RB); b++) hist[b + 1] += hist[b];
+    for (size_t i = 0; i < m; i++) {
+      const size_t d = hist[(key[i] >> shift) & ((1u << RB) - 1)]++;
+      key2[d] = key[i];
+      pos2[d] = pos[i];
+    }
+    key.swap(key2);
+    pos.swap(pos2);
+  }
+  for (size_t i = 0; i < m; i++) {
+    const Cand& cd = h[pos[i]];
+    visfd_hip_blob bl;
+    bl.ix = cd.ix; bl.iy = cd.iy; bl.iz = cd.iz;
+    bl.scale = scale_index;
+    bl.sigma = sigma;
+    bl.score = cd.score;
+    (cd.kind == 0 ? minima : maxima)->push_back(bl);
+  }
+}
+
+static int scan_enqueue(visfd_hip_ctx* ctx, const ScanBufs& B, const float* lo, const float* mid, const float* hi,
+                        const float* mask, i64 nx, i64 ny, i64 nz, float min_thr, float max_thr) {
+  hipStream_t st = ctx->stream;
+  const int tiles_x = (int)((nx + TX - 1) / TX), tiles_y = (int)((ny + TY - 1) / TY);
+  const i64 tiles = (i64)tiles_x * tiles_y;
+  i64 want_chunks = ((i64)ctx->num_cus * 16 + tiles - 1) / tiles;
+  if (want_chunks < 1) want_chunks = 1;
+  i64 zchunk = (nz + want_chunks - 1) / want_chunks;
+  if (zchunk < 16) zchunk = 16;
+  const i64 nchunks = (nz + zchunk - 1) / zchunk;
+  const i64 nblocks = tiles * nchunks;
+  if (nblocks > 0x7fffffffLL) return fail(VISFD_HIP_EINVAL, "volume too large for one launch");
+  VH_HIP(hipMemsetAsync(B.counters, 0, 2 * sizeof(unsigned long long), st));
+  blob_candidates_kernel<<<dim3((unsigned)nblocks), dim3(BLOCK), 0, st>>>(
+      mid, mask, (int)nx, (int)ny, (int)nz, min_thr, max_thr, (int)zchunk, tiles_x, tiles_y, B.idx,
+      (unsigned long long)B.cap_idx, B.counters);
+  VH_HIP(hipGetLastError());
+  blob_verify_kernel<<<dim3((unsigned)(ctx->num_cus * 8)), dim3(BLOCK), 0, st>>>(
+      B.idx, B.counters, (unsigned long long)B.cap_idx, lo, mid, hi, mask, (int)nx, (int)ny, (int)nz, min_thr, max_thr,
+      B.cand, (unsigned long long)B.cap_out, B.counters + 1);
+  VH_HIP(hipGetLastError());
+  return VISFD_HIP_OK;
+}
+
+int blob_scan_launch(visfd_hip_ctx* ctx, int set, hipEvent_t done, const float* lo, const float* mid, const float* hi,
+                     const float* mask, i64 nx, i64 ny, i64 nz, float min_thr, float max_thr) {
+  ScanBufs B;
+  VH_TRY(scan_bufs(ctx, set, &B));
+  VH_TRY(scan_enqueue(ctx, B, lo, mid, hi, mask, nx, ny, nz, min_thr, max_thr));
+  VH_HIP(hipEventRecord(done, ctx->stream));
+  return VISFD_HIP_OK;
+}
+
+int blob_scan_collect(visfd_hip_ctx* ctx, int set, hipEvent_t done, hipStream_t aux, i64 nx, i64 ny, int scale_index,
+                      float sigma, std::vector<visfd_hip_blob>* minima, std::vector<visfd_hip_blob>* maxima,
+                      bool* overflow) {
+  ScanBufs B;
+  VH_TRY(scan_bufs(ctx, set, &B));   // (sizes unchanged since the launch: same pointers)
+  *overflow = false;
+  VH_HIP(hipStreamWaitEvent(aux, done, 0));
+  unsigned long long c2[2] = {0, 0};
+  VH_HIP(hipMemcpyAsync(c2, B.counters, sizeof(c2), hipMemcpyDeviceToHost, aux));
+  VH_HIP(hipStreamSynchronize(aux));
+  if (getenv("VISFD_HIP_DEBUG")) fprintf(stderr, "[blob scan] scale %d: %llu candidates, %llu blobs\n", scale_index, c2[0], c2[1]);
+  if (c2[0] > B.cap_idx || c2[1] > B.cap_out) { *overflow = true; return VISFD_HIP_OK; }
+  std::vector<Cand> h((size_t)c2[1]);
+  if (c2[1]) {
+    VH_HIP(hipMemcpyAsync(h.data(), B.cand, sizeof(Cand) * (size_t)c2[1], hipMemcpyDeviceToHost, aux));
+    VH_HIP(hipStreamSynchronize(aux));
+  }
+  sort_and_append(h, nx, ny, scale_index, sigma, minima, maxima);
+  return VISFD_HIP_OK;
+}
+
+// One scale, synchronously (also the fallback of the pipelined form: grows its buffers until the lists fit).
 int dev_blob_scan(visfd_hip_ctx* ctx, const float* lo, const float* mid, const float* hi,
                   const float* mask, i64 nx, i64 ny, i64 nz, int scale_index, float sigma,
                   float min_thr, float max_thr, bool want_min, bool want_max,
@@ -236,91 +367,30 @@ int dev_blob_scan(visfd_hip_ctx* ctx, const float* lo, const float* mid, const f
   if (!want_min) min_thr = -inf;   // nothing is < -inf
   if (!want_max) max_thr = inf;
   hipStream_t st = ctx->stream;
-  unsigned long long* counters = nullptr;   // [0]: candidates, [1]: verified
-  VH_TRY(ws(ctx, WS_COUNTER, 2, &counters));
-  const int tiles_x = (int)((nx + TX - 1) / TX), tiles_y = (int)((ny + TY - 1) / TY);
-  const i64 tiles = (i64)tiles_x * tiles_y;
-  i64 want_chunks = ((i64)ctx->num_cus * 16 + tiles - 1) / tiles;
-  if (want_chunks < 1) want_chunks = 1;
-  i64 zchunk = (nz + want_chunks - 1) / want_chunks;
-  if (zchunk < 16) zchunk = 16;
-  const i64 nchunks = (nz + zchunk - 1) / zchunk;
-  const i64 nblocks = tiles * nchunks;
-  if (nblocks > 0x7fffffffLL) return fail(VISFD_HIP_EINVAL, "volume too large for one launch");
-
-  size_t cap_idx = ctx->slot_bytes[WS_TVAUX] / sizeof(unsigned long long);
-  if (cap_idx < (1u << 22)) cap_idx = 1u << 22;
-  size_t cap_out = ctx->slot_bytes[WS_CAND] / sizeof(Cand);
-  if (cap_out < (1u << 20)) cap_out = 1u << 20;
-  for (int attempt = 0; attempt < 3; attempt++) {
-    unsigned long long* idx = nullptr;
-    Cand* cand = nullptr;
-    VH_TRY(ws(ctx, WS_TVAUX, cap_idx, &idx));
-    VH_TRY(ws(ctx, WS_CAND, cap_out, &cand));
-    VH_HIP(hipMemsetAsync(counters, 0, 2 * sizeof(unsigned long long), st));
-    blob_candidates_kernel<<<dim3((unsigned)nblocks), dim3(BLOCK), 0, st>>>(
-        mid, mask, (int)nx, (int)ny, (int)nz, min_thr, max_thr, (int)zchunk, tiles_x, tiles_y, idx,
-        (unsigned long long)cap_idx, counters);
-    VH_HIP(hipGetLastError());
-    unsigned long long n_cand = 0;
-    VH_HIP(hipMemcpyAsync(&n_cand, counters, sizeof(n_cand), hipMemcpyDeviceToHost, st));
+  for (int attempt = 0; attempt < 4; attempt++) {
+    ScanBufs B;
+    VH_TRY(scan_bufs(ctx, 0, &B));
+    VH_TRY(scan_enqueue(ctx, B, lo, mid, hi, mask, nx, ny, nz, min_thr, max_thr));
+    unsigned long long c2[2] = {0, 0};
+    VH_HIP(hipMemcpyAsync(c2, B.counters, sizeof(c2), hipMemcpyDeviceToHost, st));
     VH_HIP(hipStreamSynchronize(st));
-    if (getenv("VISFD_HIP_DEBUG")) fprintf(stderr, "[blob scan] scale %d: %llu candidates\n", scale_index, n_cand);
-    if (n_cand > cap_idx) { cap_idx = (size_t)n_cand; continue; }   // rare: grow and rescan
-    unsigned long long count = 0;
-    if (n_cand) {
-      const unsigned g = (unsigned)((n_cand + BLOCK - 1) / BLOCK);
-      blob_verify_kernel<<<dim3(g), dim3(BLOCK), 0, st>>>(idx, n_cand, lo, mid, hi, mask, (int)nx, (int)ny,
-                                                         (int)nz, min_thr, max_thr, cand,
-                                                         (unsigned long long)cap_out, counters + 1);
-      VH_HIP(hipGetLastError());
-      VH_HIP(hipMemcpyAsync(&count, counters + 1, sizeof(count), hipMemcpyDeviceToHost, st));
-      VH_HIP(hipStreamSynchronize(st));
-      if (count > cap_out) { cap_out = (size_t)count; continue; }
+    if (getenv("VISFD_HIP_DEBUG")) fprintf(stderr, "[blob scan] scale %d: %llu candidates\n", scale_index, c2[0]);
+    if (c2[0] > B.cap_idx) {   // rare: grow and rescan
+      unsigned long long* p = nullptr;
+      VH_TRY(ws(ctx, WS_TVAUX, 2 * (size_t)c2[0] + 16, &p));
+      continue;
     }
-    std::vector<Cand> h((size_t)count);
-    if (count) {
-      VH_HIP(hipMemcpyAsync(h.data(), cand, sizeof(Cand) * (size_t)count, hipMemcpyDeviceToHost, st));
+    if (c2[1] > B.cap_out) {
+      Cand* p = nullptr;
+      VH_TRY(ws(ctx, WS_CAND, 2 * (size_t)c2[1] + 16, &p));
+      continue;
+    }
+    std::vector<Cand> h((size_t)c2[1]);
+    if (c2[1]) {
+      VH_HIP(hipMemcpyAsync(h.data(), B.cand, sizeof(Cand) * (size_t)c2[1], hipMemcpyDeviceToHost, st));
       VH_HIP(hipStreamSynchronize(st));
     }
-    // deterministic order (the device appends in arrival order): by (iz, iy, ix), i.e. by linear voxel index.
-    // LSD radix sort of (index, position) pairs: lists reach 250 k entries per scale at 1024^3, where a
-    // comparison sort of the records cost 12 ms.
-    {
-      const size_t m = h.size();
-      std::vector<unsigned long long> key(m), key2(m);
-      std::vector<unsigned int> pos(m), pos2(m);
-      unsigned long long maxkey = 0;
-      for (size_t i = 0; i < m; i++) {
-        key[i] = (unsigned long long)(((i64)h[i].iz * ny + h[i].iy) * nx + h[i].ix);
-        pos[i] = (unsigned int)i;
-        if (key[i] > maxkey) maxkey = key[i];
-      }
-      constexpr int RB = 11;
-      for (int shift = 0; shift < 64 && (maxkey >> shift) != 0; shift += RB) {
-        size_t hist[(1 << RB) + 1] = {0};
-        for (size_t i = 0; i < m; i++) hist[((key[i] >> shift) & ((1u << RB) - 1)) + 1]++;
-        for (int b = 0; b < (1 << RB); b++) hist[b + 1] += hist[b];
-        for (size_t i = 0; i < m; i++) {
-          const size_t d = hist[(key[i] >> shift) & ((1u << RB) - 1)]++;
-          key2[d] = key[i];
-          pos2[d] = pos[i];
-        }
-        key.swap(key2);
-        pos.swap(pos2);
-      }
-      std::vector<Cand> sorted(m);
-      for (size_t i = 0; i < m; i++) sorted[i] = h[pos[i]];
-      h.swap(sorted);
-    }
-    for (const Cand& cd : h) {
-      visfd_hip_blob bl;
-      bl.ix = cd.ix; bl.iy = cd.iy; bl.iz = cd.iz;
-      bl.scale = scale_index;
-      bl.sigma = sigma;
-      bl.score = cd.score;
-      (cd.kind == 0 ? minima : maxima)->push_back(bl);
-    }
+    sort_and_append(h, nx, ny, scale_index, sigma, minima, maxima);
     return VISFD_HIP_OK;
   }
   return fail(VISFD_HIP_EDEVICE, "blob candidate list kept overflowing");

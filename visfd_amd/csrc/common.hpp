@@ -62,6 +62,7 @@ struct visfd_hip_ctx {
   void* slot_ptr[vh::WS_NSLOTS] = {};
   size_t slot_bytes[vh::WS_NSLOTS] = {};
   int num_cus = 256;
+  hipStream_t aux_stream = nullptr;   // host copies that must not queue behind the main stream's kernels
 };
 
 namespace vh {
@@ -113,6 +114,11 @@ int dev_sub_scale(visfd_hip_ctx* ctx, float* a_inout, const float* b, i64 n, flo
 int dev_sub_square(visfd_hip_ctx* ctx, const float* a, const float* b, float* out, i64 n);   // out = (a-b)*(a-b)
 int dev_scale_clamp_sqrt(visfd_hip_ctx* ctx, float* a_inout, i64 n, float scale);           // a = sqrt(max(a*scale, 0))
 
+int blob_scan_launch(visfd_hip_ctx* ctx, int set, hipEvent_t done, const float* lo, const float* mid, const float* hi,
+                     const float* mask, i64 nx, i64 ny, i64 nz, float min_thr, float max_thr);
+int blob_scan_collect(visfd_hip_ctx* ctx, int set, hipEvent_t done, hipStream_t aux, i64 nx, i64 ny, int scale_index,
+                      float sigma, std::vector<visfd_hip_blob>* minima, std::vector<visfd_hip_blob>* maxima,
+                      bool* overflow);
 int dev_blob_scan(visfd_hip_ctx* ctx, const float* lo, const float* mid, const float* hi,
                   const float* mask, i64 nx, i64 ny, i64 nz, int scale_index, float sigma,
                   float min_thr, float max_thr, bool want_min, bool want_max,

@@ -263,6 +263,24 @@ scale_clamp_sqrt_kernel(float* __restrict__ a, i64 n, float scale) {
   }
 }
 
+// Boundary normaliser lines Dx | Dy | Dz (filter3d.hpp:1004-1021): each axis filter applied to a line of ones of the
+// global length -- acc = 0; acc += t[j] * 1 for the taps whose sample lies inside, j ascending (host_conv_ones).
+__global__ void __launch_bounds__(BLOCK)
+norm_lines_kernel(float* __restrict__ D, i64 nx, i64 ny, i64 nz, Taps tx, Taps ty, Taps tz) {
+  const i64 g = (i64)blockIdx.x * BLOCK + threadIdx.x;
+  if (g >= nx + ny + nz) return;
+  const Taps& T = g < nx ? tx : (g < nx + ny ? ty : tz);
+  const i64 n = g < nx ? nx : (g < nx + ny ? ny : nz);
+  const i64 i = g < nx ? g : (g < nx + ny ? g - nx : g - nx - ny);
+  float acc = 0.0f;
+  for (int j = -T.h; j <= T.h; j++) {
+    const i64 k = i - j;
+    if (k < 0 || k >= n) continue;
+    acc += T.t[j + T.h] * 1.0f;
+  }
+  D[g] = acc;
+}
+
 int fill_taps(Taps* T, const float* t, int h) {
   if (h < 0 || h > MAX_HALFWIDTH)
     return fail(VISFD_HIP_EINVAL, "filter halfwidth must be in [0, 64]");
@@ -388,16 +406,14 @@ int dev_separable3d(visfd_hip_ctx* ctx, const float* src, float* dst, const floa
   // boundary normaliser lines (unmasked case): host arithmetic, a few KB
   float *Dx = nullptr, *Dy = nullptr, *Dz = nullptr;
   if (normalize && !mask) {
+    // filled on the device (same float sums as host_conv_ones): no host copy, no stream synchronisation --
+    // a dozen Gaussians in a row (blob detection) stay queued back to back
     float* D = nullptr;
     const i64 total = nx + ny + slab.nz_global;
     VH_TRY(ws(ctx, WS_NORM, (size_t)total, &D));
-    std::vector<float> hD((size_t)total);
-    host_conv_ones(nx, tx, hx, hD.data());
-    host_conv_ones(ny, ty, hy, hD.data() + nx);
-    host_conv_ones(slab.nz_global, tz, hz, hD.data() + nx + ny);
-    // synchronous copy from pageable memory: the host vector may die right after this call
-    VH_HIP(hipMemcpyAsync(D, hD.data(), sizeof(float) * (size_t)total, hipMemcpyHostToDevice, st));
-    VH_HIP(hipStreamSynchronize(st));
+    norm_lines_kernel<<<dim3((unsigned)((total + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st>>>(D, nx, ny, slab.nz_global,
+                                                                                            Tx, Ty, Tz);
+    VH_HIP(hipGetLastError());
     Dx = D; Dy = D + nx; Dz = D + nx + ny;
   }
 
