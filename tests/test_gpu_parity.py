@@ -293,6 +293,22 @@ def test_saliency_direction_threshold(ctx, oracle):
 
 
 # ------------------------------------------------------------------------------------------ tensor voting
+
+def test_blob_scan_overflow_path(ctx, oracle, monkeypatch):
+    """The pipelined scale-space scan falls back to the synchronous, buffer-growing scan when a candidate or survivor
+    buffer overflows: with buffers of 8 entries (test hook) the lists must still equal the oracle's."""
+    src = volgen.blob_volume(volgen.BLOB_SHAPE, seed=201)
+    sig = oracle.diameters_to_sigmas(volgen.BLOB_DIAMS)
+    r = ratio(oracle)
+    want = oracle.blob_dog(src, sig, None, None, 0.02, r, np.inf, -np.inf, False)
+    monkeypatch.setenv("VISFD_HIP_BLOB_TEST_CAP", "8")
+    got = ctx.blob_dog(src, sig, None, None, 0.02, r, np.inf, -np.inf, False)
+    monkeypatch.delenv("VISFD_HIP_BLOB_TEST_CAP")
+    assert len(want[0]) > 8 or len(want[1]) > 8
+    for g, w, asc in ((got[0], want[0], True), (got[1], want[1], False)):
+        assert_bits_equal(volgen.sort_blobs(g, asc), volgen.sort_blobs(w, asc), "blob list through the overflow path")
+
+
 @pytest.mark.parametrize("tag", ["nomask", "mask"])
 def test_tensor_voting_seeded(ctx, oracle, tag, monkeypatch):
     g = golden("membrane_seeded")

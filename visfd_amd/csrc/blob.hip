@@ -244,7 +244,7 @@ struct ScanBufs {
   size_t cap_idx = 0, cap_out = 0;
 };
 
-static int scan_bufs(visfd_hip_ctx* ctx, int set, ScanBufs* B) {
+static int scan_bufs(visfd_hip_ctx* ctx, int set, ScanBufs* B, bool pipelined) {
   size_t cap_idx = ctx->slot_bytes[WS_TVAUX] / sizeof(unsigned long long) / 2;
   if (cap_idx < (1u << 22)) cap_idx = 1u << 22;
   size_t cap_out = ctx->slot_bytes[WS_CAND] / sizeof(Cand) / 2;
@@ -260,6 +260,13 @@ static int scan_bufs(visfd_hip_ctx* ctx, int set, ScanBufs* B) {
   B->counters = counters + 2 * set;
   B->cap_idx = cap_idx;
   B->cap_out = cap_out;
+  if (pipelined) {   // test hook: pretend the buffers of the pipelined form are tiny, so that its overflow path runs
+    if (const char* e = getenv("VISFD_HIP_BLOB_TEST_CAP")) {
+      const size_t v = (size_t)atoll(e);
+      if (v >= 1 && v < B->cap_idx) B->cap_idx = v;
+      if (v >= 1 && v < B->cap_out) B->cap_out = v;
+    }
+  }
   return VISFD_HIP_OK;
 }
 
@@ -328,7 +335,7 @@ static int scan_enqueue(visfd_hip_ctx* ctx, const ScanBufs& B, const float* lo, 
 int blob_scan_launch(visfd_hip_ctx* ctx, int set, hipEvent_t done, const float* lo, const float* mid, const float* hi,
                      const float* mask, i64 nx, i64 ny, i64 nz, float min_thr, float max_thr) {
   ScanBufs B;
-  VH_TRY(scan_bufs(ctx, set, &B));
+  VH_TRY(scan_bufs(ctx, set, &B, true));
   VH_TRY(scan_enqueue(ctx, B, lo, mid, hi, mask, nx, ny, nz, min_thr, max_thr));
   VH_HIP(hipEventRecord(done, ctx->stream));
   return VISFD_HIP_OK;
@@ -338,7 +345,7 @@ int blob_scan_collect(visfd_hip_ctx* ctx, int set, hipEvent_t done, hipStream_t 
                       float sigma, std::vector<visfd_hip_blob>* minima, std::vector<visfd_hip_blob>* maxima,
                       bool* overflow) {
   ScanBufs B;
-  VH_TRY(scan_bufs(ctx, set, &B));   // (sizes unchanged since the launch: same pointers)
+  VH_TRY(scan_bufs(ctx, set, &B, true));   // (sizes unchanged since the launch: same pointers)
   *overflow = false;
   VH_HIP(hipStreamWaitEvent(aux, done, 0));
   unsigned long long c2[2] = {0, 0};
@@ -369,7 +376,7 @@ int dev_blob_scan(visfd_hip_ctx* ctx, const float* lo, const float* mid, const f
   hipStream_t st = ctx->stream;
   for (int attempt = 0; attempt < 4; attempt++) {
     ScanBufs B;
-    VH_TRY(scan_bufs(ctx, 0, &B));
+    VH_TRY(scan_bufs(ctx, 0, &B, false));
     VH_TRY(scan_enqueue(ctx, B, lo, mid, hi, mask, nx, ny, nz, min_thr, max_thr));
     unsigned long long c2[2] = {0, 0};
     VH_HIP(hipMemcpyAsync(c2, B.counters, sizeof(c2), hipMemcpyDeviceToHost, st));
