@@ -357,6 +357,13 @@ int launch_row(visfd_hip_ctx* ctx, const float* in, float* out, const float* den
 VH_DECL_FUSED(1) VH_DECL_FUSED(2) VH_DECL_FUSED(3) VH_DECL_FUSED(4) VH_DECL_FUSED(5)
 VH_DECL_FUSED(6) VH_DECL_FUSED(7) VH_DECL_FUSED(8)
 #undef VH_DECL_FUSED
+#define VH_DECL_FUSED_YX(HH)                                                                       \
+  int launch_gauss_fused_yx_h##HH(visfd_hip_ctx* ctx, const float* src, float* dst, i64 nx, i64 ny, \
+                                  i64 nz, const Taps& tx, const Taps& ty, const float* numer,       \
+                                  const float* minuend, float log_scale);
+VH_DECL_FUSED_YX(1) VH_DECL_FUSED_YX(2) VH_DECL_FUSED_YX(3) VH_DECL_FUSED_YX(4) VH_DECL_FUSED_YX(5)
+VH_DECL_FUSED_YX(6) VH_DECL_FUSED_YX(7) VH_DECL_FUSED_YX(8)
+#undef VH_DECL_FUSED_YX
 
 // The single-sweep kernel covers the unmasked case with equal half-widths 1..8 on the three axes (any sigma
 // per axis) and planes below 2 GiB; everything else takes the 3-pass path.  (Beyond h = 8
@@ -382,6 +389,28 @@ static int dev_gauss_fused(visfd_hip_ctx* ctx, const float* src, float* dst, i64
   *handled = true;
   switch (H) {
 #define VH_CASE(HH) case HH: return launch_gauss_fused_h##HH(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, cfg, minuend, log_scale);
+    VH_CASE(1) VH_CASE(2) VH_CASE(3) VH_CASE(4) VH_CASE(5) VH_CASE(6) VH_CASE(7) VH_CASE(8)
+#undef VH_CASE
+  }
+  *handled = false;
+  return VISFD_HIP_OK;
+}
+
+// Y and X passes in one sweep (the masked filter after its Z pass): equal half-widths 1..8 in x and y, planes
+// below 2 GiB; numer != null selects the masked-normalisation epilogue.
+static int dev_gauss_fused_yx(visfd_hip_ctx* ctx, const float* src, float* dst, i64 nx, i64 ny, i64 nz, const Taps& tx,
+                              const Taps& ty, const float* numer, const float* minuend, float log_scale,
+                              bool* handled) {
+  *handled = false;
+  const int H = tx.h;
+  if (ty.h != H || H < 1 || H > 8) return VISFD_HIP_OK;
+  if (nx * ny >= (1LL << 29) || nz >= (1LL << 31)) return VISFD_HIP_OK;
+  if (src == dst || numer == dst) return VISFD_HIP_OK;
+  const char* force = getenv("VISFD_HIP_GAUSS_3PASS");
+  if (force && force[0] == '1') return VISFD_HIP_OK;
+  *handled = true;
+  switch (H) {
+#define VH_CASE(HH) case HH: return launch_gauss_fused_yx_h##HH(ctx, src, dst, nx, ny, nz, tx, ty, numer, minuend, log_scale);
     VH_CASE(1) VH_CASE(2) VH_CASE(3) VH_CASE(4) VH_CASE(5) VH_CASE(6) VH_CASE(7) VH_CASE(8)
 #undef VH_CASE
   }
@@ -441,18 +470,32 @@ int dev_separable3d(visfd_hip_ctx* ctx, const float* src, float* dst, const floa
     if (normalize) VH_TRY(launch_row<NORM_BOX>(ctx, B, dst, nullptr, Dx, Dy, Dz, slab.z_lo, Tx, nx, ny, nz, minuend, log_scale));
     else VH_TRY(launch_row<NORM_NONE>(ctx, B, dst, nullptr, nullptr, nullptr, nullptr, 0, Tx, nx, ny, nz, minuend, log_scale));
   } else if (!normalize) {
+    // masked: the Z pass applies the mask (one bandwidth-bound kernel); Y and X then run as one sweep where the
+    // single-sweep kernel applies (36 instead of 52 bytes per voxel for the normalised filter)
     VH_TRY(launch_march<true>(ctx, 2, src, A, mask, nullptr, Tz, nx, ny, nz));
-    VH_TRY(launch_march<false>(ctx, 1, A, B, nullptr, nullptr, Ty, nx, ny, nz));
-    VH_TRY(launch_row<NORM_NONE>(ctx, B, dst, nullptr, nullptr, nullptr, nullptr, 0, Tx, nx, ny, nz, minuend, log_scale));
+    bool yx = false;
+    VH_TRY(dev_gauss_fused_yx(ctx, A, dst, nx, ny, nz, Tx, Ty, nullptr, minuend, log_scale, &yx));
+    if (!yx) {
+      VH_TRY(launch_march<false>(ctx, 1, A, B, nullptr, nullptr, Ty, nx, ny, nz));
+      VH_TRY(launch_row<NORM_NONE>(ctx, B, dst, nullptr, nullptr, nullptr, nullptr, 0, Tx, nx, ny, nz, minuend, log_scale));
+    }
   } else {
     float *DA = nullptr, *DB = nullptr;
     VH_TRY(ws(ctx, WS_DEN_A, (size_t)n, &DA));
     VH_TRY(ws(ctx, WS_DEN_B, (size_t)n, &DB));
     VH_TRY(launch_march<true>(ctx, 2, src, A, mask, DA, Tz, nx, ny, nz));
-    VH_TRY(launch_march<false>(ctx, 1, A, B, nullptr, nullptr, Ty, nx, ny, nz));
-    VH_TRY(launch_march<false>(ctx, 1, DA, DB, nullptr, nullptr, Ty, nx, ny, nz));
-    VH_TRY(launch_row<NORM_NONE>(ctx, DB, DA, nullptr, nullptr, nullptr, nullptr, 0, Tx, nx, ny, nz));
-    VH_TRY(launch_row<NORM_DEN>(ctx, B, dst, DA, nullptr, nullptr, nullptr, 0, Tx, nx, ny, nz, minuend, log_scale));
+    bool yx = false;
+    VH_TRY(dev_gauss_fused_yx(ctx, A, B, nx, ny, nz, Tx, Ty, nullptr, nullptr, 1.0f, &yx));       // numerator
+    if (yx) {
+      // denominator through Y and X, divided into the numerator (and the DoG/LoG epilogue) as it is stored
+      VH_TRY(dev_gauss_fused_yx(ctx, DA, dst, nx, ny, nz, Tx, Ty, B, minuend, log_scale, &yx));
+      if (!yx) return fail(VISFD_HIP_EDEVICE, "internal: single-sweep Y/X pass refused its second call");
+    } else {
+      VH_TRY(launch_march<false>(ctx, 1, A, B, nullptr, nullptr, Ty, nx, ny, nz));
+      VH_TRY(launch_march<false>(ctx, 1, DA, DB, nullptr, nullptr, Ty, nx, ny, nz));
+      VH_TRY(launch_row<NORM_NONE>(ctx, DB, DA, nullptr, nullptr, nullptr, nullptr, 0, Tx, nx, ny, nz));
+      VH_TRY(launch_row<NORM_DEN>(ctx, B, dst, DA, nullptr, nullptr, nullptr, 0, Tx, nx, ny, nz, minuend, log_scale));
+    }
   }
   VH_HIP(hipGetLastError());
   return VISFD_HIP_OK;

@@ -91,12 +91,17 @@ __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rs, unsigned by
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)byte_off, 0, 0));
 }
 
-template <int H, int TX, int TY, int NT, int XV_, int YV_, bool NORMALIZE, bool ISO, bool RAGGED>
+// ZPASS == false: the Y and X passes only (the masked filter runs its Z pass, which applies the mask, as a separate
+// kernel); DENOM: the result is a filtered mask denominator and the output is numer / result where result > 0, numer
+// elsewhere (filter3d.hpp:986-996).
+template <int H, int TX, int TY, int NT, int XV_, int YV_, bool NORMALIZE, bool ISO, bool RAGGED, bool ZPASS = true,
+          bool DENOM = false>
 __global__ void __launch_bounds__(NT)
 gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH<H> tz, TapsH<H> ty_,
                    TapsH<H> tx_, const float* __restrict__ Dx, const float* __restrict__ Dy,
                    const float* __restrict__ Dz, i64 dz_offset, int nx, int ny, int nz, int zchunk,
-                   int tiles_x, int tiles_y, const float* __restrict__ minuend, float log_scale, float dz_int) {
+                   int tiles_x, int tiles_y, const float* __restrict__ minuend, float log_scale, float dz_int,
+                   const float* __restrict__ numer) {
   typedef FusedCfg<H, TX, TY, NT, XV_, YV_> C;
   constexpr int W = C::W;
   static_assert(TY % (NT / 64) == 0, "tile rows must divide evenly among the waves");
@@ -183,7 +188,7 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
   }
 
   // first input plane of the march (the topmost one, ze-1+H); planes outside the image read as 0.0f
-  const int ktop = ze - 1 + H;
+  const int ktop = ze - 1 + (ZPASS ? H : 0);
   const int nout = ze - zs;
   float xin[C::NC];
   auto request_plane = [&](int zn, bool wanted) {   // a zero-length descriptor fetches nothing and returns 0.0f
@@ -217,30 +222,8 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
       }
     }
   };
-  // warm-up: the first 2H input planes complete no output of this chunk (each step waits for its plane;
-  // a separate code region, so that the main loop below has a single wait state at its step boundaries)
-  static_for<0, W - 1>([&](auto U) {
-    constexpr int u = decltype(U)::value;
-    z_scatter(u);
-    request_plane(ktop - u - 1, true);
-  });
-  // main loop: step W-1+n completes output plane z = ze-1-n; unrolled W times (v), ring phase u = (v+W-1) % W
-  for (int nb = 0; nb < nout; nb += W) {
-    static_for<0, W>([&](auto V) {
-      constexpr int v = decltype(V)::value;
-      constexpr int u = (v + W - 1) % W;
-      const int n = nb + v;
-      if (n < nout) {  // uniform across the workgroup
-        const int z = ze - 1 - n;
-        const int k = z - H;              // this step's input plane
-        float* sZ = sZ2[v & 1];           // static: LDS addresses fold into the DS instructions' offset fields
-        z_scatter(u);
-#pragma unroll
-        for (int c = 0; c < C::NC; c++)
-          *reinterpret_cast<float*>(reinterpret_cast<char*>(sZ) + lds_off[c]) = ring[c][u];
-        // request the next input plane (k-1); its latency is covered by the Y and X passes
-        request_plane(k - 1, n + 1 < nout);
-        __syncthreads();
+  // Y and X passes of output plane z from the Z-filtered (or, without a Z pass, the source) tile sZ
+  auto yx_passes = [&](int z, const float* sZ) {
         // Y pass: two adjacent x per lane; source rows y+2H (j=-H) down to y (j=+H)
 #pragma unroll
         for (int r = 0; r < C::YROUNDS; r++) {
@@ -349,12 +332,10 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
           typedef unsigned v4u __attribute__((ext_vector_type(4)));
           typedef float v2f __attribute__((ext_vector_type(2)));
           typedef unsigned v2u __attribute__((ext_vector_type(2)));
-          if (minuend) {
-            // DoG/LoG epilogue fused into the second Gaussian: out = (G_a - G_b) * scale with the two
-            // roundings of filter3d.hpp:1387-1390 and :1495-1498 (wave-uniform branch)
+          // one output group of another volume (its minuend or numerator), with the same row-end handling
+          auto load_group = [&](const float* vol, float m[C::XV]) {
             const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)(minuend + (i64)z * plane), 0, plane_bytes, 0x00020000);
-            float m[C::XV];
+                (void*)(vol + (i64)z * plane), 0, plane_bytes, 0x00020000);
             if (C::XV == 4) {
               const v4f mv = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rm, (int)o_off[r], 0, 0));
 #pragma unroll
@@ -370,6 +351,20 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
                 if (k < e_n[r]) m[k] = e;
               }
             }
+          };
+          if (DENOM) {
+            // masked normalisation (filter3d.hpp:986-996): this kernel filtered the mask denominator; the
+            // output is numer / denominator where the denominator is positive, numer elsewhere
+            float m[C::XV];
+            load_group(numer, m);
+#pragma unroll
+            for (int k = 0; k < C::XV; k++) a[k] = (a[k] > 0.0f) ? m[k] / a[k] : m[k];
+          }
+          if (minuend) {
+            // DoG/LoG epilogue fused into the second Gaussian: out = (G_a - G_b) * scale with the two
+            // roundings of filter3d.hpp:1387-1390 and :1495-1498 (wave-uniform branch)
+            float m[C::XV];
+            load_group(minuend, m);
 #pragma unroll
             for (int k = 0; k < C::XV; k++) {
               const float dd = m[k] - a[k];
@@ -397,6 +392,46 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
                                                     (int)(k < e_n[r] ? e_off[r] + 4u * k : OOB), 0, 0);
           }
         }
+  };
+  if constexpr (!ZPASS) {
+    // no Z pass: plane z itself goes to the LDS tile (alternating buffers, one barrier per plane)
+    for (int n = 0; n < nout; n++) {
+      const int z = ze - 1 - n;
+      float* sZ = sZ2[n & 1];
+#pragma unroll
+      for (int c = 0; c < C::NC; c++)
+        *reinterpret_cast<float*>(reinterpret_cast<char*>(sZ) + lds_off[c]) = xin[c];
+      request_plane(z - 1, n + 1 < nout);
+      __syncthreads();
+      yx_passes(z, sZ);
+    }
+    return;
+  }
+  // warm-up: the first 2H input planes complete no output of this chunk (each step waits for its plane;
+  // a separate code region, so that the main loop below has a single wait state at its step boundaries)
+  static_for<0, W - 1>([&](auto U) {
+    constexpr int u = decltype(U)::value;
+    z_scatter(u);
+    request_plane(ktop - u - 1, true);
+  });
+  // main loop: step W-1+n completes output plane z = ze-1-n; unrolled W times (v), ring phase u = (v+W-1) % W
+  for (int nb = 0; nb < nout; nb += W) {
+    static_for<0, W>([&](auto V) {
+      constexpr int v = decltype(V)::value;
+      constexpr int u = (v + W - 1) % W;
+      const int n = nb + v;
+      if (n < nout) {  // uniform across the workgroup
+        const int z = ze - 1 - n;
+        const int k = z - H;              // this step's input plane
+        float* sZ = sZ2[v & 1];           // static: LDS addresses fold into the DS instructions' offset fields
+        z_scatter(u);
+#pragma unroll
+        for (int c = 0; c < C::NC; c++)
+          *reinterpret_cast<float*>(reinterpret_cast<char*>(sZ) + lds_off[c]) = ring[c][u];
+        // request the next input plane (k-1); its latency is covered by the Y and X passes
+        request_plane(k - 1, n + 1 < nout);
+        __syncthreads();
+        yx_passes(z, sZ);
         // One workgroup barrier per plane: sZ is double-buffered (buffer v & 1), so a wave may start the
         // next Z pass (writing the other buffer) while slower waves still read this one; that buffer's
         // readers (previous step) all finished before they arrived at this step's barrier.  sY rows are
@@ -411,7 +446,8 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
 template <int H, int TX, int TY, int NT, int XV = 4, int YV = 2>
 int launch_cfg(visfd_hip_ctx* ctx, const float* src, float* dst, i64 nx, i64 ny, i64 nz,
                const Taps& tx, const Taps& ty, const Taps& tz, const float* Dx, const float* Dy,
-               const float* Dz, i64 dz_offset, bool normalize, const float* minuend, float log_scale) {
+               const float* Dz, i64 dz_offset, bool normalize, const float* minuend, float log_scale,
+               bool zpass = true, const float* numer = nullptr) {
   TapsH<H> a, b, c;
   bool iso = true;
   for (int k = 0; k < 2 * H + 1; k++) {
@@ -438,14 +474,15 @@ int launch_cfg(visfd_hip_ctx* ctx, const float* src, float* dst, i64 nx, i64 ny,
   const i64 nblk = tiles * nchunks;
   if (nblk > 0x7fffffffLL) return fail(VISFD_HIP_EINVAL, "volume too large for one launch");
   dim3 grid((unsigned)nblk), block(NT);
-#define VH_GO(NORM, ISOV, RAG)                                                                   \
-  gauss_fused_kernel<H, TX, TY, NT, XV, YV, NORM, ISOV, RAG><<<grid, block, 0, ctx->stream>>>(           \
+#define VH_GO(NORM, ISOV, RAG, ZP, DEN)                                                          \
+  gauss_fused_kernel<H, TX, TY, NT, XV, YV, NORM, ISOV, RAG, ZP, DEN><<<grid, block, 0, ctx->stream>>>(  \
       src, dst, a, b, c, Dx, Dy, Dz, dz_offset, (int)nx, (int)ny, (int)nz, (int)zchunk, tiles_x, tiles_y,  \
-      minuend, log_scale, dz_int)
+      minuend, log_scale, dz_int, numer)
   // anisotropic taps share the ragged-row instantiation (both are the uncommon cases)
   const bool ragged = (nx % XV) != 0;
-  if (normalize) { if (iso && !ragged) VH_GO(true, true, false); else VH_GO(true, false, true); }
-  else           { if (iso && !ragged) VH_GO(false, true, false); else VH_GO(false, false, true); }
+  if (!zpass) { if (numer) VH_GO(false, false, true, false, true); else VH_GO(false, false, true, false, false); }
+  else if (normalize) { if (iso && !ragged) VH_GO(true, true, false, true, false); else VH_GO(true, false, true, true, false); }
+  else                { if (iso && !ragged) VH_GO(false, true, false, true, false); else VH_GO(false, false, true, true, false); }
 #undef VH_GO
   VH_HIP(hipGetLastError());
   return VISFD_HIP_OK;
@@ -482,6 +519,20 @@ int VH_CAT(launch_gauss_fused_h, VH_FUSED_H)(visfd_hip_ctx* ctx, const float* sr
     return launch_cfg<H, 128, 32, 1024, 4, 2>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
   else
     return launch_cfg<H, 64, 32, 1024, 2, 1>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
+}
+
+// The Y and X passes alone (no Z pass, no box normaliser), optionally with the masked-normalisation epilogue
+// out = numer / result where result > 0 (numer elsewhere) and the DoG/LoG epilogue after it.
+int VH_CAT(launch_gauss_fused_yx_h, VH_FUSED_H)(visfd_hip_ctx* ctx, const float* src, float* dst, i64 nx, i64 ny,
+                                               i64 nz, const Taps& tx, const Taps& ty, const float* numer,
+                                               const float* minuend, float log_scale) {
+  constexpr int H = VH_FUSED_H;
+  if constexpr (H <= 3)
+    return launch_cfg<H, 128, 16, 512, 4, 2>(ctx, src, dst, nx, ny, nz, tx, ty, ty, nullptr, nullptr, nullptr, 0, false, minuend, log_scale, false, numer);
+  else if constexpr (H <= 5)
+    return launch_cfg<H, 128, 32, 1024, 4, 2>(ctx, src, dst, nx, ny, nz, tx, ty, ty, nullptr, nullptr, nullptr, 0, false, minuend, log_scale, false, numer);
+  else
+    return launch_cfg<H, 64, 32, 1024, 2, 1>(ctx, src, dst, nx, ny, nz, tx, ty, ty, nullptr, nullptr, nullptr, 0, false, minuend, log_scale, false, numer);
 }
 
 }  // namespace vh
