@@ -162,7 +162,7 @@ int blob_dog_dev(visfd_hip_ctx* ctx, const float* src, const float* mask, i64 nx
   int pending = -1;   // middle scale whose scan is queued but not collected yet (buffer set: pending & 1)
   auto collect = [&](int scale) -> int {
     bool overflow = false;
-    VH_TRY(blob_scan_collect(ctx, scale & 1, ev[scale & 1], ctx->aux_stream, nx, ny, scale, blob_sigma[scale], &mins,
+    VH_TRY(blob_scan_collect(ctx, scale & 1, ev[scale & 1], ctx->aux_stream, nx, ny, n, scale, blob_sigma[scale], &mins,
                              &maxs, &overflow));
     if (overflow) redo = true;
     return VISFD_HIP_OK;

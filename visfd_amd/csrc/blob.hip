@@ -244,11 +244,15 @@ struct ScanBufs {
   size_t cap_idx = 0, cap_out = 0;
 };
 
-static int scan_bufs(visfd_hip_ctx* ctx, int set, ScanBufs* B, bool pipelined) {
+static int scan_bufs(visfd_hip_ctx* ctx, int set, ScanBufs* B, bool pipelined, i64 nvox) {
+  // at least 4 M candidates / 1 M survivors, and room for 1 voxel in 32 / 128 (noise volumes at 1024^3 give ~1 in
+  // 100 / 1 in 4000 per scale): the pipelined scan then does not overflow on its first call
   size_t cap_idx = ctx->slot_bytes[WS_TVAUX] / sizeof(unsigned long long) / 2;
   if (cap_idx < (1u << 22)) cap_idx = 1u << 22;
+  if (cap_idx < (size_t)(nvox / 32)) cap_idx = (size_t)(nvox / 32);
   size_t cap_out = ctx->slot_bytes[WS_CAND] / sizeof(Cand) / 2;
   if (cap_out < (1u << 20)) cap_out = 1u << 20;
+  if (cap_out < (size_t)(nvox / 128)) cap_out = (size_t)(nvox / 128);
   unsigned long long* idx = nullptr;
   Cand* cand = nullptr;
   unsigned long long* counters = nullptr;
@@ -335,17 +339,18 @@ static int scan_enqueue(visfd_hip_ctx* ctx, const ScanBufs& B, const float* lo, 
 int blob_scan_launch(visfd_hip_ctx* ctx, int set, hipEvent_t done, const float* lo, const float* mid, const float* hi,
                      const float* mask, i64 nx, i64 ny, i64 nz, float min_thr, float max_thr) {
   ScanBufs B;
-  VH_TRY(scan_bufs(ctx, set, &B, true));
+  VH_TRY(scan_bufs(ctx, set, &B, true, nx * ny * nz));
   VH_TRY(scan_enqueue(ctx, B, lo, mid, hi, mask, nx, ny, nz, min_thr, max_thr));
   VH_HIP(hipEventRecord(done, ctx->stream));
   return VISFD_HIP_OK;
 }
 
-int blob_scan_collect(visfd_hip_ctx* ctx, int set, hipEvent_t done, hipStream_t aux, i64 nx, i64 ny, int scale_index,
+int blob_scan_collect(visfd_hip_ctx* ctx, int set, hipEvent_t done, hipStream_t aux, i64 nx, i64 ny, i64 nvox,
+                      int scale_index,
                       float sigma, std::vector<visfd_hip_blob>* minima, std::vector<visfd_hip_blob>* maxima,
                       bool* overflow) {
   ScanBufs B;
-  VH_TRY(scan_bufs(ctx, set, &B, true));   // (sizes unchanged since the launch: same pointers)
+  VH_TRY(scan_bufs(ctx, set, &B, true, nvox));   // (sizes unchanged since the launch: same pointers)
   *overflow = false;
   VH_HIP(hipStreamWaitEvent(aux, done, 0));
   unsigned long long c2[2] = {0, 0};
@@ -376,7 +381,7 @@ int dev_blob_scan(visfd_hip_ctx* ctx, const float* lo, const float* mid, const f
   hipStream_t st = ctx->stream;
   for (int attempt = 0; attempt < 4; attempt++) {
     ScanBufs B;
-    VH_TRY(scan_bufs(ctx, 0, &B, false));
+    VH_TRY(scan_bufs(ctx, 0, &B, false, nx * ny * nz));
     VH_TRY(scan_enqueue(ctx, B, lo, mid, hi, mask, nx, ny, nz, min_thr, max_thr));
     unsigned long long c2[2] = {0, 0};
     VH_HIP(hipMemcpyAsync(c2, B.counters, sizeof(c2), hipMemcpyDeviceToHost, st));

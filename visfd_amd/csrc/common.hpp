@@ -116,7 +116,8 @@ int dev_scale_clamp_sqrt(visfd_hip_ctx* ctx, float* a_inout, i64 n, float scale)
 
 int blob_scan_launch(visfd_hip_ctx* ctx, int set, hipEvent_t done, const float* lo, const float* mid, const float* hi,
                      const float* mask, i64 nx, i64 ny, i64 nz, float min_thr, float max_thr);
-int blob_scan_collect(visfd_hip_ctx* ctx, int set, hipEvent_t done, hipStream_t aux, i64 nx, i64 ny, int scale_index,
+int blob_scan_collect(visfd_hip_ctx* ctx, int set, hipEvent_t done, hipStream_t aux, i64 nx, i64 ny, i64 nvox,
+                      int scale_index,
                       float sigma, std::vector<visfd_hip_blob>* minima, std::vector<visfd_hip_blob>* maxima,
                       bool* overflow);
 int dev_blob_scan(visfd_hip_ctx* ctx, const float* lo, const float* mid, const float* hi,
