@@ -488,6 +488,43 @@ def test_gauss_large_volume_crops_equal_oracle(ctx, oracle):
         assert_bits_equal(a, b, "crop at %s" % ((z0, y0, x0),))
 
 
+def test_blob_large_volume_crops_equal_oracle(ctx, oracle):
+    """Scale-space blob detection on a 1024 x 1024 x 96 volume (BASELINE plane size; 12 scales, sigma 2..4, window
+    half-widths 5..10, i.e. single-sweep and three-pass filters, pipelined scans): the blobs inside a crop -- far
+    enough from the crop's faces that neither a filter window nor the non-max neighbourhood leaves it -- equal, with
+    bit-identical scores, the blobs the CPU restatement finds on the crop alone."""
+    import torch
+    from visfd_amd import pipeline
+    dev = torch.device("cuda:0")
+    nz, ny, nx = 96, 1024, 1024
+    g = torch.Generator(device=dev).manual_seed(4242)
+    src = torch.randn((nz, ny, nx), device=dev, generator=g) * 100 + 1000
+    sig = pipeline.cli_blob_sigmas(2.0, 4.0, 1.066)
+    r = ratio(oracle)
+    torch.cuda.synchronize()
+    mins, maxs = ctx.blob_dog_dev(src, sig, None, None, 0.02, r, np.inf, -np.inf, False, cap=1 << 22)
+    assert len(mins) > 1000 and len(maxs) > 1000
+    halo = int(np.floor(r * float(sig[-1]) * 1.01)) + 2      # widest window + the 3x3x3 neighbourhood
+    E = 40
+    for (z0, y0, x0) in [(halo, 500, 1000 - E), (nz - halo - 30, 60, 120), (30, 1024 - halo - E, 3 * 64 - 5)]:
+        ez = min(E, nz - halo - z0)
+        lo = [z0 - halo, y0 - halo, x0 - halo]
+        hi = [z0 + ez + halo, y0 + E + halo, x0 + E + halo]
+        assert min(lo) >= 0 and hi[0] <= nz and hi[1] <= ny and hi[2] <= nx
+        sub = src[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]].cpu().numpy().copy()
+        wmin, wmax = oracle.blob_dog(sub, sig, None, None, 0.02, r, np.inf, -np.inf, False)
+        for got, want, asc in ((mins, wmin, True), (maxs, wmax, False)):
+            inside = ((got[:, 0] >= x0) & (got[:, 0] < x0 + E) & (got[:, 1] >= y0) & (got[:, 1] < y0 + E) &
+                      (got[:, 2] >= z0) & (got[:, 2] < z0 + ez))
+            a = got[inside].copy()
+            a[:, 0] -= lo[2]; a[:, 1] -= lo[1]; a[:, 2] -= lo[0]
+            keep = ((want[:, 0] >= halo) & (want[:, 0] < halo + E) & (want[:, 1] >= halo) & (want[:, 1] < halo + E) &
+                    (want[:, 2] >= halo) & (want[:, 2] < halo + ez))
+            b = want[keep]
+            assert len(b) > 0
+            assert_bits_equal(volgen.sort_blobs(a, asc), volgen.sort_blobs(b, asc), "blobs in crop at %s" % ((z0, y0, x0),))
+
+
 def test_gauss_2048_cubed_crops_equal_oracle(ctx, oracle):
     """2048^3 float32 (the north-star target size; 2^33 voxels, beyond 32-bit indexing and beyond what the reference
     can allocate): single-sweep kernel == three single-axis kernels on the whole 32 GiB volume, and crops in the
