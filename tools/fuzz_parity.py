@@ -35,8 +35,12 @@ def main():
     counts = {"gauss": 0, "log": 0, "blob": 0, "tv": 0, "bin": 0}
     bad = []
     it = 0
+    t_report = t0
     while time.time() - t0 < a.seconds:
         it += 1
+        if time.time() - t_report > 60:    # a progress line per minute (a silent GPU job is taken to be hung)
+            t_report = time.time()
+            print("... %d cases, %d mismatches after %.0f s" % (sum(counts.values()), len(bad), t_report - t0), flush=True)
         kind = ["gauss", "log", "blob", "tv", "bin"][it % 5]
         shape = tuple(int(v) for v in rng.integers(3, 70, 3))
         if rng.random() < 0.4:
