@@ -1,4 +1,5 @@
-// gauss_fused.hip -- single-sweep separable 3-D Gaussian for gfx950 (unmasked case).
+// gauss_fused.hip -- single-sweep separable 3-D Gaussian for gfx950 (unmasked case; its Y+X half alone serves the
+// masked filter after that filter's masking Z pass).
 //
 // One kernel reads the source once and writes the result once (algorithmic 8 B/voxel), while
 // keeping the reference's value-level order (lib/visfd/filter3d.hpp:741-981): convolve along Z,
@@ -22,7 +23,9 @@
 //   * the Z-filtered haloed plane goes to LDS; Y pass: two adjacent x per lane (ds_read_b64 down a
 //     column), result rows to LDS; X pass: four adjacent outputs per lane from ds_read_b128
 //     windows, normalise, 16-byte buffer store (x-contiguous across lanes, dropped by the range
-//     check outside the image).
+//     check outside the image; when nx is not a multiple of the group, the group cut by the end of a row is
+//     written element by element).  The normaliser division uses a per-lane reciprocal with exact residual
+//     corrections where that provably yields the IEEE quotient (see the X pass).
 // Zero extension: a 0.0f sample adds an exact +0.0 to the accumulator, which equals skipping the
 // term as the reference does (filter1d.hpp:98-99) for finite data.
 //
