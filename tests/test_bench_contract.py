@@ -1,0 +1,37 @@
+"""bench.py's output contract on a small volume (GPU): one JSON line with the fields the driver reads, the roofline
+objects and the CPU baseline."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--size", "128", "--steps", "1", "--warmup", "1",
+                        "--no-2048", "--cpu-sample", "48"], capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in out, key
+    assert out["unit"] == "Mvoxels/s" and out["n_gpus"] == 1 and out["steps"] == 1 and out["higher_is_better"] is True
+    assert out["scaling"] == "weak" and out["vs_baseline"] is None and out["dtype"] == "f32" and out["data"] == "synthetic"
+    assert "workload" in out["config"] and "model" not in out["config"]
+    assert out["value"] > 0 and out["ms_per_step"] > 0
+    assert abs(out["value"] - 128 ** 3 / (out["ms_per_step"] * 1e-3) / 1e6) <= 1e-3 * out["value"]
+    rf = out["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in rf, key
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = out["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cb, key
+    assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0
+    assert out["roofline_tv"]["bound"] == "valu" and out["roofline_pass"]["bound"] == "hbm"
