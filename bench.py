@@ -272,10 +272,17 @@ def main():
             del os.environ["VISFD_HIP_GAUSS_3PASS"]
         p_ms = e0.elapsed_time(e1) / reps / 3.0
         p_ach = 8.0 * nv / (p_ms * 1e-3) / 1e9
+        p_traffic = None   # PMC bytes per launch, average of the three passes (profiles/r01_gauss_pass_traffic.json)
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_gauss_pass_traffic.json")))
+            if list(tr["shape"]) == [shape[0], shape[1], shape[2]]:
+                p_traffic = tr["traffic_bytes"]
+        except Exception:
+            pass
         roofline_pass = {"bound": "hbm", "kernel": "conv_march_kernel<5> (Z, Y) / conv_row_kernel<5> (X): one 1-D pass of "
                                                    "the separable Gaussian, sigma=2",
                          "achieved": round(p_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(p_ach / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes": 8 * nv,
+                         "frac": round(p_ach / HBM_PEAK_GBS, 4), "traffic": p_traffic, "algorithmic_bytes": 8 * nv,
                          "ms_per_launch": round(p_ms, 4), "voxels_per_launch": nv,
                          "note": "average of the three pass launches; a device copy on this box runs at ~5.0 TB/s"}
 
