@@ -378,10 +378,13 @@ static int dev_gauss_fused(visfd_hip_ctx* ctx, const float* src, float* dst, i64
   if (ty.h != H || tz.h != H || H < 1 || H > 8) return VISFD_HIP_OK;
   if (nx * ny >= (1LL << 29) || nz >= (1LL << 31)) return VISFD_HIP_OK;
   if (src == dst) return VISFD_HIP_OK;  // in place: 3-pass path through scratch volumes
-  // the single-sweep kernel's Z pass shares the product of a sample with the taps +j and -j: the Z taps must be
-  // symmetric bit for bit (every Gaussian is; arbitrary filters take the 3-pass path)
+  // the single-sweep kernel's Z pass shares the product of a sample with the taps +j and -j, and all three passes
+  // keep only the taps 0..H (in VGPRs): the taps must be symmetric bit for bit on every axis (every Gaussian is;
+  // arbitrary filters take the 3-pass path)
   for (int j = 1; j <= H; j++)
-    if (std::memcmp(&tz.t[H + j], &tz.t[H - j], sizeof(float)) != 0) return VISFD_HIP_OK;
+    if (std::memcmp(&tz.t[H + j], &tz.t[H - j], sizeof(float)) != 0 || std::memcmp(&ty.t[H + j], &ty.t[H - j], sizeof(float)) != 0 ||
+        std::memcmp(&tx.t[H + j], &tx.t[H - j], sizeof(float)) != 0)
+      return VISFD_HIP_OK;
   const char* force = getenv("VISFD_HIP_GAUSS_3PASS");
   if (force && force[0] == '1') return VISFD_HIP_OK;
   int cfg = 0;
@@ -406,6 +409,9 @@ static int dev_gauss_fused_yx(visfd_hip_ctx* ctx, const float* src, float* dst, 
   if (ty.h != H || H < 1 || H > 8) return VISFD_HIP_OK;
   if (nx * ny >= (1LL << 29) || nz >= (1LL << 31)) return VISFD_HIP_OK;
   if (src == dst || numer == dst) return VISFD_HIP_OK;
+  for (int j = 1; j <= H; j++)   // the kernel keeps the taps 0..H only
+    if (std::memcmp(&ty.t[H + j], &ty.t[H - j], sizeof(float)) != 0 || std::memcmp(&tx.t[H + j], &tx.t[H - j], sizeof(float)) != 0)
+      return VISFD_HIP_OK;
   const char* force = getenv("VISFD_HIP_GAUSS_3PASS");
   if (force && force[0] == '1') return VISFD_HIP_OK;
   *handled = true;

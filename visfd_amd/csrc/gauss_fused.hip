@@ -45,14 +45,24 @@ namespace {
 
 constexpr unsigned OOB = 0x7ffffff0u;  // byte offset beyond any descriptor: loads give 0, stores vanish
 
+#ifdef VH_FUSED_STAMPS   // development build only (tools/build_variant.py): where a wave's cycles go, per phase of a plane step
+__device__ unsigned long long g_fused_stamps[8];
+#define VH_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_last; st_last = t_; } while (0)
+#else
+#define VH_STAMP(i) do {} while (0)
+#endif
+
 template <int H, int TX, int TY, int NT, int XV_, int YV_>
 struct FusedCfg {
   static constexpr int W = 2 * H + 1;
   static constexpr int HX = TX + 2 * H;           // haloed tile width (even: TX even)
   static constexpr int HY = TY + 2 * H;
-  static constexpr int NCOL = HX * HY;
-  static constexpr int NC = (NCOL + NT - 1) / NT;  // ring columns per thread
   static constexpr int SX = ((HX + 2 + 3) / 4) * 4; // LDS row stride in floats (16-byte rows)
+  // Z-pass columns are dealt to threads over the PADDED tile (SX x HY): column id = tid + c * NT sits at LDS float
+  // offset id, so the LDS address of a thread's c-th column is one base register plus a compile-time constant
+  // (pad columns load 0.0f and land in the row padding)
+  static constexpr int NCOL = SX * HY;
+  static constexpr int NC = (NCOL + NT - 1) / NT;  // ring columns per thread
   // Y and X passes are WAVE-LOCAL: wave w owns output rows [w*RPW, (w+1)*RPW) of the tile, computes their
   // Y-filtered rows into sY and then reads only those rows back for the X pass (no workgroup barrier
   // between the two passes)
@@ -72,7 +82,7 @@ struct FusedCfg {
   static_assert(XV == 2 || XV == 4, "X pass vector width");
   static_assert(YV == 1 || YV == 2, "Y pass vector width");
   static_assert(HX % YV == 0 && TX % XV == 0, "tile width must be a multiple of the vector widths");
-  static constexpr int SZ_FLOATS = HY * SX + 64;   // + a dump area for padding ring slots
+  static constexpr int SZ_FLOATS = NC * NT;        // >= HY * SX: slots past the tile are scratch
   static constexpr int SY_FLOATS = TY * SX;
 };
 
@@ -89,6 +99,23 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for<B + 1, E>(f);
   }
 }
+
+// Plain ds_read_b64 / ds_read_b32: left to itself the compiler pairs two of these into ds_read2_b64 / ds_read2_b32, which
+// the LDS serves at HALF the bytes per clock of the single form on gfx950 (MI355X_MICROARCH.md, LDS table: ds_read2_b64
+// 8 cycles for 1 KB, ds_read_b64 2 cycles for 512 B) -- and the Y pass is bound by exactly these reads
+// (profiles/r02_gauss_phase_stamps.txt).  Volatile accesses are not merged.
+#define VH_LDS __attribute__((address_space(3)))
+__device__ __forceinline__ float2 lds_read_f2(const float* p) {
+#if defined(VH_FUSED_EXP) && VH_FUSED_EXP == 4   // experiment 4: no LDS reads in the Y pass
+  float x = 1.0f, y = 2.0f;
+  asm volatile("" : "+v"(x), "+v"(y) : "v"(p));
+  return make_float2(x, y);
+#endif
+  typedef float v2f_ __attribute__((ext_vector_type(2)));
+  const v2f_ v = *(const volatile VH_LDS v2f_*)(const VH_LDS void*)p;
+  return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ float lds_read_f1(const float* p) { return *(const volatile VH_LDS float*)(const VH_LDS void*)p; }
 
 __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)byte_off, 0, 0));
@@ -110,8 +137,35 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
   static_assert(TY % (NT / 64) == 0, "tile rows must divide evenly among the waves");
   __shared__ __attribute__((aligned(16))) float sZ2[2][C::SZ_FLOATS];   // double-buffered: see the march loop
   __shared__ __attribute__((aligned(16))) float sY[C::SY_FLOATS];
-  const TapsH<H>& ty = ISO ? tz : ty_;
-  const TapsH<H>& tx = ISO ? tz : tx_;
+  // Taps live in VGPRs: on gfx950 a VALU instruction with an SGPR operand issues at half the rate of the same
+  // instruction on VGPRs (profiles/r02_microbench_valu.txt: v_mul_f32 v,s,v 37 T lane-ops/s against 70 T for v,v,v),
+  // and every multiply of the three passes has a tap as operand.  Symmetric taps (checked on the host): tap |j| is
+  // vt*[|j|].  The empty asm makes the copies opaque, so that the compiler cannot fold them back into the scalars.
+  // Two instantiations have no registers to spare and keep scalar taps: unequal taps per axis / ragged rows with
+  // the normaliser (all taps), and the same without it (Y and X taps).
+  constexpr bool VZ = ZPASS && !(NORMALIZE && !ISO);   // Z taps in VGPRs
+  constexpr bool VYX_OWN = !ZPASS;                      // the Y/X-only kernel: its own Y and X tap registers
+  float vtz[H + 1], vty[H + 1], vtx[H + 1];
+#pragma unroll
+  for (int m = 0; m <= H; m++) {
+    vtz[m] = tz.t[H + m];
+    vty[m] = ty_.t[H + m];
+    vtx[m] = tx_.t[H + m];
+    if (VZ) asm volatile("" : "+v"(vtz[m]));
+    if (VYX_OWN) {
+      asm volatile("" : "+v"(vty[m]));
+      asm volatile("" : "+v"(vtx[m]));
+    }
+  }
+  auto tap_z = [&](int m) -> float { return VZ ? vtz[m] : tz.t[H + m]; };
+  auto tap_y = [&](int jj) -> float {
+    const int m = jj < H ? H - jj : jj - H;
+    return VYX_OWN ? vty[m] : ((ISO && VZ) ? vtz[m] : (ISO ? tz.t[jj] : ty_.t[jj]));
+  };
+  auto tap_x = [&](int jj) -> float {
+    const int m = jj < H ? H - jj : jj - H;
+    return VYX_OWN ? vtx[m] : ((ISO && VZ) ? vtz[m] : (ISO ? tz.t[jj] : tx_.t[jj]));
+  };
 
   // XCD-aware block order: consecutive logical tiles (neighbours in x, then y) share an XCD/L2.
   const unsigned nblk = gridDim.x;
@@ -136,18 +190,16 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
   for (int c = 0; c < C::NC; c++)
 #pragma unroll
     for (int m = 0; m < W; m++) ring[c][m] = 0.0f;
-  unsigned col_off[C::NC];  // byte offset of the column inside a plane (OOB outside the image)
-  int lds_off[C::NC];       // BYTE offset of its Z-filtered value in sZ (dump area for padding slots)
+  unsigned col_off[C::NC];  // byte offset of the column inside a plane (OOB outside the image and in the padding)
 #pragma unroll
   for (int c = 0; c < C::NC; c++) {
     const int id = tid + c * NT;
-    const int cy = id / C::HX, cx = id - cy * C::HX;
+    const int cy = id / C::SX, cx = id - cy * C::SX;
     const int gx = x0 - H + cx, gy = y0 - H + cy;
-    const bool slot = id < C::NCOL;
-    const bool inside = slot && gx >= 0 && gx < nx && gy >= 0 && gy < ny;
+    const bool inside = cx < C::HX && cy < C::HY && gx >= 0 && gx < nx && gy >= 0 && gy < ny;
     col_off[c] = inside ? (unsigned)(gy * nx + gx) * 4u : OOB;
-    lds_off[c] = 4 * (slot ? (cy * C::SX + cx) : (C::HY * C::SX + (tid & 63)));
   }
+  const int lds_base = 4 * tid;   // BYTE offset of column c in sZ: lds_base + 4 * NT * c
   const int lane = tid & 63, wave = tid >> 6;
   int y_off[C::YROUNDS];    // LDS BYTE offset of (row y, column pair xp); -1: idle lane
 #pragma unroll
@@ -161,8 +213,10 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
   unsigned o_off[C::XROUNDS];  // byte offset of the output quad inside a plane (OOB outside)
   unsigned e_off[RAGGED ? C::XROUNDS : 1];   // the same for a group cut by the end of its row (RAGGED only)
   int e_n[RAGGED ? C::XROUNDS : 1];          // and the number of its elements inside the row
-  float dxy[C::XROUNDS][C::XV];
-  float rcp_int[C::XROUNDS][C::XV];   // 1 / ((Dx*Dy)*Dz) for the planes whose Dz is the interior value dz_int
+  // per-lane normaliser constants, parked in LDS (the kernel is short of registers, not of LDS): group g = 2 * r (the
+  // products Dx*Dy) and 2 * r + 1 (1 / ((Dx*Dy)*Dz) for the planes whose Dz is the interior value dz_int) of round r,
+  // XV consecutive floats per thread
+  __shared__ __attribute__((aligned(16))) float sK[NORMALIZE ? 2 * C::XROUNDS * C::XV * NT : 4];
 #pragma unroll
   for (int r = 0; r < C::XROUNDS; r++) {
     const int task = lane + r * 64;
@@ -184,8 +238,9 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
       const float dy = ok ? Dy[gy] : 1.0f;
 #pragma unroll
       for (int k = 0; k < C::XV; k++) {
-        dxy[r][k] = ((ok && gx + k < nx) ? Dx[gx + k] : 1.0f) * dy;  // (Dx*Dy) first, then *Dz (filter3d.hpp:1016-1018)
-        rcp_int[r][k] = 1.0f / (dxy[r][k] * dz_int);  // IEEE division: the correctly rounded reciprocal
+        const float dxy = ((ok && gx + k < nx) ? Dx[gx + k] : 1.0f) * dy;  // (Dx*Dy) first, then *Dz (filter3d.hpp:1016-1018)
+        sK[((2 * r) * NT + tid) * C::XV + k] = dxy;
+        sK[((2 * r + 1) * NT + tid) * C::XV + k] = 1.0f / (dxy * dz_int);  // IEEE division: the correctly rounded reciprocal
       }
     }
   }
@@ -195,6 +250,9 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
   const int nout = ze - zs;
   float xin[C::NC];
   auto request_plane = [&](int zn, bool wanted) {   // a zero-length descriptor fetches nothing and returns 0.0f
+#if defined(VH_FUSED_EXP) && VH_FUSED_EXP == 1   // experiment: every request re-reads one (cache-resident) plane
+    zn = ktop < nz ? ktop : nz - 1;
+#endif
     const bool zin = wanted && zn >= 0 && zn < nz;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(src + (zin ? (i64)zn * plane : 0)), 0, zin ? plane_bytes : 0, 0x00020000);
@@ -202,6 +260,10 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
     for (int c = 0; c < C::NC; c++) xin[c] = buf_load(rs, col_off[c]);
   };
   request_plane(ktop, true);
+#ifdef VH_FUSED_STAMPS
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
 
   // ---- march DOWN along z, unrolled W times so that ring indices are compile-time -------------
   // Z pass in scatter form.  g[i] = sum_j t[j]*f[i-j] with j ascending means: for a fixed output plane i
@@ -216,7 +278,7 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
     for (int c = 0; c < C::NC; c++) {
       float pr[H + 1];
 #pragma unroll
-      for (int m = 0; m <= H; m++) pr[m] = tz.t[H + m] * xin[c];
+      for (int m = 0; m <= H; m++) pr[m] = tap_z(m) * xin[c];
 #pragma unroll
       for (int j = -H; j <= H; j++) {
         const int s = (u + H - j) % W;
@@ -234,27 +296,33 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
             const float* base = reinterpret_cast<const float*>(reinterpret_cast<const char*>(sZ) + y_off[r]);
             if (C::YV == 2 && !(C::YLAST_SINGLE && r == C::YROUNDS - 1)) {
               float a0 = 0.0f, a1 = 0.0f;
+              float2 v[W];   // the whole window is requested before the first use: one LDS round trip per round
+#pragma unroll
+              for (int jj = 0; jj < W; jj++) v[jj] = lds_read_f2(base + (2 * H - jj) * C::SX);
 #pragma unroll
               for (int jj = 0; jj < W; jj++) {
-                const float2 v = *reinterpret_cast<const float2*>(base + (2 * H - jj) * C::SX);
-                const float t = ty.t[jj];
-                const float p0 = t * v.x;
-                const float p1 = t * v.y;
+                const float t = tap_y(jj);
+                const float p0 = t * v[jj].x;
+                const float p1 = t * v[jj].y;
                 a0 = a0 + p0;
                 a1 = a1 + p1;
               }
               *reinterpret_cast<float2*>(reinterpret_cast<char*>(sY) + y_off[r]) = make_float2(a0, a1);
             } else {
               float a0 = 0.0f;
+              float v[W];
+#pragma unroll
+              for (int jj = 0; jj < W; jj++) v[jj] = lds_read_f1(base + (2 * H - jj) * C::SX);
 #pragma unroll
               for (int jj = 0; jj < W; jj++) {
-                const float p0 = ty.t[jj] * base[(2 * H - jj) * C::SX];
+                const float p0 = tap_y(jj) * v[jj];
                 a0 = a0 + p0;
               }
               *reinterpret_cast<float*>(reinterpret_cast<char*>(sY) + y_off[r]) = a0;
             }
           }
         }
+        VH_STAMP(4);
         __builtin_amdgcn_wave_barrier();   // same wave wrote these sY rows: LDS ops of a wave execute in order
         // X pass: four adjacent outputs per lane; haloed source index x+2H (j=-H) down to x (j=+H)
         const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
@@ -268,6 +336,14 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
 #pragma unroll
         for (int r = 0; r < C::XROUNDS; r++) {
           float v[C::XV * C::XWINV];
+          float dxy[C::XV], rcp_int[C::XV];   // requested together with the window (only this thread touches these LDS words)
+          if (NORMALIZE) {
+#pragma unroll
+            for (int k = 0; k < C::XV; k++) {
+              dxy[k] = sK[((2 * r) * NT + tid) * C::XV + k];
+              rcp_int[k] = sK[((2 * r + 1) * NT + tid) * C::XV + k];
+            }
+          }
           if (C::XV == 4) {
             const float4* base = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sY) + x_off[r]);
 #pragma unroll
@@ -288,7 +364,7 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
           for (int k = 0; k < C::XV; k++) a[k] = 0.0f;
 #pragma unroll
           for (int jj = 0; jj < W; jj++) {
-            const float t = tx.t[jj];
+            const float t = tap_x(jj);
 #pragma unroll
             for (int k = 0; k < C::XV; k++) {
               const float pr = t * v[2 * H - jj + k];
@@ -304,7 +380,7 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
             // else (first/last H planes, zeros, extreme magnitudes) takes the full-range division.
             float d[C::XV];
 #pragma unroll
-            for (int k = 0; k < C::XV; k++) d[k] = dxy[r][k] * dz;
+            for (int k = 0; k < C::XV; k++) d[k] = dxy[k] * dz;
             bool fast = dz_is_int;
             if (fast) {
               float hi = __builtin_fmaxf(__builtin_fabsf(a[0]), __builtin_fabsf(a[1]));
@@ -319,7 +395,7 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
             if (fast) {
 #pragma unroll
               for (int k = 0; k < C::XV; k++) {
-                const float y = rcp_int[r][k];
+                const float y = rcp_int[k];
                 const float q0 = a[k] * y;
                 const float r0 = __builtin_fmaf(-d[k], q0, a[k]);
                 const float q1 = __builtin_fmaf(r0, y, q0);
@@ -377,11 +453,17 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
           // vmcnt counts loads and stores in one queue: make the wait for the next input plane (requested
           // after the Z pass, long since arrived) happen BEFORE the first output store is issued, so that the
           // next Z pass does not have to drain that store to see its inputs
+          VH_STAMP(5);
           if (r == 0) {
 #pragma unroll
             for (int c = 0; c < C::NC; c++) asm volatile("" : "+v"(xin[c]));
           }
+#if defined(VH_FUSED_EXP) && VH_FUSED_EXP == 2   // experiment: no output stores (values kept live)
+          asm volatile("" :: "v"(a[0]), "v"(a[1]));
+          if (false) {
+#else
           if (C::XV == 4) {
+#endif
             v4f out = {a[0], a[1], a[2], a[3]};
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, out), ro, (int)o_off[r], 0, 0);
           } else {
@@ -403,7 +485,7 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
       float* sZ = sZ2[n & 1];
 #pragma unroll
       for (int c = 0; c < C::NC; c++)
-        *reinterpret_cast<float*>(reinterpret_cast<char*>(sZ) + lds_off[c]) = xin[c];
+        *reinterpret_cast<float*>(reinterpret_cast<char*>(sZ) + lds_base + 4 * NT * c) = xin[c];
       request_plane(z - 1, n + 1 < nout);
       __syncthreads();
       yx_passes(z, sZ);
@@ -417,33 +499,60 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
     z_scatter(u);
     request_plane(ktop - u - 1, true);
   });
-  // main loop: step W-1+n completes output plane z = ze-1-n; unrolled W times (v), ring phase u = (v+W-1) % W
+  // Z pass of the step that completes output plane number n (z = ze-1-n; ring phase u = (n + W-1) % W, a constant at
+  // every call site), its tile into LDS buffer n & 1, and the request for the next input plane, whose latency the
+  // rest of the interval covers
+  auto z_step = [&](auto U, int n) {
+    constexpr int u = decltype(U)::value;
+    float* sZ = sZ2[n & 1];
+    z_scatter(u);
+#pragma unroll
+    for (int c = 0; c < C::NC; c++)
+      *reinterpret_cast<float*>(reinterpret_cast<char*>(sZ) + lds_base + 4 * NT * c) = ring[c][u];
+    request_plane(ze - 1 - n - H - 1, n + 1 < nout);
+  };
+  z_step(std::integral_constant<int, W - 1>{}, 0);
+  // Main loop, one workgroup barrier per plane.  Between two barriers every wave runs the Y and X passes of plane n
+  // (reading buffer n & 1, complete since the barrier) AND the Z pass of plane n+1 (writing the other buffer, whose
+  // readers finished before the barrier); the two pieces are independent.  VH_FUSED_STAGGER=1 lets the two halves of
+  // the workgroup take them in OPPOSITE order (each SIMD hosts waves of both halves), so that LDS-bound Y passes run
+  // beside VALU-bound Z passes: measured neutral at 1024^3 (2.48 against 2.46 ms, profiles/r02_gauss_experiments.txt)
+  // at 1.7x the code, hence off.  Unrolled W times (v) so that the ring indices are constants: plane n+1 has phase v.
+#ifndef VH_FUSED_STAGGER
+#define VH_FUSED_STAGGER 0
+#endif
+  const bool z_first = VH_FUSED_STAGGER && __builtin_amdgcn_readfirstlane(wave) >= C::NW / 2;
   for (int nb = 0; nb < nout; nb += W) {
     static_for<0, W>([&](auto V) {
       constexpr int v = decltype(V)::value;
-      constexpr int u = (v + W - 1) % W;
       const int n = nb + v;
       if (n < nout) {  // uniform across the workgroup
-        const int z = ze - 1 - n;
-        const int k = z - H;              // this step's input plane
-        float* sZ = sZ2[v & 1];           // static: LDS addresses fold into the DS instructions' offset fields
-        z_scatter(u);
-#pragma unroll
-        for (int c = 0; c < C::NC; c++)
-          *reinterpret_cast<float*>(reinterpret_cast<char*>(sZ) + lds_off[c]) = ring[c][u];
-        // request the next input plane (k-1); its latency is covered by the Y and X passes
-        request_plane(k - 1, n + 1 < nout);
+        VH_STAMP(0);
+#if !(defined(VH_FUSED_EXP) && VH_FUSED_EXP == 3)   // experiment 3: no workgroup barrier (wrong results)
         __syncthreads();
-        yx_passes(z, sZ);
-        // One workgroup barrier per plane: sZ is double-buffered (buffer v & 1), so a wave may start the
-        // next Z pass (writing the other buffer) while slower waves still read this one; that buffer's
-        // readers (previous step) all finished before they arrived at this step's barrier.  sY rows are
-        // private to a wave.  W is odd: the last step of a block and the first of the next use the same
-        // buffer, hence one more barrier there.
-        if (v == W - 1) __syncthreads();
+#endif
+        VH_STAMP(3);
+        // (the Z pass, which updates the register ring, stands once in the code; the Y/X passes stand before and
+        // after it and each wave runs one of the two copies)
+        if (!z_first) {   // uniform per wave
+          yx_passes(ze - 1 - n, sZ2[n & 1]);
+          VH_STAMP(6);
+        }
+        if (n + 1 < nout) z_step(V, n + 1);
+        VH_STAMP(1);
+        if (z_first) {
+          yx_passes(ze - 1 - n, sZ2[n & 1]);
+          VH_STAMP(6);
+        }
       }
     });
   }
+#ifdef VH_FUSED_STAMPS
+  if (lane == 0 && blockIdx.x < 256) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) atomicAdd(&g_fused_stamps[i], st_acc[i]);
+  }
+#endif
 }
 
 template <int H, int TX, int TY, int NT, int XV = 4, int YV = 2>
@@ -488,6 +597,17 @@ int launch_cfg(visfd_hip_ctx* ctx, const float* src, float* dst, i64 nx, i64 ny,
   else                { if (iso && !ragged) VH_GO(false, true, false, true, false); else VH_GO(false, false, true, true, false); }
 #undef VH_GO
   VH_HIP(hipGetLastError());
+#ifdef VH_FUSED_STAMPS
+  {
+    unsigned long long st8[8], z8[8] = {};
+    VH_HIP(hipStreamSynchronize(ctx->stream));
+    VH_HIP(hipMemcpyFromSymbol(st8, HIP_SYMBOL(g_fused_stamps), sizeof(st8)));
+    const double per = 1.0 / ((double)(nblk < 256 ? nblk : 256) * (NT / 64) * (double)(zchunk));
+    fprintf(stderr, "[fused stamps H=%d] cycles per wave and plane: other %.0f | z-pass %.0f | lds write+request %.0f | barrier %.0f | y-pass %.0f | "
+            "x-pass to store %.0f | stores+tail %.0f\n", H, st8[0] * per, st8[1] * per, st8[2] * per, st8[3] * per, st8[4] * per, st8[5] * per, st8[6] * per);
+    VH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_fused_stamps), z8, sizeof(z8)));
+  }
+#endif
   return VISFD_HIP_OK;
 }
 
