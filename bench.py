@@ -259,8 +259,7 @@ def main():
 
         # one 1-D pass of the separable Gaussian (the 3-pass path used for masks, ragged widths and wide windows):
         # three launches (Z, Y, X with the normalisation), 8 B/voxel each; average launch time = total / 3
-        os.environ["VISFD_HIP_GAUSS_3PASS"] = "1"
-        try:
+        with ctx.options(gauss_3pass=1):
             pipeline.gauss(ctx, src, dst, GAUSS_SIGMA)
             torch.cuda.synchronize()
             e0.record()
@@ -268,8 +267,6 @@ def main():
                 pipeline.gauss(ctx, src, dst, GAUSS_SIGMA)
             e1.record()
             torch.cuda.synchronize()
-        finally:
-            del os.environ["VISFD_HIP_GAUSS_3PASS"]
         p_ms = e0.elapsed_time(e1) / reps / 3.0
         p_ach = 8.0 * nv / (p_ms * 1e-3) / 1e9
         p_traffic = None   # PMC bytes per launch, average of the three passes (profiles/r01_gauss_pass_traffic.json)
@@ -346,11 +343,8 @@ def main():
                 torch.cuda.synchronize()
                 return e0.elapsed_time(e1) / reps
             f_ms = timed(5)
-            os.environ["VISFD_HIP_GAUSS_3PASS"] = "1"
-            try:
+            with ctx.options(gauss_3pass=1):
                 p_ms = timed(3) / 3.0
-            finally:
-                del os.environ["VISFD_HIP_GAUSS_3PASS"]
             nv2 = n2 ** 3
             roofline_2048 = {
                 "bound": "hbm", "workload": "separable 3-D Gaussian, sigma=2 (h=5), 2048^3 float32 (32 GiB)",

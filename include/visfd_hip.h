@@ -57,7 +57,18 @@ int visfd_hip_synchronize(visfd_hip_ctx* ctx);
 /* release the cached workspace (it otherwise persists between calls) */
 int visfd_hip_trim(visfd_hip_ctx* ctx);
 const char* visfd_hip_last_error(void);
-int visfd_hip_abi_version(void);   /* 4: entry points only get added between versions */
+int visfd_hip_abi_version(void);   /* 5: entry points only get added between versions */
+/* Tuning and test switches of a context (integers; unknown names are VISFD_HIP_EINVAL).  A new context starts from the
+ * environment (VISFD_HIP_<NAME>, read once in visfd_hip_create); nothing reads the environment afterwards.
+ *   gauss_3pass      1: the separable filter always takes its three single-axis passes
+ *   gauss_wg_per_cu  workgroups per CU the single-sweep filter cuts the volume into (default 2)
+ *   tv_dense         1: tensor voting by the baseline kernel
+ *   tv_zrun          receiver planes per unit of work (default 32);  tv_group: sender planes per LDS group
+ *   tv_no_replay     1: no scratch rings (every sender plane is compacted from the volume)
+ *   tv_max_wg        cap on the number of persistent workgroups (tests: forces many units of work per workgroup)
+ *   blob_test_cap    tests: capacity the pipelined blob scan pretends to have (exercises its overflow path)
+ *   gauss_cfg, debug development aids */
+int visfd_hip_set_option(visfd_hip_ctx* ctx, const char* name, int64_t value);
 /* bytes of device workspace currently held by the context */
 int64_t visfd_hip_workspace_bytes(visfd_hip_ctx* ctx);
 

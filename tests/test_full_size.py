@@ -1,0 +1,177 @@
+"""BASELINE configs 3 and 4 at FULL size (1024^3, the bench's own synthetic volume and parameters), checked against the
+CPU restatement through locality: every stage of the path has a finite reach, so the result inside a crop equals the
+oracle's result on the crop plus a halo.  The crops sit at corners and faces of the volume, in its interior, across
+the seams of the voting kernel's units of work (tiles of 16 x 16 voxels, runs of 32 receiver planes) and on the
+synthetic membranes, where sender lists are long.  At this size every persistent workgroup of the voting kernel claims
+more than a hundred units, which no small test reaches.
+
+Tensor voting is compared bit for bit: the oracle votes on the DEVICE's thresholded saliency and directions of the
+crop + halo (handlers.cpp:1751-1835 feeds TVDenseStick the same way).  Eigen-derived fields (saliency, post-vote
+score) are compared within 1e-5 of the field's scale, blob lists bit for bit."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import volgen  # noqa: E402
+from conftest import assert_bits_equal, assert_close_rel  # noqa: E402
+from oracle import pyoracle as po  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+N = 1024
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    from visfd_amd import api
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    ctx = api.Context(0, stream.cuda_stream)
+    yield torch, dev, ctx
+    ctx.close()
+
+
+@pytest.fixture(scope="module")
+def volume(gpu):
+    """The volume bench.py times (same generator, same seed)."""
+    import bench
+    torch, dev, ctx = gpu
+    src = bench.synth_volume(torch, ctx, (N, N, N), dev, seed=12345)
+    torch.cuda.synchronize()
+    return src
+
+
+def _crop(t, lo, hi):
+    return t[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]].contiguous().cpu().numpy()
+
+
+def test_membrane_1024_cubed_crops_equal_oracle(gpu, volume, oracle):
+    """BASELINE config 4: `-membrane minima 3 -tv 5 -tv-angle-exponent 4` on 1024^3 (sigma 1.732, top 5 %, sigma_tv 8.66,
+    25^3 vote window), every stage fed by the previous device stage as in bench.py."""
+    import bench
+    from visfd_amd import api
+    torch, dev, ctx = gpu
+    src = volume
+    P = bench.MEMBRANE
+    sigma = P["sigma"]
+    ratio = api.ratio_from_threshold(0.03)
+    order = api.DECREASING_EIVALS
+    sigma_tv = float(np.float32(P["tv_sigma_ratio"]) * np.float32(sigma))
+    h = int(math.floor(np.float32(sigma_tv) * np.float32(math.sqrt(2.0))))
+    assert h == 12
+    # the steps of pipeline.membrane_detect, keeping the thresholded saliency (what the votes are cast from)
+    sal = torch.empty_like(src)
+    smoothed = torch.empty_like(src)
+    dirs = torch.zeros((3, N, N, N), device=dev)
+    ten = torch.empty((6, N, N, N), device=dev)
+    ctx.ridge_scores_dev(src, sal, smoothed, sigma, ratio, order)
+    thr = ctx.threshold_fraction_dev(sal, P["best_fraction"])
+    ctx.ridge_directions_dev(smoothed, sal, dirs, sigma, order)
+    ctx.synchronize()
+    sal_thr = sal.clone()
+    ctx.tv_dense_stick_dev(sal, dirs, ten, sigma_tv, P["tv_exponent"], math.sqrt(2.0))
+    ctx.tensor_saliency_dev(ten, sal, order)
+    ctx.synchronize()
+    nsal = int((sal_thr != 0).sum().item())
+    assert abs(nsal / N ** 3 - P["best_fraction"]) < 1e-3 and thr > 0
+
+    # membranes of the synthetic volume (bench.synth_volume): the tilted plane 0.15 x - 0.1 y + z = 0.35 N and the shell
+    # of radius 0.3 N around (0.5, 0.4, 0.5) N
+    zp = lambda y, x: int(round(0.35 * N - 0.15 * x + 0.1 * y))
+    E = 28
+    crops = [
+        (0, 0, 0),                                   # corner
+        (N - E, N - E, N - E),                       # opposite corner
+        (0, 500, 333),                               # z face
+        (320 - E // 2, 16 * 20 - E // 2, 16 * 31 - E // 2),   # across a run seam (z = 320) and tile seams in x and y
+        (640 - 5, N - E, 7),                         # run seam at z = 640, y face
+        (zp(200, 300) - E // 2, 200, 300),           # on the tilted membrane
+        (int(0.5 * N + 0.3 * N) - E // 2, int(0.4 * N), int(0.5 * N)),   # on the shell (its top)
+    ]
+    seen_dense = False
+    for (z0, y0, x0) in crops:
+        c0 = np.array([z0, y0, x0])
+        lo = np.maximum(c0 - h, 0)
+        hi = np.minimum(c0 + E + h, N)
+        s_sub = _crop(sal_thr, lo, hi)
+        d_sub = np.ascontiguousarray(np.stack([_crop(dirs[k], lo, hi) for k in range(3)], axis=-1))
+        want = oracle.tv_dense_stick(s_sub, d_sub, sigma_tv, P["tv_exponent"], 2.0 ** 0.5)
+        o = c0 - lo
+        want_c = want[o[0]:o[0] + E, o[1]:o[1] + E, o[2]:o[2] + E]
+        got_c = np.ascontiguousarray(np.stack([_crop(ten[k], c0, c0 + E) for k in range(6)], axis=-1))
+        assert np.abs(want_c).max() > 0
+        assert_bits_equal(got_c, want_c, "vote tensor in the crop at %s" % ((z0, y0, x0),))
+        seen_dense = seen_dense or (s_sub != 0).mean() > 0.12
+        # post-vote score of the crop (eigen-derived: 1e-5 of the field's scale)
+        s2 = np.zeros(want_c.shape[:3], np.float32)
+        oracle.tensor_saliency(np.ascontiguousarray(want_c), po.ORDER_DECREASING, s2)
+        assert_close_rel(_crop(sal, c0, c0 + E), s2, 1e-5, "post-vote score in the crop at %s" % ((z0, y0, x0),))
+    assert seen_dense, "no crop sits on a membrane (sender density several times the 5 % average)"
+
+    # the ridge stage that fed the votes, at full size: saliency before thresholding within 1e-5 of the oracle's on a
+    # crop + halo (Gaussian window + finite differences), and the threshold cut consistent with it
+    hg = int(math.floor(np.float32(sigma) * np.float32(ratio))) + 1
+    for (z0, y0, x0) in crops[:4]:
+        c0 = np.array([z0, y0, x0])
+        lo = np.maximum(c0 - hg, 0)
+        hi = np.minimum(c0 + E + hg, N)
+        sub = _crop(src, lo, hi)
+        _, hess = oracle.calc_hessian(sub, np.float32(sigma), ratio)
+        s_o, _ = oracle.hessian_saliency(hess, po.ORDER_DECREASING)
+        o = c0 - lo
+        # faces of the crop that are interior to the big volume see a different boundary normaliser: compare away from them
+        inner = [slice(o[k] + (hg if lo[k] > 0 else 0), o[k] + E - (hg if hi[k] < N else 0)) for k in range(3)]
+        innerg = [slice(c0[k] + (hg if lo[k] > 0 else 0), c0[k] + E - (hg if hi[k] < N else 0)) for k in range(3)]
+        a = sal_thr[innerg[0], innerg[1], innerg[2]].cpu().numpy()
+        b = s_o[inner[0], inner[1], inner[2]]
+        kept = a != 0
+        scale = float(np.abs(b).max())
+        assert np.all(np.abs(a[kept] - b[kept]) <= 1e-5 * scale), "saliency of kept voxels at %s" % ((z0, y0, x0),)
+        # voxels the device zeroed lie below the threshold, up to the tolerance band around it
+        assert np.all(b[~kept] < thr + 1e-5 * scale), "thresholded voxels at %s" % ((z0, y0, x0),)
+
+
+def test_blob_1024_cubed_crops_equal_oracle(gpu, volume, oracle):
+    """BASELINE config 3: `-blob-s all out 2.0 4.0 1.066` (12 scales) on 1024^3: the blobs found inside crops at a corner,
+    on faces and in the interior equal the oracle's on crop + halo, scores bit for bit."""
+    import bench
+    from visfd_amd import api, pipeline
+    torch, dev, ctx = gpu
+    src = volume
+    sig = pipeline.cli_blob_sigmas(*bench.BLOB)
+    assert len(sig) == 12
+    r = api.ratio_from_threshold(0.03)
+    mins, maxs = pipeline.blob_detect(ctx, src, sig)
+    assert len(mins) > 100000 and len(maxs) > 100000
+    halo = int(np.floor(r * float(sig[-1]) * 1.01)) + 2      # widest window + the 3x3x3 neighbourhood
+    E = 40
+    crops = [(0, 0, 0), (N - E, N - E, N - E), (0, 500, 700), (300, N - E, 0), (512 - 20, 512 - 20, 512 - 20),
+             (700, 123, N - E)]
+    total = 0
+    for (z0, y0, x0) in crops:
+        c0 = np.array([z0, y0, x0])
+        lo = np.maximum(c0 - halo, 0)
+        hi = np.minimum(c0 + E + halo, N)
+        sub = _crop(src, lo, hi)
+        wmin, wmax = oracle.blob_dog(sub, sig, None, None, 0.02, r, np.inf, -np.inf, False)
+        o = c0 - lo
+        for got, want, asc in ((mins, wmin, True), (maxs, wmax, False)):
+            inside = np.ones(len(got), bool)
+            keep = np.ones(len(want), bool)
+            for k, col in ((0, 2), (1, 1), (2, 0)):     # k: z, y, x axis; rows are x, y, z, sigma, score
+                inside &= (got[:, col] >= c0[k]) & (got[:, col] < c0[k] + E)
+                keep &= (want[:, col] >= o[k]) & (want[:, col] < o[k] + E)
+            a = got[inside].copy()
+            a[:, 0] -= lo[2]; a[:, 1] -= lo[1]; a[:, 2] -= lo[0]
+            b = want[keep]
+            total += len(b)
+            assert_bits_equal(volgen.sort_blobs(a, asc), volgen.sort_blobs(b, asc), "blobs in the crop at %s" % ((z0, y0, x0),))
+    assert total > 50

@@ -301,9 +301,8 @@ def test_blob_scan_overflow_path(ctx, oracle, monkeypatch):
     sig = oracle.diameters_to_sigmas(volgen.BLOB_DIAMS)
     r = ratio(oracle)
     want = oracle.blob_dog(src, sig, None, None, 0.02, r, np.inf, -np.inf, False)
-    monkeypatch.setenv("VISFD_HIP_BLOB_TEST_CAP", "8")
-    got = ctx.blob_dog(src, sig, None, None, 0.02, r, np.inf, -np.inf, False)
-    monkeypatch.delenv("VISFD_HIP_BLOB_TEST_CAP")
+    with ctx.options(blob_test_cap=8):
+        got = ctx.blob_dog(src, sig, None, None, 0.02, r, np.inf, -np.inf, False)
     assert len(want[0]) > 8 or len(want[1]) > 8
     for g, w, asc in ((got[0], want[0], True), (got[1], want[1], False)):
         assert_bits_equal(volgen.sort_blobs(g, asc), volgen.sort_blobs(w, asc), "blob list through the overflow path")
@@ -314,15 +313,16 @@ def test_tensor_voting_seeded(ctx, oracle, tag, monkeypatch):
     g = golden("membrane_seeded")
     m = volgen.block_mask(volgen.MEM_SHAPE, seed=302) if tag == "mask" else None
     sal, dirs = g[tag + "_salthr"], g[tag + "_dir"]
-    for dense in ("0", "1"):
-        monkeypatch.setenv("VISFD_HIP_TV_DENSE", dense)
-        for ex in (4, 2):
-            ten = ctx.tv_dense_stick(sal, dirs, volgen.MEM_TV_SIGMA, ex, 2.0 ** 0.5, m, m)
-            assert_bits_equal(ten, g["%s_tensor_e%d" % (tag, ex)], "tensor e%d dense=%s" % (ex, dense))
-        ten = ctx.tv_dense_stick(sal, dirs, volgen.MEM_TV_SIGMA, 3, 2.0 ** 0.5, m, m)
-        assert_close_rel(ten, g[tag + "_tensor_e3"], 1e-5, "tensor e3")
-        ten = ctx.tv_dense_stick(sal, dirs, volgen.MEM_TV_SIGMA, 4, 2.0 ** 0.5, m, m, curves=True)
-        assert_bits_equal(ten, g[tag + "_tensor_curves"], "curve-mode tensor")
+    # both kernels; the tiled one also with a persistent grid of 3 workgroups, so that each claims many units of work
+    for opts in ({"tv_dense": 0}, {"tv_dense": 1}, {"tv_max_wg": 3}, {"tv_max_wg": 1, "tv_zrun": 3}):
+        with ctx.options(**opts):
+            for ex in (4, 2):
+                ten = ctx.tv_dense_stick(sal, dirs, volgen.MEM_TV_SIGMA, ex, 2.0 ** 0.5, m, m)
+                assert_bits_equal(ten, g["%s_tensor_e%d" % (tag, ex)], "tensor e%d %s" % (ex, opts))
+            ten = ctx.tv_dense_stick(sal, dirs, volgen.MEM_TV_SIGMA, 3, 2.0 ** 0.5, m, m)
+            assert_close_rel(ten, g[tag + "_tensor_e3"], 1e-5, "tensor e3")
+            ten = ctx.tv_dense_stick(sal, dirs, volgen.MEM_TV_SIGMA, 4, 2.0 ** 0.5, m, m, curves=True)
+            assert_bits_equal(ten, g[tag + "_tensor_curves"], "curve-mode tensor")
     ten = g[tag + "_tensor_e4"]
     s2 = sal.copy()
     ctx.tensor_saliency(ten, po.ORDER_DECREASING, s2, m)
@@ -376,14 +376,17 @@ def test_tensor_voting_wide_windows(ctx, oracle, sigma_tv, shape, monkeypatch):
     ref = oracle.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5)
     ref_m = oracle.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5, mask, mask)
     assert np.abs(ref).max() > 0
-    for dense in ("0", "1"):
-        if dense == "1" and sigma_tv > 9:
+    # tiled kernel with the chip-filling grid, with 3 and with 1 persistent workgroup (every workgroup then claims
+    # many units: ring re-use, per-unit resets), with short runs on top of that, and the baseline kernel
+    for opts in ({}, {"tv_max_wg": 3}, {"tv_max_wg": 1}, {"tv_max_wg": 2, "tv_zrun": 4}, {"tv_max_wg": 2, "tv_no_replay": 1},
+                 {"tv_dense": 1}):
+        if opts.get("tv_dense") and sigma_tv > 9:
             continue
-        monkeypatch.setenv("VISFD_HIP_TV_DENSE", dense)
-        ten = ctx.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5)
-        assert_bits_equal(ten, ref, "tensor sigma_tv=%g dense=%s" % (sigma_tv, dense))
-        ten = ctx.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5, mask, mask)
-        assert_bits_equal(ten, ref_m, "masked tensor sigma_tv=%g dense=%s" % (sigma_tv, dense))
+        with ctx.options(**opts):
+            ten = ctx.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5)
+            assert_bits_equal(ten, ref, "tensor sigma_tv=%g %s" % (sigma_tv, opts))
+            ten = ctx.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5, mask, mask)
+            assert_bits_equal(ten, ref_m, "masked tensor sigma_tv=%g %s" % (sigma_tv, opts))
 
 
 def test_tensor_voting_dense_saliency(ctx, oracle):
@@ -437,13 +440,11 @@ def test_tensor_voting_unit_shapes_agree(ctx, oracle, monkeypatch):
     mask = volgen.block_mask(shape, seed=82)
     want = oracle.tv_dense_stick(sal, dirs, 3.0, 4, 2.0 ** 0.5)
     want_m = oracle.tv_dense_stick(sal, dirs, 3.0, 4, 2.0 ** 0.5, mask, mask)
-    for env in ({}, {"VISFD_HIP_TV_ZRUN": "1"}, {"VISFD_HIP_TV_ZRUN": "5"}, {"VISFD_HIP_TV_NO_REPLAY": "1"}):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        assert_bits_equal(ctx.tv_dense_stick(sal, dirs, 3.0, 4, 2.0 ** 0.5), want, "tensor %s" % env)
-        assert_bits_equal(ctx.tv_dense_stick(sal, dirs, 3.0, 4, 2.0 ** 0.5, mask, mask), want_m, "masked tensor %s" % env)
-        for k in env:
-            monkeypatch.delenv(k)
+    for opts in ({}, {"tv_zrun": 1}, {"tv_zrun": 5}, {"tv_no_replay": 1}, {"tv_max_wg": 3}, {"tv_max_wg": 3, "tv_zrun": 1},
+                 {"tv_max_wg": 2, "tv_zrun": 5}, {"tv_max_wg": 1, "tv_no_replay": 1}, {"tv_group": 2, "tv_max_wg": 5}):
+        with ctx.options(**opts):
+            assert_bits_equal(ctx.tv_dense_stick(sal, dirs, 3.0, 4, 2.0 ** 0.5), want, "tensor %s" % opts)
+            assert_bits_equal(ctx.tv_dense_stick(sal, dirs, 3.0, 4, 2.0 ** 0.5, mask, mask), want_m, "masked tensor %s" % opts)
 
 
 # ------------------------------------------------------------------------------------------ BASELINE-size volumes
@@ -464,11 +465,8 @@ def test_gauss_large_volume_crops_equal_oracle(ctx, oracle):
     ctx.synchronize()      # the library runs on its own stream here: finish before torch copies the result
     outs["fused"] = dst.clone()
     torch.cuda.synchronize()
-    os.environ["VISFD_HIP_GAUSS_3PASS"] = "1"
-    try:
+    with ctx.options(gauss_3pass=1):
         ctx.gauss_dev(src, dst, sigma, (h, h, h))
-    finally:
-        del os.environ["VISFD_HIP_GAUSS_3PASS"]
     outs["3-pass"] = dst
     ctx.synchronize()
     assert torch.equal(outs["fused"], outs["3-pass"])
@@ -557,13 +555,10 @@ def test_gauss_2048_cubed_crops_equal_oracle(ctx, oracle):
         b = want[z0 - lo[0]:z0 - lo[0] + E, y0 - lo[1]:y0 - lo[1] + E, x0 - lo[2]:x0 - lo[2] + E]
         assert_bits_equal(a, b, "2048^3 crop at %s" % ((z0, y0, x0),))
     # the three single-axis kernels on the same volume
-    os.environ["VISFD_HIP_GAUSS_3PASS"] = "1"
-    try:
+    with ctx.options(gauss_3pass=1):
         alt = torch.empty_like(src)
         ctx.gauss_dev(src, alt, sigma, (h, h, h), None, False)
         ctx.synchronize()
-    finally:
-        del os.environ["VISFD_HIP_GAUSS_3PASS"]
     for z in range(0, n, 256):
         assert torch.equal(got[z:z + 256], alt[z:z + 256]), "fused != 3-pass in slab %d" % z
     # normalised: interior voxels are divided by one constant (filter3d.hpp:1016-1018)
@@ -588,8 +583,8 @@ def test_empty_and_degenerate_inputs(ctx, oracle):
     d = np.zeros(shape + (3,), np.float32)
     d[..., 2] = 1.0
     zero = np.zeros(shape, np.float32)
-    for dense in ("0", "1"):
-        os.environ["VISFD_HIP_TV_DENSE"] = dense
+    for dense in (0, 1):
+        ctx.set_option("tv_dense", dense)
         try:
             ten = ctx.tv_dense_stick(zero, d, 3.0, 4, 2.0 ** 0.5)
             assert not ten.any(), "votes without senders"
@@ -602,7 +597,7 @@ def test_empty_and_degenerate_inputs(ctx, oracle):
             assert_bits_equal(ctx.tv_dense_stick(flat, dflat, 3.0, 4, 2.0 ** 0.5),
                               oracle.tv_dense_stick(flat, dflat, 3.0, 4, 2.0 ** 0.5), "single-plane volume")
         finally:
-            del os.environ["VISFD_HIP_TV_DENSE"]
+            ctx.set_option("tv_dense", 0)
     const = np.full((12, 14, 16), 7.0, np.float32)
     sig = np.array([1.0, 1.3, 1.7, 2.2], np.float32)
     mins, maxs = ctx.blob_dog(const, sig, None, None, 0.02, oracle.ratio_from_threshold(0.03))

@@ -47,6 +47,7 @@ _SIGS = {
     "visfd_hip_last_error": (C.c_char_p, []),
     "visfd_hip_abi_version": (C.c_int, []),
     "visfd_hip_workspace_bytes": (_i64, [_vp]),
+    "visfd_hip_set_option": (C.c_int, [_vp, C.c_char_p, _i64]),
     "visfd_hip_gauss_taps": (C.c_int, [C.c_float, C.c_int, _fp]),
     "visfd_hip_ratio_from_threshold": (C.c_float, [C.c_float]),
     "visfd_hip_local_fluctuations": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _fp, C.c_float, C.c_float, C.c_int]),
@@ -414,6 +415,26 @@ class Context:
 
     def workspace_bytes(self):
         return int(self._L.visfd_hip_workspace_bytes(self._h))
+
+    def set_option(self, name, value):
+        """Tuning / test switch of this context (include/visfd_hip.h: visfd_hip_set_option)."""
+        self._chk(self._L.visfd_hip_set_option(self._h, name.encode(), int(value)))
+
+    def options(self, **kw):
+        """Context manager: set options for the duration of a with-block, then restore the given defaults (0)."""
+        ctx = self
+
+        class _Scope:
+            def __enter__(self_):
+                for k, v in kw.items():
+                    ctx.set_option(k, v)
+                return ctx
+
+            def __exit__(self_, *a):
+                for k in kw:
+                    ctx.set_option(k, 2 if k == "gauss_wg_per_cu" else 0)
+                return False
+        return _Scope()
 
     # ---------------------------------------------------------------- host face (numpy)
     def separable3d(self, src, taps_xyz, mask=None, normalize=True):

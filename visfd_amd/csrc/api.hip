@@ -2,6 +2,8 @@
 // Device-pointer entry points orchestrate the stage functions; host-pointer entry points stage the
 // caller's volumes through the context workspace (H2D, run, D2H) and are synchronous.
 #include <cmath>
+#include <cctype>
+#include <cstdlib>
 #include <limits>
 #include <vector>
 
@@ -239,7 +241,34 @@ using namespace vh;
 
 extern "C" {
 
-int visfd_hip_abi_version(void) { return 4; }   // 2: + blob post-processing, binning, LabelConnected and its host helpers; 3: + host DiagonalizeFlatSym3 / ConvertFlatSym2Evects3; 4: + LocalFluctuations, two-step ridge (scores / directions)
+// ---- options: name -> field; VISFD_HIP_<NAME> in the environment gives the value a new context starts with ----------
+namespace {
+struct OptionDesc { const char* name; int visfd_hip_options::*i; int64_t visfd_hip_options::*l; };
+const OptionDesc kOptions[] = {
+    {"gauss_3pass", &visfd_hip_options::gauss_3pass, nullptr},   {"gauss_cfg", &visfd_hip_options::gauss_cfg, nullptr},
+    {"gauss_wg_per_cu", &visfd_hip_options::gauss_wg_per_cu, nullptr}, {"tv_dense", &visfd_hip_options::tv_dense, nullptr},
+    {"tv_group", &visfd_hip_options::tv_group, nullptr},         {"tv_zrun", &visfd_hip_options::tv_zrun, nullptr},
+    {"tv_no_replay", &visfd_hip_options::tv_no_replay, nullptr}, {"tv_max_wg", &visfd_hip_options::tv_max_wg, nullptr},
+    {"blob_test_cap", nullptr, &visfd_hip_options::blob_test_cap}, {"debug", &visfd_hip_options::debug, nullptr},
+};
+bool set_option(visfd_hip_options* o, const char* name, int64_t value) {
+  for (const OptionDesc& d : kOptions) {
+    if (std::strcmp(d.name, name) != 0) continue;
+    if (d.i) o->*(d.i) = (int)value; else o->*(d.l) = value;
+    return true;
+  }
+  return false;
+}
+void options_from_environment(visfd_hip_options* o) {
+  for (const OptionDesc& d : kOptions) {
+    std::string env = "VISFD_HIP_";
+    for (const char* c = d.name; *c; c++) env += (char)std::toupper((unsigned char)*c);
+    if (const char* e = std::getenv(env.c_str())) set_option(o, d.name, (int64_t)std::atoll(e));
+  }
+}
+}  // namespace
+
+int visfd_hip_abi_version(void) { return 5; }   // 5: + visfd_hip_set_option, CompactMultiChannelImage3D/TVDenseStick normalisation in the shim; 2: + blob post-processing, binning, LabelConnected and its host helpers; 3: + host DiagonalizeFlatSym3 / ConvertFlatSym2Evects3; 4: + LocalFluctuations, two-step ridge (scores / directions)
 const char* visfd_hip_last_error(void) { return g_last_error.c_str(); }
 
 int visfd_hip_create(int device, void* stream, visfd_hip_ctx** out) {
@@ -255,6 +284,7 @@ int visfd_hip_create(int device, void* stream, visfd_hip_ctx** out) {
   visfd_hip_ctx* ctx = new visfd_hip_ctx();
   ctx->device = device;
   ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  options_from_environment(&ctx->opt);
   if (stream) {
     ctx->stream = (hipStream_t)stream;
     ctx->own_stream = false;
@@ -270,10 +300,18 @@ int visfd_hip_create(int device, void* stream, visfd_hip_ctx** out) {
   return VISFD_HIP_OK;
 }
 
+int visfd_hip_set_option(visfd_hip_ctx* ctx, const char* name, int64_t value) {
+  VH_REQUIRE(ctx && name, "null argument");
+  if (!set_option(&ctx->opt, name, value)) return fail(VISFD_HIP_EINVAL, std::string("unknown option: ") + name);
+  return VISFD_HIP_OK;
+}
+
 int visfd_hip_trim(visfd_hip_ctx* ctx) {
   VH_REQUIRE(ctx, "null context");
   VH_HIP(hipSetDevice(ctx->device));
   VH_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->tv_table_dev = nullptr;   // lives in a workspace slot
+  ctx->tv_table_h = -1;
   for (int s = 0; s < WS_NSLOTS; s++) {
     if (ctx->slot_ptr[s]) VH_HIP(hipFree(ctx->slot_ptr[s]));
     ctx->slot_ptr[s] = nullptr;

@@ -265,10 +265,10 @@ static int scan_bufs(visfd_hip_ctx* ctx, int set, ScanBufs* B, bool pipelined, i
   B->cap_idx = cap_idx;
   B->cap_out = cap_out;
   if (pipelined) {   // test hook: pretend the buffers of the pipelined form are tiny, so that its overflow path runs
-    if (const char* e = getenv("VISFD_HIP_BLOB_TEST_CAP")) {
-      const size_t v = (size_t)atoll(e);
-      if (v >= 1 && v < B->cap_idx) B->cap_idx = v;
-      if (v >= 1 && v < B->cap_out) B->cap_out = v;
+    if (ctx->opt.blob_test_cap > 0) {
+      const size_t v = (size_t)ctx->opt.blob_test_cap;
+      if (v < B->cap_idx) B->cap_idx = v;
+      if (v < B->cap_out) B->cap_out = v;
     }
   }
   return VISFD_HIP_OK;
@@ -356,7 +356,7 @@ int blob_scan_collect(visfd_hip_ctx* ctx, int set, hipEvent_t done, hipStream_t 
   unsigned long long c2[2] = {0, 0};
   VH_HIP(hipMemcpyAsync(c2, B.counters, sizeof(c2), hipMemcpyDeviceToHost, aux));
   VH_HIP(hipStreamSynchronize(aux));
-  if (getenv("VISFD_HIP_DEBUG")) fprintf(stderr, "[blob scan] scale %d: %llu candidates, %llu blobs\n", scale_index, c2[0], c2[1]);
+  if (ctx->opt.debug) fprintf(stderr, "[blob scan] scale %d: %llu candidates, %llu blobs\n", scale_index, c2[0], c2[1]);
   if (c2[0] > B.cap_idx || c2[1] > B.cap_out) { *overflow = true; return VISFD_HIP_OK; }
   std::vector<Cand> h((size_t)c2[1]);
   if (c2[1]) {
@@ -386,7 +386,7 @@ int dev_blob_scan(visfd_hip_ctx* ctx, const float* lo, const float* mid, const f
     unsigned long long c2[2] = {0, 0};
     VH_HIP(hipMemcpyAsync(c2, B.counters, sizeof(c2), hipMemcpyDeviceToHost, st));
     VH_HIP(hipStreamSynchronize(st));
-    if (getenv("VISFD_HIP_DEBUG")) fprintf(stderr, "[blob scan] scale %d: %llu candidates\n", scale_index, c2[0]);
+    if (ctx->opt.debug) fprintf(stderr, "[blob scan] scale %d: %llu candidates\n", scale_index, c2[0]);
     if (c2[0] > B.cap_idx) {   // rare: grow and rescan
       unsigned long long* p = nullptr;
       VH_TRY(ws(ctx, WS_TVAUX, 2 * (size_t)c2[0] + 16, &p));

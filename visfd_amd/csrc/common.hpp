@@ -55,7 +55,26 @@ enum Slot {
 
 }  // namespace vh
 
+// Tuning and test switches: read ONCE from the environment when the context is created (VISFD_HIP_<NAME>) and
+// changed afterwards only through visfd_hip_set_option -- no getenv on any hot path.
+struct visfd_hip_options {
+  int gauss_3pass = 0;      // 1: the separable filter always takes its three single-axis passes
+  int gauss_cfg = 0;        // development builds: alternative tilings of the single-sweep filter
+  int gauss_wg_per_cu = 2;  // workgroups per CU the single-sweep filter cuts the volume into
+  int tv_dense = 0;         // 1: tensor voting by the baseline kernel (csrc/tv.hip)
+  int tv_group = 0;         // sender planes per LDS group (0: default)
+  int tv_zrun = 0;          // receiver planes per unit of work (0: default)
+  int tv_no_replay = 0;     // 1: compact every sender plane from the volume (no scratch rings)
+  int tv_max_wg = 0;        // cap on the persistent grid (0: fill the chip); tests use it to make workgroups claim many units
+  int64_t blob_test_cap = 0;   // pretend the pipelined blob scan's buffers hold this many entries (0: off)
+  int debug = 0;
+};
+
 struct visfd_hip_ctx {
+  visfd_hip_options opt;
+  float* tv_table_dev = nullptr;   // cached vote table (tv_tiled.hip) and what it was built for
+  float tv_table_key[2] = {0.0f, 0.0f};
+  int tv_table_h = -1;
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;

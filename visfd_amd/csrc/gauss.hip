@@ -385,10 +385,8 @@ static int dev_gauss_fused(visfd_hip_ctx* ctx, const float* src, float* dst, i64
     if (std::memcmp(&tz.t[H + j], &tz.t[H - j], sizeof(float)) != 0 || std::memcmp(&ty.t[H + j], &ty.t[H - j], sizeof(float)) != 0 ||
         std::memcmp(&tx.t[H + j], &tx.t[H - j], sizeof(float)) != 0)
       return VISFD_HIP_OK;
-  const char* force = getenv("VISFD_HIP_GAUSS_3PASS");
-  if (force && force[0] == '1') return VISFD_HIP_OK;
-  int cfg = 0;
-  if (const char* e = getenv("VISFD_HIP_GAUSS_CFG")) cfg = atoi(e);
+  if (ctx->opt.gauss_3pass) return VISFD_HIP_OK;
+  const int cfg = ctx->opt.gauss_cfg;
   *handled = true;
   switch (H) {
 #define VH_CASE(HH) case HH: return launch_gauss_fused_h##HH(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, cfg, minuend, log_scale);
@@ -412,8 +410,7 @@ static int dev_gauss_fused_yx(visfd_hip_ctx* ctx, const float* src, float* dst, 
   for (int j = 1; j <= H; j++)   // the kernel keeps the taps 0..H only
     if (std::memcmp(&ty.t[H + j], &ty.t[H - j], sizeof(float)) != 0 || std::memcmp(&tx.t[H + j], &tx.t[H - j], sizeof(float)) != 0)
       return VISFD_HIP_OK;
-  const char* force = getenv("VISFD_HIP_GAUSS_3PASS");
-  if (force && force[0] == '1') return VISFD_HIP_OK;
+  if (ctx->opt.gauss_3pass) return VISFD_HIP_OK;
   *handled = true;
   switch (H) {
 #define VH_CASE(HH) case HH: return launch_gauss_fused_yx_h##HH(ctx, src, dst, nx, ny, nz, tx, ty, numer, minuend, log_scale);

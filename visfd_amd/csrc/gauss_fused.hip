@@ -575,7 +575,7 @@ int launch_cfg(visfd_hip_ctx* ctx, const float* src, float* dst, i64 nx, i64 ny,
   // to amortise the 2H-plane ring warm-up
   const i64 tiles = (i64)tiles_x * tiles_y;
   int per_cu = 2;   // sweep at 1024^3: 1-2 workgroups per CU are best (fewer ring warm-ups), 6 costs 2.5 %
-  if (const char* e = getenv("VISFD_HIP_GAUSS_WG_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 64) per_cu = v; }   // tuning aid
+  if (ctx->opt.gauss_wg_per_cu >= 1 && ctx->opt.gauss_wg_per_cu <= 64) per_cu = ctx->opt.gauss_wg_per_cu;   // tuning aid
   i64 want_chunks = ((i64)ctx->num_cus * per_cu + tiles - 1) / tiles;
   if (want_chunks < 1) want_chunks = 1;
   i64 zchunk = (nz + want_chunks - 1) / want_chunks;

@@ -121,8 +121,35 @@ tv_dense_kernel(const float* __restrict__ sal, const float* __restrict__ dir,
 // declared in tv_tiled.hip
 int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* ten,
                  const float* mask_src, const float* mask_dst, i64 nx, i64 ny, i64 nz, i64 z_out0,
-                 i64 z_out1, int h, const float* w, const float* rhat, int exponent, bool curves,
-                 bool* handled);
+                 i64 z_out1, int h, const float4* dtab, int exponent, bool curves, bool* handled);
+
+// The vote table of (sigma_tv, cutoff) on the device: float4 {w, rhat_x, rhat_y, rhat_z} per offset j in z, y, x order
+// (filter3d.hpp:563-578, feature.hpp:2470-2478).  Built on the host once and kept in the context: a launch with the same
+// parameters queues no copy and never waits for the stream.
+static int tv_table_device(visfd_hip_ctx* ctx, float sigma_tv, float cutoff, int h, const float4** out) {
+  const size_t n = 2 * (size_t)h + 1, m = n * n * n;
+  if (ctx->tv_table_dev && ctx->tv_table_h == h && ctx->tv_table_key[0] == sigma_tv && ctx->tv_table_key[1] == cutoff) {
+    *out = reinterpret_cast<const float4*>(ctx->tv_table_dev);
+    return VISFD_HIP_OK;
+  }
+  // kernels of an earlier call may still read the old table, and the copy below reads host memory of this call
+  VH_HIP(hipStreamSynchronize(ctx->stream));
+  std::vector<float> w(m), rh(3 * m);
+  host_tv_tables(sigma_tv, h, w.data(), rh.data());
+  std::vector<float4> tab(m);
+  for (size_t k = 0; k < m; k++) tab[k] = make_float4(w[k], rh[3 * k], rh[3 * k + 1], rh[3 * k + 2]);
+  float4* dtab = nullptr;
+  ctx->tv_table_dev = nullptr;
+  VH_TRY(ws(ctx, WS_TVTAB, m, &dtab));
+  VH_HIP(hipMemcpyAsync(dtab, tab.data(), sizeof(float4) * m, hipMemcpyHostToDevice, ctx->stream));
+  VH_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->tv_table_dev = reinterpret_cast<float*>(dtab);
+  ctx->tv_table_h = h;
+  ctx->tv_table_key[0] = sigma_tv;
+  ctx->tv_table_key[1] = cutoff;
+  *out = dtab;
+  return VISFD_HIP_OK;
+}
 
 int dev_tv_dense_stick(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* ten,
                        const float* mask_src, const float* mask_dst, i64 nx, i64 ny, i64 nz,
@@ -134,25 +161,16 @@ int dev_tv_dense_stick(visfd_hip_ctx* ctx, const float* sal, const float* dir, f
   if (z_out0 == z_out1) return VISFD_HIP_OK;
   const int h = host_tv_halfwidth(sigma_tv, cutoff);
   VH_REQUIRE(h >= 0 && h <= 255, "tensor-voting window halfwidth out of range");
-  const int n = 2 * h + 1;
-  const size_t m = (size_t)n * n * n;
-  std::vector<float> w(m), rh(3 * m);
-  host_tv_tables(sigma_tv, h, w.data(), rh.data());
+  const float4* dtab = nullptr;
+  VH_TRY(tv_table_device(ctx, sigma_tv, cutoff, h, &dtab));
 
   bool handled = false;
-  const char* force_dense = getenv("VISFD_HIP_TV_DENSE");
-  if (!(force_dense && force_dense[0] == '1'))
-    VH_TRY(dev_tv_tiled(ctx, sal, dir, ten, mask_src, mask_dst, nx, ny, nz, z_out0, z_out1, h, w.data(),
-                        rh.data(), exponent, curves, &handled));
+  if (!ctx->opt.tv_dense)
+    VH_TRY(dev_tv_tiled(ctx, sal, dir, ten, mask_src, mask_dst, nx, ny, nz, z_out0, z_out1, h, dtab, exponent, curves,
+                        &handled));
   if (handled) return VISFD_HIP_OK;
 
-  std::vector<float4> tab(m);
-  for (size_t k = 0; k < m; k++) tab[k] = make_float4(w[k], rh[3 * k], rh[3 * k + 1], rh[3 * k + 2]);
-  float4* dtab = nullptr;
-  VH_TRY(ws(ctx, WS_TVTAB, m, &dtab));
   hipStream_t st = ctx->stream;
-  VH_HIP(hipMemcpyAsync(dtab, tab.data(), sizeof(float4) * m, hipMemcpyHostToDevice, st));
-  VH_HIP(hipStreamSynchronize(st));
   TvParams p;
   p.nx = (int)nx; p.ny = (int)ny; p.nz = (int)nz;
   p.z_out0 = (int)z_out0; p.z_out1 = (int)z_out1;

@@ -38,6 +38,12 @@ namespace vh {
 
 namespace {
 
+// VH_TV_SWEEP=1: the flush tests a listed sender against the wave's 64 receivers and votes it at once under the
+// resulting execution mask (sender data from uniform-address LDS reads); 0: the round-1 scheme (per-lane hit words,
+// every lane walks its own hits).
+#ifndef VH_TV_SWEEP
+#define VH_TV_SWEEP 1
+#endif
 constexpr int NT = 256;
 constexpr int TILE = 16;
 constexpr int VPT = 7;               // region voxels per thread per band
@@ -137,54 +143,20 @@ __device__ __forceinline__ void vote_acc(float T[6], float bse, float m0, float 
   acc(T[2], b2 * m2);
 }
 
-// VH_TV_PK=1 (tools/build_variant.py) builds the vote with two-wide float operations: 9 packed + 14 scalar
-// instead of 32 scalar instructions, bit-identical results -- and 6 % SLOWER on MI355X (877 vs 827 ms at 1024^3):
-// a v_pk_mul/add_f32 costs more than two scalar operations here (profiles/r01_microbench_valu.txt).  Kept as the
-// measured alternative; the product builds with 0.
-#ifndef VH_TV_PK
-#define VH_TV_PK 0
-#endif
-#if VH_TV_PK
-// The same vote with two-wide float operations (v_pk_mul_f32 / v_pk_add_f32: IEEE per component, no FMA), for the
-// surface modes.  d = {n0, n1, n2, sal}, tw = {r0, r1, r2, w}; sums T01 = (T0, T1), T54 = (T5, T4), and T3, T2.
-typedef float v2f __attribute__((ext_vector_type(2)));
-template <int MODE>
-__device__ __forceinline__ void vote_pk(const f4v& d, const f4v& tw, float mv, bool masked, v2f& T01, v2f& T54, float& T3,
-                                        float& T2) {
-  const v2f r01 = {tw.x, tw.y}, n01 = {d.x, d.y};
-  const v2f r2w = {tw.z, tw.w}, n2s = {d.z, d.w};
-  const v2f p01 = r01 * n01;             // (r0 n0, r1 n1)
-  v2f p2s;
-  if (masked) {                          // fv = w * mask value first (feature.hpp:2262-2275), then sal * fv
-    const float fv = tw.w * mv;
-    p2s = v2f{tw.z, fv} * n2s;
-  } else {
-    p2s = r2w * n2s;                     // (r2 n2, w sal)
-  }
-  const float u = (p01.x + p01.y) + p2s.x;
-  const float ux2 = u * 2.0f;
-  const float u2 = u * u;
-  const float c2 = 1.0f - u2;
-  const float dec = (MODE == 0) ? c2 * c2 : c2;
-  const float bse = p2s.y * dec;
-  const v2f m01 = v2f{ux2, ux2} * r01 - n01;
-  const float m2 = ux2 * tw.z - d.z;
-  const v2f b01 = v2f{bse, bse} * m01;
-  const float b2 = bse * m2;
-  T01 = T01 + b01 * m01;                 // (b0 m0, b1 m1)
-  T54 = T54 + b01 * v2f{m2, m2};         // (b0 m2, b1 m2)
-  T3 = T3 + b01.x * m01.y;
-  T2 = T2 + b2 * m2;
-}
-#endif
-
 // magnitude m (>= 0) with the sign of the integer j; j == 0 keeps +m (rhat components are +0.0 there)
 __device__ __forceinline__ float with_sign_of(float m, int j) {
   return __uint_as_float(__float_as_uint(m) | ((unsigned)j & 0x80000000u));
 }
 
 template <bool MASKED_SRC, int MODE>
+#ifndef VH_TV_WAVES
+#define VH_TV_WAVES 8
+#endif
+#if VH_TV_SWEEP
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MODE != 1 ? VH_TV_WAVES : 2, 8)))
+#else
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MODE != 1 ? 4 : 2, 4)))
+#endif
 tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, float* __restrict__ ten,
                 const float* __restrict__ mask_src, const float* __restrict__ mask_dst,
                 const float4* __restrict__ table /* [(2h+1)^3] : w, rhat_x, rhat_y, rhat_z at j */,
@@ -196,7 +168,11 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
   // it, which adds +-0 to their accumulators and leaves them bit-for-bit unchanged.
   // (one static block with the entry list first: its LDS address is then 0 and drops out of the vote loop's
   // address arithmetic)
+#if VH_TV_SWEEP
+  constexpr int OFF_POS = ENT_BYTES * (CAP + 1), OFF_HITW = OFF_POS + 8 * (CAP + 8), OFF_TOT = OFF_HITW;
+#else
   constexpr int OFF_POS = ENT_BYTES * (CAP + 1), OFF_HITW = OFF_POS + 4 * CAP, OFF_TOT = OFF_HITW + 4 * (NWORDS + 1) * NT;
+#endif
   constexpr int OFF_TILE = OFF_TOT + 2 * (NT / 64) * 4;
   constexpr int OFF_PCNT = OFF_TILE + 16;       // entries per cached sender plane, [2h+1] ints (h <= 40)
   __shared__ __attribute__((aligned(16))) unsigned char lds_static[OFF_PCNT + 4 * 84];
@@ -223,7 +199,9 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
     *reinterpret_cast<int*>(ent + 16) = 16 * (p.h * (2 * p.h + 1) + p.h);
     *reinterpret_cast<float*>(ent + 20) = 0.0f;
   }
+#if !VH_TV_SWEEP
   *reinterpret_cast<unsigned*>(hitw + SENT_WB + (tid << 2)) = 1u;   // sentinel row
+#endif
   for (int i = tid; i < p.slice_f4; i += NT) reinterpret_cast<float4*>(slices)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 
   // ---- persistent workgroups: tiles are claimed from a global counter ---------------------------------------
@@ -315,6 +293,50 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
     }
   };
 
+#if VH_TV_SWEEP
+  // ---- flush: every wave sweeps the list entries [0, n) in vote order; a sender is tested against the wave's 64
+  // receivers (one v_dot4_i32_i8, see above) and voted at once by the lanes it reaches, under their execution mask.
+  // Sender data (saliency, normal, table offset) come from uniform-address LDS reads, the table entry of
+  // j = receiver - sender from the lane's own address R - E.  Receivers that take no votes never hit: their
+  // accumulator operand is a large positive number.  The pos words of up to three entries past the end of the list
+  // hold a never-hit pattern (written with the list), so the sweep runs in whole batches of four.
+  auto flush = [&](int n, int ez_first) {
+    (void)ez_first;
+    const int recv_c_live = r_live ? recv_c : 0x100000;
+    // the table entry is requested with the sender's own data: its address needs only e16, which comes with the batch
+    auto vote_one = [&](int s, unsigned e16) {
+      const unsigned ent = ent_base + ((unsigned)s << 5);
+      const f4v tw = *lds_ptr<f4v>(r16s - e16);
+      const f4v d = *lds_ptr<f4v>(ent);
+      float fv = tw.x;
+      if (MASKED_SRC) fv = fv * *lds_ptr<float>(ent + 20);
+      float bse, m0, m1, m2;
+      vote_dir<MODE>(d.x, fv, tw.y, tw.z, tw.w, d.y, d.z, d.w, p.exponent, p.curves, bse, m0, m1, m2);
+      vote_acc(T, bse, m0, m1, m2);
+    };
+    // batches of four senders: {pos, e16} pairs; the next batch is in flight while this one is tested and voted
+    const uint4* pq = reinterpret_cast<const uint4*>(l_pos);
+    uint4 qa = pq[0], qb = pq[1];
+    for (int s0 = 0; s0 < n; s0 += 4) {   // uniform
+      const uint4 ca = qa, cb = qb;
+      qa = pq[(s0 >> 1) + 2];             // (at most 8 entries past the list: inside the array)
+      qb = pq[(s0 >> 1) + 3];
+      int d0, d1, d2, d3;
+      // four dots back to back: a dot result may be read by the VALU three instructions later at the earliest, and
+      // the compiler does not see hazards of instructions inside an asm block
+      asm("v_dot4_i32_i8 %0, %4, %6, %5\n\t"
+          "v_dot4_i32_i8 %1, %4, %7, %5\n\t"
+          "v_dot4_i32_i8 %2, %4, %8, %5\n\t"
+          "v_dot4_i32_i8 %3, %4, %9, %5"
+          : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
+          : "v"(recv4), "v"(recv_c_live), "v"(ca.x), "v"(ca.z), "v"(cb.x), "v"(cb.z));
+      if (d0 < 0) vote_one(s0, ca.y);
+      if (d1 < 0) vote_one(s0 + 1, ca.w);
+      if (d2 < 0) vote_one(s0 + 2, cb.y);
+      if (d3 < 0) vote_one(s0 + 3, cb.w);
+    }
+  };
+#else
   // ---- flush: phase A (tests) + phase B (votes) over list entries [0, n) in vote order ---------
   // slot_of_plane0: region-relative z (ez) of the group's first plane; slice slot = ez_first - ez
   auto flush = [&](int n, int ez_first) {
@@ -405,15 +427,9 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
     // A zero weight (taps on the rim of the spherical support, feature.hpp:2276) needs no branch: the
     // vote is then (+-0)*m*m and adding +-0 leaves the accumulators bit-for-bit unchanged.
     auto half1 = [&](const f4v& d, const f4v& tw, float mv, float& bse, float& m0, float& m1, float& m2) {
-#if VH_TV_PK
-      float fv = tw.w;
-      if (MASKED_SRC) fv = fv * mv;
-      vote_dir<MODE>(d.w, fv, tw.x, tw.y, tw.z, d.x, d.y, d.z, p.exponent, p.curves, bse, m0, m1, m2);
-#else
       float fv = tw.x;
       if (MASKED_SRC) fv = fv * mv;
       vote_dir<MODE>(d.x, fv, tw.y, tw.z, tw.w, d.y, d.z, d.w, p.exponent, p.curves, bse, m0, m1, m2);
-#endif
     };
     refill();
     read_entry(next_ent(), dA, eA, mvA);
@@ -421,25 +437,6 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
     twA = read_table(eA);
     const int npairs = niter >> 1;   // an odd count ends with the single vote after the loop (the pair loop's
                                      // prefetches beyond the last hit read the dummy entry: harmless)
-#if VH_TV_PK
-    if (MODE != 1) {
-      v2f T01 = {T[0], T[1]}, T54 = {T[5], T[4]};
-      float T3 = T[3], T2 = T[2];
-      for (int it = 0; it < npairs; it++) {
-        read_entry(next_ent(), dB, eB, mvB);
-        refill();
-        twB = read_table(eB);
-        vote_pk<MODE>(dA, twA, mvA, MASKED_SRC, T01, T54, T3, T2);
-        read_entry(next_ent(), dA, eA, mvA);
-        refill();
-        twA = read_table(eA);
-        vote_pk<MODE>(dB, twB, mvB, MASKED_SRC, T01, T54, T3, T2);
-      }
-      if (niter & 1) vote_pk<MODE>(dA, twA, mvA, MASKED_SRC, T01, T54, T3, T2);
-      T[0] = T01.x; T[1] = T01.y; T[5] = T54.x; T[4] = T54.y; T[3] = T3; T[2] = T2;
-      return;
-    }
-#endif
     for (int it = 0; it < npairs; it++) {
       float bse, m0, m1, m2;
       read_entry(next_ent(), dB, eB, mvB);
@@ -464,6 +461,7 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
     }
   };
 
+#endif
   // ---- the unit's receiver planes, bottom up --------------------------------------------------------------
   // Consecutive receiver planes share 2h of their 2h+1 sender planes.  The compacted sender list of a plane
   // (entries in vote order) is therefore written to a per-workgroup scratch ring in global memory when the plane
@@ -486,7 +484,11 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
 
   int n_list = 0;         // entries currently in the LDS list
   int ez_first = 0;       // region-relative z of the first plane of the current group
+  constexpr unsigned NEVER_HIT = 0x009c0000u;   // pos word whose dot product is positive for every receiver
   auto flush_full = [&]() {
+#if VH_TV_SWEEP
+    if (tid < 8) l_pos[2 * (n_list + tid)] = NEVER_HIT;
+#endif
     __syncthreads();   // list complete
     flush(n_list, ez_first);
     n_list = 0;
@@ -527,9 +529,14 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
           const int ex = (int)(m.x & 0xffu), ey = (int)(m.x >> 8);
           const int epx = ex - h - 8, epy = ey - h - 8;
           const int e2 = epx * epx + epy * epy + epz * epz;
-          l_pos[slot] = (unsigned)(epx & 0xff) | ((unsigned)(epy & 0xff) << 8) | ((unsigned)((-(e2 >> 7)) & 0xff) << 16) |
-                        ((unsigned)(e2 & 127) << 24);
+          const unsigned posw = (unsigned)(epx & 0xff) | ((unsigned)(epy & 0xff) << 8) | ((unsigned)((-(e2 >> 7)) & 0xff) << 16) |
+                                ((unsigned)(e2 & 127) << 24);
+#if VH_TV_SWEEP
+          *reinterpret_cast<uint2*>(l_pos + 2 * slot) = make_uint2(posw, (unsigned)(16 * (ey * S + ex - e16_plane)));
+#else
+          l_pos[slot] = posw;
           *reinterpret_cast<int*>(ent + 16) = 16 * (ey * S + ex - e16_plane);
+#endif
           if (MASKED_SRC) *reinterpret_cast<unsigned*>(ent + 20) = m.y;
         }
         n_list += take;
@@ -581,18 +588,19 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
                 const unsigned off = voff_of(v, row0, rows);
                 const int slot = n_list + (q - done);
                 unsigned char* ent = l_ent + ENT_BYTES * slot;
-#if VH_TV_PK
-                const float4 a = make_float4(buf_load(rd0, off), buf_load(rd1, off), buf_load(rd2, off), cur[v]);
-#else
                 const float4 a = make_float4(cur[v], buf_load(rd0, off), buf_load(rd1, off), buf_load(rd2, off));
-#endif
                 *reinterpret_cast<float4*>(ent) = a;
                 const int ex = rc_[v] & 0xff, ey = row0 + (rc_[v] >> 8);
                 const int epx = ex - h - 8, epy = ey - h - 8;
                 const int e2 = epx * epx + epy * epy + epz * epz;
-                l_pos[slot] = (unsigned)(epx & 0xff) | ((unsigned)(epy & 0xff) << 8) | ((unsigned)((-(e2 >> 7)) & 0xff) << 16) |
-                              ((unsigned)(e2 & 127) << 24);
+                const unsigned posw = (unsigned)(epx & 0xff) | ((unsigned)(epy & 0xff) << 8) | ((unsigned)((-(e2 >> 7)) & 0xff) << 16) |
+                                      ((unsigned)(e2 & 127) << 24);
+#if VH_TV_SWEEP
+                *reinterpret_cast<uint2*>(l_pos + 2 * slot) = make_uint2(posw, (unsigned)(16 * (ey * S + ex - e16_plane)));
+#else
+                l_pos[slot] = posw;
                 *reinterpret_cast<int*>(ent + 16) = 16 * (ey * S + ex - e16_plane);
+#endif
                 unsigned mv = 0u;
                 if (MASKED_SRC) {
                   mv = __float_as_uint(buf_load(plane_rsrc(mask_src, sz), off));
@@ -624,6 +632,9 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
     }
     // end of group (or of all planes): flush what is left
     if (((pl + 1) % p.group == 0) || (pl + 1 == nplanes)) {
+#if VH_TV_SWEEP
+      if (tid < 8) l_pos[2 * (n_list + tid)] = NEVER_HIT;
+#endif
       __syncthreads();
       if (n_list > 0) flush(n_list, ez_first);
       n_list = 0;
@@ -643,26 +654,13 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
 
 int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* ten,
                  const float* mask_src, const float* mask_dst, i64 nx, i64 ny, i64 nz, i64 z_out0,
-                 i64 z_out1, int h, const float* w, const float* rhat, int exponent, bool curves,
-                 bool* handled) {
+                 i64 z_out1, int h, const float4* dtab /* device: w, rhat_x, rhat_y, rhat_z per offset */, int exponent,
+                 bool curves, bool* handled) {
   *handled = false;
   if (h < 1 || h > 40) return VISFD_HIP_OK;  // table slices in LDS + byte-packed coordinates limits
   if (nx * ny >= (1LL << 29)) return VISFD_HIP_OK;  // plane descriptors are 32-bit
   const int hp1 = h + 1, n = 2 * h + 1;
-  // full signed table, one float4 per offset j (z, y, x order as built by filter3d.hpp:563-578 and
-  // feature.hpp:2470-2478)
-  const size_t m = (size_t)n * n * n;
-  std::vector<float4> tab(m);
-#if VH_TV_PK
-  for (size_t k = 0; k < m; k++) tab[k] = make_float4(rhat[3 * k], rhat[3 * k + 1], rhat[3 * k + 2], w[k]);
-#else
-  for (size_t k = 0; k < m; k++) tab[k] = make_float4(w[k], rhat[3 * k], rhat[3 * k + 1], rhat[3 * k + 2]);
-#endif
-  float4* dtab = nullptr;
-  VH_TRY(ws(ctx, WS_TVTAB, tab.size(), &dtab));
   hipStream_t st = ctx->stream;
-  VH_HIP(hipMemcpyAsync(dtab, tab.data(), sizeof(float4) * tab.size(), hipMemcpyHostToDevice, st));
-  VH_HIP(hipStreamSynchronize(st));
 
   TiledParams p;
   p.nx = (int)nx; p.ny = (int)ny; p.nz = (int)nz;
@@ -676,14 +674,17 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
   p.group = SLICE_BYTES / slice_bytes;
   if (p.group > MAX_GROUP) p.group = MAX_GROUP;
   if (p.group < 1) p.group = 1;
-  if (const char* e = getenv("VISFD_HIP_TV_GROUP")) { const int g = atoi(e); if (g >= 1 && g <= p.group) p.group = g; }
+#if VH_TV_SWEEP
+  p.group = 1;   // the sweep gains nothing from longer lists; one slice leaves LDS for eight workgroups per CU
+#endif
+  if (ctx->opt.tv_group >= 1 && ctx->opt.tv_group <= MAX_GROUP && (size_t)ctx->opt.tv_group * slice_bytes <= (size_t)SLICE_BYTES) p.group = ctx->opt.tv_group;
   p.tiles_x = (int)((nx + TILE - 1) / TILE);
   p.tiles_y = (int)((ny + TILE - 1) / TILE);
   p.exponent = exponent;
   p.curves = curves ? 1 : 0;
   // units of work: a tile over a run of receiver planes (the kernel replays compacted sender planes within a run)
   p.zrun = 32;   // sweep at 1024^3: 16: 853 ms, 24-64: 820-833 ms, 128: 838 ms
-  if (const char* e = getenv("VISFD_HIP_TV_ZRUN")) { const int v = atoi(e); if (v >= 1 && v <= 4096) p.zrun = v; }   // tuning aid
+  if (ctx->opt.tv_zrun >= 1 && ctx->opt.tv_zrun <= 4096) p.zrun = ctx->opt.tv_zrun;   // tuning aid
   if ((i64)p.zrun > z_out1 - z_out0) p.zrun = (int)(z_out1 - z_out0);
   if (p.zrun < 1) p.zrun = 1;
   const i64 nruns = (z_out1 - z_out0 + p.zrun - 1) / p.zrun;
@@ -695,7 +696,13 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
   if (slice_f4 < dummy_span) slice_f4 = dummy_span;
   p.slice_f4 = (int)slice_f4;
   const size_t lds = sizeof(float4) * slice_f4;   // dynamic part
+#if VH_TV_SWEEP
+  const size_t lds_static = (size_t)ENT_BYTES * (CAP + 1) + (size_t)8 * (CAP + 8) + 64 + 16 + 4 * 84;
+  const size_t max_wg = 8;
+#else
   const size_t lds_static = (size_t)ENT_BYTES * (CAP + 1) + (size_t)4 * CAP + (size_t)4 * (NWORDS + 1) * NT + 64 + 16 + 4 * 84;
+  const size_t max_wg = 4;
+#endif
   if (lds + lds_static > 150 * 1024) return VISFD_HIP_OK;   // window too wide for the LDS slices: baseline kernel
   const int mode = curves ? 1 : (exponent == 4 ? 0 : (exponent == 2 ? 2 : 1));
   // persistent workgroups (see the kernel): as many as the chip holds at once -- LDS allows 160 KB / (static +
@@ -704,9 +711,10 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
   VH_TRY(ws(ctx, WS_COUNTER, 16, &counter));
   VH_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned), st));
   size_t wg_per_cu = (160 * 1024) / (lds + lds_static);
-  if (wg_per_cu > 4) wg_per_cu = 4;
+  if (wg_per_cu > max_wg) wg_per_cu = max_wg;
   if (wg_per_cu < 1) wg_per_cu = 1;
   i64 ngrid = (i64)ctx->num_cus * (i64)wg_per_cu;
+  if (ctx->opt.tv_max_wg > 0 && ngrid > ctx->opt.tv_max_wg) ngrid = ctx->opt.tv_max_wg;   // tests: many units per workgroup
   if (ngrid > nblk) ngrid = nblk;
   // scratch rings: (2h+1) planes x (TILE+2h)^2 entries of 32 bytes per workgroup (1.3 GB for h = 12 on 256 CUs);
   // beyond 16 GB (very wide windows) the kernel runs without them and compacts every plane from the volume
@@ -714,8 +722,10 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
   {
     const size_t per_wg = (size_t)n * p.rw * p.rh * ENT_BYTES;
     const size_t total = per_wg * (size_t)ngrid;
-    const char* off = getenv("VISFD_HIP_TV_NO_REPLAY");
-    if (total <= ((size_t)16 << 30) && p.zrun > 1 && !(off && off[0] == '1')) VH_TRY(ws(ctx, WS_TVSCRATCH, total, &scratch));
+    if (total <= ((size_t)16 << 30) && p.zrun > 1 && !ctx->opt.tv_no_replay) {
+      // the kernel also runs without rings (it then compacts every plane from the volume): out of memory is not an error
+      if (ws(ctx, WS_TVSCRATCH, total, &scratch) != VISFD_HIP_OK) { scratch = nullptr; set_error(""); (void)hipGetLastError(); }
+    }
   }
 #define VH_TV_LAUNCH(MSK, MD)                                                                        \
   do {                                                                                               \
