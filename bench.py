@@ -116,6 +116,21 @@ def cpu_baseline(sample=96):
     }
 
 
+STAGE_BYTES_PER_VOXEL = {"gauss": 8.0, "blob_dog": 216.0, "membrane_tv": 112.0}
+
+
+def pipeline_roofline(stage_ms, ms_per_step, nvox):
+    total_b = sum(STAGE_BYTES_PER_VOXEL.values())
+    out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_voxel": total_b,
+           "achieved": round(total_b * nvox / (ms_per_step * 1e-3) / 1e9, 1),
+           "frac": round(total_b * nvox / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "stages": {}}
+    for (name, b), ms in zip(STAGE_BYTES_PER_VOXEL.items(), stage_ms):
+        gbs = b * nvox / (max(float(ms), 1e-9) * 1e-3) / 1e9
+        out["stages"][name] = {"bytes_per_voxel": b, "ms": round(float(ms), 3), "achieved": round(gbs, 1),
+                               "frac": round(gbs / HBM_PEAK_GBS, 4)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,6 +144,22 @@ def main():
     ap.add_argument("--no-2048", action="store_true", help="skip the extra Gaussian timing on a 2048^3 volume")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` run directly: start the N ranks as a FRESH child (torch.distributed.run, one rank per
+        # GPU over RCCL) and relay its JSON line and exit code.  This process has not touched the GPU -- nothing that has
+        # may replace itself with another program on this pool, hence a child, not an exec.
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+        sys.stdout.write(r.stdout)
+        sys.stdout.flush()
+        raise SystemExit(r.returncode)
+
     import torch
     import torch.distributed as dist
     from visfd_amd import api, pipeline, slab
@@ -137,9 +168,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
-                             % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # one GPU per rank over RCCL; a rehearsal with more ranks than GPUs (one-GPU box) shares cuda:0 and
     # stages halos through gloo -- that run checks the code path, its number means nothing
     own_gpu = world == 1 or torch.cuda.device_count() >= world
@@ -252,7 +281,8 @@ def main():
         roofline = {"bound": "hbm", "kernel": "gauss_fused_kernel<H=5> (separable 3-D Gaussian, sigma=2)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_gauss_traffic.json)",
+                    "traffic_unit": "bytes per launch, measured OFFLINE (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE in separate passes, "
+                                    "profiles/r01_gauss_traffic.json), not in this run",
                     "algorithmic_bytes": 8 * nv,
                     "ms_per_launch": round(g_ms, 4), "voxels_per_launch": nv,
                     "note": "exact mul+add arithmetic (no FMA) makes this kernel VALU-bound, see DESIGN.md"}
@@ -314,9 +344,10 @@ def main():
                        "flop_per_vote": 45, "salient_senders": n_salient, "nonzero_taps": n_taps,
                        "algorithmic_bytes": 40 * nv, "hbm_achieved_gbs": round(40.0 * nv / (tv_ms * 1e-3) / 1e9, 1),
                        "hbm_frac": round(40.0 * nv / (tv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                       "note": "peak = nominal FP32 vector rate (packed FMA); the reference's operation order forbids FMA "
-                               "and packing, which leaves ~39 T scalar fp32 instructions/s to issue: rocprofv3 VALUBusy of "
-                               "this kernel is 95-108 % (profiles/r01_pmc_occupancy_valu.txt, DESIGN.md 4.2)"}
+                       "traffic_unit": "bytes per launch, measured OFFLINE for the round-1 kernel (profiles/r01_tv_traffic.json)",
+                       "note": "peak = nominal FP32 vector rate, which counts an FMA as 2 flop; the reference's operation order "
+                               "forbids FMA, so the reachable rate is the 70 T scalar lane-operations/s the VALU issues "
+                               "(profiles/r02_microbench_valu.txt): 32 of them per vote, DESIGN.md 4.2"}
 
     # ---- the north-star target case: the separable Gaussian on a 2048^3 volume (2^33 voxels, 32 GiB) -------
     roofline_2048 = None
@@ -371,6 +402,10 @@ def main():
             "stages_ms": {"gauss": round(stage_ms[0] / args.steps, 3), "blob_dog": round(stage_ms[1] / args.steps, 3),
                           "membrane_tv": round(stage_ms[2] / args.steps, 3)},
             "results": counts,
+            # the BASELINE metric's own "% HBM roofline": algorithmic bytes of SURVEY.md 8d per voxel (3-D Gaussian 8, blob
+            # detection with 12 scales 8*12 + 12*10 = 216, Gauss + Hessian/eigen + select + TV + score 112) over the
+            # measured stage times of the timed steps
+            "roofline_pipeline": pipeline_roofline(stage_ms / args.steps, ms_per_step, nvox_rank * world),
             "roofline": roofline,
             "roofline_pass": roofline_pass,
             "roofline_tv": roofline_tv,

@@ -54,6 +54,8 @@ typedef struct visfd_hip_ctx visfd_hip_ctx;
 int visfd_hip_create(int device, void* stream, visfd_hip_ctx** out);
 int visfd_hip_destroy(visfd_hip_ctx* ctx);
 int visfd_hip_synchronize(visfd_hip_ctx* ctx);
+/* the hipStream_t every _dev entry point of this context runs on (the one given to visfd_hip_create, or the context's own) */
+void* visfd_hip_get_stream(visfd_hip_ctx* ctx);
 /* release the cached workspace (it otherwise persists between calls) */
 int visfd_hip_trim(visfd_hip_ctx* ctx);
 const char* visfd_hip_last_error(void);
@@ -147,10 +149,16 @@ typedef struct visfd_hip_blob {
 } visfd_hip_blob;
 
 /* aspect_ratio: NULL = {1,1,1}.  minima/maxima thresholds and use_threshold_ratios as
- * feature.hpp:72-74 (pass +INFINITY / -INFINITY to disable).  With ratios, a side whose threshold
- * is infinite is treated as disabled (the reference's behaviour there depends on thread
- * scheduling).  src and mask are HOST pointers in the first form, DEVICE pointers
- * in the _dev form; the blob lists are always host arrays of the given capacities. */
+ * feature.hpp:72-74 (pass +INFINITY / -INFINITY to disable).  With ratios the thresholds are multiplied by the best
+ * scores unconditionally, as the reference does (feature.hpp:369-372), so an infinite ratio is NOT "disabled":
+ *   minima_threshold = +inf with a finite maxima ratio: no minimum is kept (inf * negative best = -inf);
+ *   maxima_threshold = -inf: no maximum is ever recorded (feature.hpp:286-289: -inf * (-1) = +inf in every thread).
+ * ONE FENCE: with BOTH sides infinite in ratio mode the reference keeps, of the minima, the first one each OpenMP
+ * thread meets (its result depends on the thread count); this library returns all minima there (and no maxima).
+ * Volumes are expected to be finite: NaN/Inf voxels are outside the contract (the reference's sparse-input shortcut,
+ * filter1d.hpp:59-94, hides Inf*0 where the plain sums here would produce NaN).
+ * src and mask are HOST pointers in the first form, DEVICE pointers in the _dev form; the blob lists are always host
+ * arrays of the given capacities. */
 int visfd_hip_blob_dog(visfd_hip_ctx*, const float* src, const float* mask,
                        int64_t nx, int64_t ny, int64_t nz, const float* blob_sigma, int n_sigma,
                        const float* aspect_ratio, float delta_sigma_over_sigma,
@@ -334,6 +342,10 @@ int visfd_hip_threshold_fraction_dev(visfd_hip_ctx*, float* saliency, const floa
 int visfd_hip_select_histogram_dev(visfd_hip_ctx*, const float* saliency, const float* mask,
                                    int64_t nvox, int round, uint32_t prefix,
                                    uint64_t* hist_host /* 2048 */, uint64_t* n_unmasked_host);
+/* the same histogram written to DEVICE memory (2048 counters), asynchronous on the context's stream: multi-GPU callers
+ * all-reduce it there (RCCL) and fetch the sum once per round */
+int visfd_hip_select_histogram_todev(visfd_hip_ctx*, const float* saliency, const float* mask, int64_t nvox, int round,
+                                     uint32_t prefix, uint64_t* hist_dev /* 2048, device */);
 int visfd_hip_apply_threshold_dev(visfd_hip_ctx*, float* saliency, int64_t nvox, float threshold);
 
 /* ---- a13+a14: TV3D::TVDenseStick, lib/visfd/feature.hpp:1645-1675,1711-2037,2217-2384 ------------ */

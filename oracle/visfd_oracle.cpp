@@ -621,6 +621,9 @@ int vo_blob_dog(const float* src, const float* mask, int nx, int ny, int nz, con
           }
         }
   }
+  // ratio mode, maxima_threshold = -inf: every thread of the reference compares score > (-inf) * (-1) = +inf
+  // (feature.hpp:286-289; its running best starts at -1 and is never updated) and records no maximum at all
+  if (use_ratios && maxima_threshold == -inf) { maxs.clear(); gmax = -1.0f; }
   if ((minima_threshold != inf) || (maxima_threshold != -inf)) {
     float tmin = minima_threshold, tmax = maxima_threshold;
     if (use_ratios) { tmin *= gmin; tmax *= gmax; }

@@ -27,3 +27,20 @@ def test_slab_pipeline_on_gpu_equals_single_volume(world):
            os.path.join(ROOT, "tools", "slab_check.py")]
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "SLAB-OK world=%d" % world in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` run directly (as the driver runs the N=1 line) starts its ranks itself as a fresh child
+    and relays ONE JSON line and the exit code; on a one-GPU box the ranks share the card (a rehearsal of the code path:
+    the number means nothing)."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "96", "--steps", "1",
+                        "--warmup", "1", "--no-2048", "--no-cpu"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["per_gpu_voxels"] == 96 ** 3
+    assert abs(out["value"] - 2 * 96 ** 3 / (out["ms_per_step"] * 1e-3) / 1e6) <= 1e-3 * out["value"]

@@ -35,3 +35,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
         assert key in cb, key
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0
     assert out["roofline_tv"]["bound"] == "valu" and out["roofline_pass"]["bound"] == "hbm"
+    rp = out["roofline_pipeline"]   # the BASELINE metric's own "% HBM roofline"
+    assert rp["algorithmic_bytes_per_voxel"] == 336.0 and set(rp["stages"]) == {"gauss", "blob_dog", "membrane_tv"}
+    assert abs(rp["frac"] - rp["achieved"] / rp["peak"]) < 1e-3
+    assert abs(rp["achieved"] - 336.0 * 128 ** 3 / (out["ms_per_step"] * 1e-3) / 1e9) <= 0.02 * rp["achieved"] + 0.1

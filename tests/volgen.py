@@ -20,6 +20,9 @@ BLOB_MODES = {
     "none": dict(),
     "abs": dict(minima_threshold=-50.0, maxima_threshold=50.0, use_ratios=False),
     "ratio": dict(minima_threshold=0.5, maxima_threshold=0.5, use_ratios=True),
+    # one-sided ratios: the infinite side is NOT disabled in the reference (feature.hpp:286-289, 369-372)
+    "ratio_min_only": dict(minima_threshold=0.5, maxima_threshold=-np.inf, use_ratios=True),
+    "ratio_max_only": dict(minima_threshold=np.inf, maxima_threshold=0.5, use_ratios=True),
 }
 MEM_SHAPE = (20, 22, 26)
 MEM_SIGMA = np.float32(1.732)

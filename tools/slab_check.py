@@ -48,6 +48,17 @@ def main():
     sal = torch.zeros(lshape, device=dev)
     dirs = torch.zeros((3,) + lshape, device=dev)
     ten = torch.zeros((6,) + lshape, device=dev)
+    # a context on a stream of its own would race with torch's halo copies: the slab functions must refuse it
+    other = api.Context(dev_index)
+    try:
+        slab.membrane_detect_slab(other, L, src, sal, dirs, ten, sigma, tv_ratio, 4, fraction)
+        refused = False
+    except RuntimeError as e:
+        refused = "current stream" in str(e)
+    other.close()
+    if not refused:
+        print("SLAB-MISMATCH: a context on its own stream was accepted", flush=True)
+        sys.exit(1)
     thr = slab.membrane_detect_slab(ctx, L, src, sal, dirs, ten, sigma, tv_ratio, 4, fraction)
     src2 = torch.full(lshape, float("nan"), device=dev)
     L.owned(src2).copy_(full[L.z0:L.z1])

@@ -85,6 +85,8 @@ _SIGS = {
     "visfd_hip_threshold_fraction_dev": (C.c_int, [_vp, _vp, _vp, _i64, C.c_float, _fp]),
     "visfd_hip_select_histogram_dev": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_uint32,
                                                  C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "visfd_hip_select_histogram_todev": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_uint32, _vp]),
+    "visfd_hip_get_stream": (_vp, [_vp]),
     "visfd_hip_apply_threshold_dev": (C.c_int, [_vp, _vp, _i64, C.c_float]),
     "visfd_hip_tv_dense_stick": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, C.c_float, C.c_int,
                                            C.c_float, C.c_int]),
@@ -487,14 +489,20 @@ class Context:
                    use_ratios, cap):
         nz, ny, nx = shape
         sig = np.ascontiguousarray(sigmas, np.float32)
-        amin = np.empty(cap, _BLOB_DTYPE)   # visfd_hip_blob records
-        amax = np.empty(cap, _BLOB_DTYPE)
-        nmin, nmax = _i64(), _i64()
         asp = _f3(aspect) if aspect is not None else None
-        self._chk(fn(self._h, psrc, pmask, nx, ny, nz, sig.ctypes.data_as(_fp), len(sig), asp, float(delta),
-                     float(ratio), float(minima_threshold), float(maxima_threshold), int(use_ratios),
-                     amin.ctypes.data_as(C.POINTER(Blob)), cap, C.byref(nmin),
-                     amax.ctypes.data_as(C.POINTER(Blob)), cap, C.byref(nmax)))
+        for attempt in (0, 1):
+            amin = np.empty(cap, _BLOB_DTYPE)   # visfd_hip_blob records
+            amax = np.empty(cap, _BLOB_DTYPE)
+            nmin, nmax = _i64(), _i64()
+            rc = fn(self._h, psrc, pmask, nx, ny, nz, sig.ctypes.data_as(_fp), len(sig), asp, float(delta),
+                    float(ratio), float(minima_threshold), float(maxima_threshold), int(use_ratios),
+                    amin.ctypes.data_as(C.POINTER(Blob)), cap, C.byref(nmin),
+                    amax.ctypes.data_as(C.POINTER(Blob)), cap, C.byref(nmax))
+            if rc == 4 and attempt == 0:   # VISFD_HIP_ECAPACITY: the exact counts came back; once more with room for them
+                cap = max(nmin.value, nmax.value, 1)
+                continue
+            self._chk(rc)
+            break
         return _blobs_to_rows(amin, nmin.value)[0], _blobs_to_rows(amax, nmax.value)[0]
 
     def blob_dog(self, src, sigmas, mask=None, aspect=None, delta=0.02, ratio=2.5, minima_threshold=np.inf,
@@ -653,6 +661,16 @@ class Context:
                                                          int(prefix), hist.ctypes.data_as(C.POINTER(C.c_uint64)),
                                                          C.byref(n)))
         return hist, int(n.value)
+
+    def select_histogram_todev(self, sal, pass_, prefix, hist, mask=None):
+        """The round's histogram into `hist` (int64 tensor of 2048 on the device), asynchronous."""
+        assert hist.is_cuda and hist.numel() == 2048 and hist.element_size() == 8 and hist.is_contiguous()
+        self._chk(self._L.visfd_hip_select_histogram_todev(self._h, _dev(sal), _dev(mask), sal.numel(), int(pass_),
+                                                           int(prefix), hist.data_ptr()))
+
+    def stream_handle(self):
+        """The hipStream_t (as an integer) this context's device face runs on."""
+        return int(self._L.visfd_hip_get_stream(self._h) or 0)
 
     def apply_threshold_dev(self, sal, thr):
         self._chk(self._L.visfd_hip_apply_threshold_dev(self._h, _dev(sal), sal.numel(), float(thr)))

@@ -193,15 +193,17 @@ int blob_dog_dev(visfd_hip_ctx* ctx, const float* src, const float* mask, i64 nx
                            blob_sigma[ir - 1], scan_min, scan_max, true, true, &mins, &maxs));
     }
   }
+  // Ratio mode with max_thr = -inf: the reference's scan compares score > (-inf) * (its running best, initially -1) = +inf in
+  // every thread, so it never records a maximum (feature.hpp:286-289) -- deterministically none.
+  if (use_ratios && max_thr == -inf) maxs.clear();
   if ((min_thr != inf) || (max_thr != -inf)) {
     float tmin = min_thr, tmax = max_thr;
     if (use_ratios) {
       float gmin = 1.0f, gmax = -1.0f;  // feature.hpp:122-123
       for (auto& b : mins) if (b.score < gmin) gmin = b.score;
       for (auto& b : maxs) if (b.score > gmax) gmax = b.score;
-      // a side whose ratio threshold is infinite is "disabled": keep everything on that side
-      tmin = (min_thr == inf) ? inf : min_thr * gmin;
-      tmax = (max_thr == -inf) ? -inf : max_thr * gmax;
+      tmin = min_thr * gmin;   // feature.hpp:369-372, unconditionally: +inf * (negative best) = -inf keeps no minimum
+      tmax = max_thr * gmax;
     }
     std::vector<visfd_hip_blob> a, b;
     for (auto& m : mins) if (m.score <= tmin) a.push_back(m);
@@ -328,6 +330,8 @@ int visfd_hip_destroy(visfd_hip_ctx* ctx) {
   delete ctx;
   return rc;
 }
+
+void* visfd_hip_get_stream(visfd_hip_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 int visfd_hip_synchronize(visfd_hip_ctx* ctx) {
   VH_REQUIRE(ctx, "null context");
@@ -725,6 +729,14 @@ int visfd_hip_select_histogram_dev(visfd_hip_ctx* ctx, const float* sal, const f
   VH_REQUIRE(pass >= 0 && pass <= 2, "round must be 0, 1 or 2");
   VH_HIP(hipSetDevice(ctx->device));
   return dev_select_histogram(ctx, sal, mask, nvox, pass, prefix, hist_host, n_unmasked);
+}
+
+int visfd_hip_select_histogram_todev(visfd_hip_ctx* ctx, const float* sal, const float* mask, int64_t nvox, int pass,
+                                     uint32_t prefix, uint64_t* hist_dev) {
+  VH_REQUIRE(ctx && sal && hist_dev && nvox > 0, "bad argument");
+  VH_REQUIRE(pass >= 0 && pass <= 2, "round must be 0, 1 or 2");
+  VH_HIP(hipSetDevice(ctx->device));
+  return dev_select_histogram_todev(ctx, sal, mask, nvox, pass, prefix, hist_dev);
 }
 
 int visfd_hip_apply_threshold_dev(visfd_hip_ctx* ctx, float* sal, int64_t nvox, float thr) {

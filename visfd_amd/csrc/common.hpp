@@ -161,6 +161,8 @@ int dev_tensor_saliency(visfd_hip_ctx* ctx, const float* tensor_planar, const fl
 
 int dev_select_histogram(visfd_hip_ctx* ctx, const float* sal, const float* mask, i64 nvox, int pass,
                          uint32_t prefix, uint64_t* hist_host, uint64_t* n_unmasked_host);
+int dev_select_histogram_todev(visfd_hip_ctx* ctx, const float* sal, const float* mask, i64 nvox, int pass, uint32_t prefix,
+                               uint64_t* hist_dev);
 int dev_apply_threshold(visfd_hip_ctx* ctx, float* sal, i64 nvox, float thr);
 int dev_threshold_fraction(visfd_hip_ctx* ctx, float* sal, const float* mask, i64 nvox, float fraction,
                            float* thr_out);

@@ -88,6 +88,18 @@ int dev_select_histogram(visfd_hip_ctx* ctx, const float* sal, const float* mask
   return VISFD_HIP_OK;
 }
 
+// The same histogram left on the device (2048 counters, zeroed here first), asynchronous: multi-GPU callers all-reduce it
+// there and fetch the sum once.
+int dev_select_histogram_todev(visfd_hip_ctx* ctx, const float* sal, const float* mask, i64 nvox, int pass, uint32_t prefix,
+                               uint64_t* hist_dev) {
+  hipStream_t st = ctx->stream;
+  VH_HIP(hipMemsetAsync(hist_dev, 0, sizeof(unsigned long long) * NBINS, st));
+  const unsigned g = grid_for(nvox, BLOCK, (i64)ctx->num_cus * 32);
+  histogram_kernel<<<dim3(g), dim3(BLOCK), 0, st>>>(sal, mask, nvox, pass, prefix, reinterpret_cast<unsigned long long*>(hist_dev));
+  VH_HIP(hipGetLastError());
+  return VISFD_HIP_OK;
+}
+
 int dev_apply_threshold(visfd_hip_ctx* ctx, float* sal, i64 nvox, float thr) {
   const unsigned g = grid_for(nvox, BLOCK, (i64)ctx->num_cus * 32);
   apply_threshold_kernel<<<dim3(g), dim3(BLOCK), 0, ctx->stream>>>(sal, nvox, thr);

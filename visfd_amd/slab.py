@@ -17,6 +17,11 @@ along Z, one process and one GPU per slab:
 Stage kernels are reached through an `ops` object (visfd_amd.api.Context on a GPU); the arithmetic of
 an owned plane never depends on the decomposition, so slab results equal single-volume results
 bit-for-bit (tests/test_slab_*.py).
+
+STREAMS.  The functions here interleave library kernels (on the Context's HIP stream) with torch operations and
+torch.distributed collectives (on torch's CURRENT stream): the two must be the same stream, i.e. build the context as
+`api.Context(dev, torch.cuda.current_stream().cuda_stream)` (bench.py does).  Every entry point checks this and raises
+otherwise -- a context on its own stream would race with the halo copies silently.
 """
 import math
 
@@ -48,38 +53,66 @@ class SlabLayout:
         return t[..., self.own0:self.own1, :, :]
 
 
+def check_stream(ops, t):
+    """The library's stream must be torch's current stream on t's device (see the module docstring)."""
+    if t.is_cuda and hasattr(ops, "stream_handle"):
+        cur = torch.cuda.current_stream(t.device).cuda_stream
+        if ops.stream_handle() != cur:
+            raise RuntimeError("visfd_amd.slab: the Context runs on HIP stream %#x but torch's current stream is %#x; "
+                               "create it with api.Context(dev, torch.cuda.current_stream().cuda_stream)"
+                               % (ops.stream_handle(), cur))
+
+
+class HaloExchange:
+    """The ghost planes of several tensors ([nz_local, ny, nx] each, contiguous) within `depth` planes of the owned range,
+    from the two Z-neighbours' owned planes: ALL sends and receives are posted as one batch (one RCCL group: one launch
+    per neighbour link, not one per tensor) by start() and complete at wait(); work that does not touch the ghost planes
+    may be queued in between and overlaps the transfer."""
+
+    def __init__(self, tensors, layout, depth, group=None):
+        self.L, self.depth, self.group = layout, int(depth), group
+        self.tensors = list(tensors)
+        self.reqs, self.copies = [], []
+
+    def start(self):
+        L, depth, group = self.L, self.depth, self.group
+        if L.world == 1 or depth == 0:
+            return self
+        assert depth <= L.ghost
+        up, down = L.rank + 1, L.rank - 1
+        ops = []
+        for t in self.tensors:
+            # RCCL moves device memory directly.  gloo (CPU tests, or several ranks sharing one GPU in a rehearsal) has
+            # no device-memory point-to-point, so device tensors are staged through host copies.
+            staged = t.is_cuda and dist.get_backend(group) != "nccl"
+            if down >= 0:
+                send, recv = t[L.own0:L.own0 + depth], t[L.own0 - depth:L.own0]
+                rbuf = torch.empty(recv.shape, dtype=recv.dtype) if staged else recv
+                ops.append(dist.P2POp(dist.isend, send.cpu() if staged else send, down, group))
+                ops.append(dist.P2POp(dist.irecv, rbuf, down, group))
+                if staged:
+                    self.copies.append((recv, rbuf))
+            if up < L.world:
+                send, recv = t[L.own1 - depth:L.own1], t[L.own1:L.own1 + depth]
+                rbuf = torch.empty(recv.shape, dtype=recv.dtype) if staged else recv
+                ops.append(dist.P2POp(dist.isend, send.cpu() if staged else send, up, group))
+                ops.append(dist.P2POp(dist.irecv, rbuf, up, group))
+                if staged:
+                    self.copies.append((recv, rbuf))
+        self.reqs = dist.batch_isend_irecv(ops)
+        return self
+
+    def wait(self):
+        for r in self.reqs:
+            r.wait()      # RCCL: torch's current stream waits for the transfer; gloo: the host does
+        for dst, buf in self.copies:
+            dst.copy_(buf)
+        self.reqs, self.copies = [], []
+
+
 def exchange_halos(t, layout, depth, group=None):
-    """Fill the ghost planes of `t` ([nz_local, ny, nx], contiguous) within `depth` planes of the
-    owned range with the neighbours' owned planes.  Point-to-point with the two Z-neighbours."""
-    L = layout
-    if L.world == 1 or depth == 0:
-        return
-    assert depth <= L.ghost
-    up, down = L.rank + 1, L.rank - 1
-    # RCCL moves device memory directly.  gloo (CPU tests, or several ranks sharing one GPU in a
-    # test) has no device-memory point-to-point, so device tensors are staged through host copies.
-    staged = t.is_cuda and dist.get_backend(group) != "nccl"
-    views = {}
-    if down >= 0:
-        views["send_down"] = t[L.own0:L.own0 + depth]
-        views["recv_down"] = t[L.own0 - depth:L.own0]
-    if up < L.world:
-        views["send_up"] = t[L.own1 - depth:L.own1]
-        views["recv_up"] = t[L.own1:L.own1 + depth]
-    bufs = {k: (v.cpu() if staged else v) for k, v in views.items()}
-    ops = []
-    if down >= 0:
-        ops.append(dist.P2POp(dist.isend, bufs["send_down"], down, group))
-        ops.append(dist.P2POp(dist.irecv, bufs["recv_down"], down, group))
-    if up < L.world:
-        ops.append(dist.P2POp(dist.isend, bufs["send_up"], up, group))
-        ops.append(dist.P2POp(dist.irecv, bufs["recv_up"], up, group))
-    for r in dist.batch_isend_irecv(ops):
-        r.wait()
-    if staged:
-        for k in ("recv_down", "recv_up"):
-            if k in views:
-                views[k].copy_(bufs[k])
+    """Fill the ghost planes of `t` (or of every tensor of a list) within `depth` planes of the owned range."""
+    HaloExchange(t if isinstance(t, (list, tuple)) else [t], layout, depth, group).start().wait()
 
 
 def _pick_descending(hist, k):
@@ -103,15 +136,22 @@ def distributed_threshold_fraction(ops, sal_owned, fraction, layout, mask_owned=
     it (handlers.cpp:1751-1797).  Three radix rounds; each all-reduces 2048 counters."""
     prefix, k, thr_key = 0, None, 0
     shifts = (21, 10, 0)
+    # over RCCL the histogram never leaves the devices until it is summed: the kernel writes it to device memory, the
+    # all-reduce runs there, and one 16 KB copy per round brings the sum to the host that picks the digit
+    on_dev = (layout.world > 1 and sal_owned.is_cuda and hasattr(ops, "select_histogram_todev")
+              and dist.get_backend(group) == "nccl")
+    hdev = torch.empty(2048, dtype=torch.int64, device=sal_owned.device) if on_dev else None
     for rnd in range(3):
-        hist, _ = ops.select_histogram_dev(sal_owned, rnd, prefix, mask_owned)
-        h = torch.from_numpy(hist.astype(np.int64))
-        if layout.world > 1:
-            dev = sal_owned.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
-            h = h.to(dev)
-            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
-            h = h.cpu()
-        h = h.numpy()
+        if on_dev:
+            ops.select_histogram_todev(sal_owned, rnd, prefix, hdev, mask_owned)
+            dist.all_reduce(hdev, op=dist.ReduceOp.SUM, group=group)
+            h = hdev.cpu().numpy()
+        else:
+            hist, _ = ops.select_histogram_dev(sal_owned, rnd, prefix, mask_owned)
+            h = torch.from_numpy(hist.astype(np.int64))
+            if layout.world > 1:
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            h = h.numpy()
         if rnd == 0:
             n = int(h.sum())
             k = int(math.floor(np.float32(n) * np.float32(fraction)))  # size_t -> float product
@@ -136,6 +176,7 @@ def membrane_detect_slab(ops, layout, src, sal, dirs, tensor, sigma, tv_sigma_ra
     sigma_tv = float(np.float32(tv_sigma_ratio) * np.float32(sigma))
     h_tv = int(math.floor(np.float32(sigma_tv) * np.float32(tv_truncate_ratio)))
     assert L.world == 1 or (h_gauss + 1 <= L.ghost and h_tv <= L.ghost), "ghost depth too small"
+    check_stream(ops, src)
     # 1. source halo deep enough for smoothing + the 19-point stencil
     exchange_halos(src, L, min(L.ghost, h_gauss + 1), group)
     # 2. saliency/direction on every stored plane; planes closer than h_gauss+1 to an interior
@@ -155,18 +196,30 @@ def membrane_detect_slab(ops, layout, src, sal, dirs, tensor, sigma, tv_sigma_ra
         # ghost planes keep their unthresholded scores here: their directions are overwritten by the halo exchange
         # below, and planes beyond the voting halo are zeroed before voting
         ops.ridge_directions_dev(smoothed, sal, dirs, sigma, order)
-    # 4. (saliency, direction) halo for the voting window
-    exchange_halos(sal, L, min(L.ghost, h_tv), group)
-    for c in range(3):
-        exchange_halos(dirs[c], L, min(L.ghost, h_tv), group)
-    # stored planes beyond the exchanged halo must not vote
+    # 4. (saliency, direction) halo for the voting window: the four channels in ONE batch.  Receiver planes at least h_tv
+    #    away from both ends of the owned range see owned sender planes only, so their votes are queued while the halo is
+    #    in flight; the two bands next to the ends follow once it has arrived.
+    #    Stored planes beyond the exchanged halo must not vote: zeroed first (they are not part of the transfer).
     if L.own0 - h_tv > 0:
         sal[:L.own0 - h_tv].zero_()
     if L.own1 + h_tv < L.nz_local:
         sal[L.own1 + h_tv:].zero_()
-    # 5. votes for the owned planes; 6. score
-    ops.tv_dense_stick_dev(sal, dirs, tensor, sigma_tv, tv_exponent, tv_truncate_ratio, None, None, False,
-                           (L.own0, L.own1))
+    halo = HaloExchange([sal, dirs[0], dirs[1], dirs[2]], L, min(L.ghost, h_tv), group).start()
+    vote = lambda z0, z1: ops.tv_dense_stick_dev(sal, dirs, tensor, sigma_tv, tv_exponent, tv_truncate_ratio, None, None,
+                                                 False, (z0, z1))
+    lo_band = L.own0 + (h_tv if L.rank > 0 else 0)              # first receiver plane that needs no ghost plane
+    hi_band = L.own1 - (h_tv if L.rank < L.world - 1 else 0)
+    if L.world > 1 and hi_band > lo_band:
+        vote(lo_band, hi_band)                                  # 5a. interior, overlapping the transfer
+        halo.wait()
+        if lo_band > L.own0:
+            vote(L.own0, lo_band)                               # 5b. the bands that read ghost planes
+        if hi_band < L.own1:
+            vote(hi_band, L.own1)
+    else:
+        halo.wait()
+        vote(L.own0, L.own1)
+    # 6. score
     ops.tensor_saliency_dev(tensor, sal, order)
     return thr
 
@@ -209,9 +262,14 @@ def blob_detect_slab(ops, layout, src, sigmas, truncate_threshold=0.03, delta=0.
     smax = float(np.max(sigmas)) * (1.0 + 0.5 * delta)
     depth = int(math.floor(ratio * smax)) + 1
     assert L.world == 1 or depth <= L.ghost, "ghost depth too small for the widest LoG"
+    check_stream(ops, src)
     exchange_halos(src, L, min(L.ghost, depth), group)
-    # thresholds are applied after the merge (ratio mode needs the global best score)
-    mins, maxs = ops.blob_dog_dev(src, sigmas, None, None, delta, ratio, np.inf, -np.inf, False, cap)
+    # absolute thresholds prune inside the scan (strict, feature.hpp:270-291): only survivors are sorted and copied to
+    # the host; ratio thresholds need the global best score first, so they are applied after the merge
+    if use_ratios:
+        mins, maxs = ops.blob_dog_dev(src, sigmas, None, None, delta, ratio, np.inf, -np.inf, False, cap)
+    else:
+        mins, maxs = ops.blob_dog_dev(src, sigmas, None, None, delta, ratio, minima_threshold, maxima_threshold, False, cap)
 
     def own(rows):
         keep = (rows[:, 2] >= L.own0) & (rows[:, 2] < L.own1)
@@ -224,14 +282,14 @@ def blob_detect_slab(ops, layout, src, sigmas, truncate_threshold=0.03, delta=0.
         mins, maxs = _all_gather_rows(src, (mins, maxs), group)
     inf = np.float32(np.inf)
     tmin, tmax = np.float32(minima_threshold), np.float32(maxima_threshold)
-    if use_ratios:  # feature.hpp:369-372 with the global best scores
-        gmin = np.float32(min([1.0] + list(mins[:, 4])))
-        gmax = np.float32(max([-1.0] + list(maxs[:, 4])))
-        tmin = inf if tmin == inf else np.float32(tmin * gmin)
-        tmax = -inf if tmax == -inf else np.float32(tmax * gmax)
-        mins = mins[mins[:, 4] <= tmin]
-        maxs = maxs[maxs[:, 4] >= tmax]
-    else:  # absolute thresholds are strict in the scan (feature.hpp:270-291)
-        mins = mins[mins[:, 4] < tmin]
-        maxs = maxs[maxs[:, 4] > tmax]
+    if use_ratios:
+        # feature.hpp:286-289: with maxima_threshold = -inf the reference never records a maximum in ratio mode
+        if tmax == -inf:
+            maxs = maxs[:0]
+        if tmin != inf or tmax != -inf:   # feature.hpp:362-417 with the GLOBAL best scores, multiplied unconditionally
+            gmin = np.float32(min([1.0] + list(mins[:, 4])))
+            gmax = np.float32(max([-1.0] + list(maxs[:, 4])))
+            with np.errstate(invalid="ignore"):
+                mins = mins[mins[:, 4] <= np.float32(tmin * gmin)]
+                maxs = maxs[maxs[:, 4] >= np.float32(tmax * gmax)]
     return mins, maxs
