@@ -369,6 +369,12 @@ int visfd_hip_tv_dense_stick_slab_dev(visfd_hip_ctx*, const float* saliency, con
                                       int64_t nx, int64_t ny, int64_t nz_local, int64_t z_out0,
                                       int64_t z_out1, float sigma_tv, int exponent,
                                       float cutoff_ratio, int detect_curves);
+/* The denominators of TVDenseStick(normalize=true) with a source mask (feature.hpp:1761-1822, 2376-2382):
+ * den[voxel] = sum of w(j) * mask_src(sender) over the votes the voxel receives, added in vote order; voxels with
+ * mask_dst == 0 keep the caller's value.  Host pointers.  include/visfd_hip.hpp divides the tensors by it exactly as
+ * the reference does. */
+int visfd_hip_tv_weight_sum(visfd_hip_ctx*, const float* saliency, float* den, const float* mask_src, const float* mask_dst,
+                            int64_t nx, int64_t ny, int64_t nz, float sigma_tv, float cutoff_ratio);
 /* halfwidth of the vote window, floor(sigma_tv*cutoff) (feature.hpp:1671); tables (nullable):
  * w[(2h+1)^3], rhat[(2h+1)^3][3] as built by filter3d.hpp:546-601 and feature.hpp:2468-2482. */
 int visfd_hip_tv_tables(float sigma_tv, float cutoff_ratio, int* halfwidth_out, float* w,

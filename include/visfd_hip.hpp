@@ -14,8 +14,10 @@
 //   ApplySeparable lib/visfd/filter3d.hpp:686-695  (with GenFilterGauss1D, filter1d.hpp:409)
 //   BlobDog      lib/visfd/feature.hpp:53-77               BlobDogD  :446-470
 //   CalcHessian  lib/visfd/feature.hpp:1203-1219
-//   TV3D         lib/visfd/feature.hpp:1645-1647, TVDenseStick :1711-1724
+//   TV3D         lib/visfd/feature.hpp:1645-1647, TVDenseStick :1711-1901 (with its normalize / diagonalize_dest steps)
+//   BlobDogNM / _BlobDogNM  bin/filter_mrc/feature_variants.hpp:393-580
 //   Alloc3D / Dealloc3D  lib/visfd/alloc3d.hpp:25, :75
+//   CompactMultiChannelImage3D  lib/visfd/multichannel_image3d.hpp:41-204
 // Only Scalar = float is provided (the hot path and the CLI use float throughout).
 #ifndef VISFD_HIP_HPP
 #define VISFD_HIP_HPP
@@ -28,6 +30,7 @@
 #include <limits>
 #include <ostream>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "visfd_hip.h"
@@ -94,6 +97,98 @@ void Dealloc3D(Entry*** a) {
     delete[] a;
   }
 }
+
+// ---- lib/visfd/multichannel_image3d.hpp:41-204 ------------------------------------------------------
+// One pointer per voxel (nullptr where mask == 0) into one compact array of n_good_voxels * channels numbers in scan
+// order: the container HandleTV keeps its Hessians and vote tensors in (bin/filter_mrc/handlers.cpp:1564-1565).
+template <typename Scalar>
+class CompactMultiChannelImage3D {
+  Scalar* afI;
+  size_t n_good_voxels;
+  int n_channels_per_voxel;
+  int image_size[3];
+
+  void Alloc(int const set_image_size[3], Scalar const* const* const* aaafMask, std::ostream* pReportProgress) {
+    for (int d = 0; d < 3; d++) image_size[d] = set_image_size[d];
+    if (pReportProgress)
+      *pReportProgress << " -- Attempting to allocate space for a " << n_channels_per_voxel << "-channel image\n"
+                       << " -- (If this crashes your computer, find a computer with\n"
+                       << " --  more RAM and use \"ulimit\", OR use a smaller image.)\n";
+    aaaafI = Alloc3D<Scalar*>(image_size);
+    n_good_voxels = 0;
+    for (int iz = 0; iz < image_size[2]; iz++)
+      for (int iy = 0; iy < image_size[1]; iy++)
+        for (int ix = 0; ix < image_size[0]; ix++) {
+          aaaafI[iz][iy][ix] = nullptr;
+          if (!(aaafMask && aaafMask[iz][iy][ix] == 0.0)) n_good_voxels++;
+        }
+    afI = new Scalar[n_good_voxels * (size_t)n_channels_per_voxel];
+    size_t n = 0;
+    for (int iz = 0; iz < image_size[2]; iz++)
+      for (int iy = 0; iy < image_size[1]; iy++)
+        for (int ix = 0; ix < image_size[0]; ix++) {
+          if (aaafMask && aaafMask[iz][iy][ix] == 0.0) continue;
+          aaaafI[iz][iy][ix] = &afI[n * (size_t)n_channels_per_voxel];
+          n++;
+        }
+    if (pReportProgress) *pReportProgress << "        done\n" << std::endl;
+  }
+  void Dealloc() {
+    delete[] afI;
+    Dealloc3D(aaaafI);
+    afI = nullptr;
+    aaaafI = nullptr;
+  }
+
+ public:
+  Scalar**** aaaafI;   // a 3-D array of pointers into the compact array
+
+  int nchannels() { return n_channels_per_voxel; }
+  explicit CompactMultiChannelImage3D(int set_n_channels_per_voxel)
+      : afI(nullptr), n_good_voxels(0), n_channels_per_voxel(set_n_channels_per_voxel), aaaafI(nullptr) {
+    image_size[0] = image_size[1] = image_size[2] = 0;
+  }
+  CompactMultiChannelImage3D(int set_n_channels_per_voxel, int const set_image_size[3],
+                             Scalar const* const* const* aaafMask = nullptr, std::ostream* pReportProgress = nullptr)
+      : afI(nullptr), n_good_voxels(0), n_channels_per_voxel(set_n_channels_per_voxel), aaaafI(nullptr) {
+    Resize(set_image_size, aaafMask, pReportProgress);
+  }
+  void Resize(int const set_image_size[3], Scalar const* const* const* aaafMask = nullptr,
+              std::ostream* pReportProgress = nullptr) {
+    if (aaaafI) Dealloc();
+    Alloc(set_image_size, aaafMask, pReportProgress);
+  }
+  ~CompactMultiChannelImage3D() { Dealloc(); }
+  CompactMultiChannelImage3D(const CompactMultiChannelImage3D<Scalar>& source)
+      : afI(nullptr), n_good_voxels(0), n_channels_per_voxel(source.n_channels_per_voxel), aaaafI(nullptr) {
+    for (int d = 0; d < 3; d++) image_size[d] = source.image_size[d];
+    if (!source.aaaafI) return;
+    n_good_voxels = source.n_good_voxels;
+    aaaafI = Alloc3D<Scalar*>(image_size);
+    afI = new Scalar[n_good_voxels * (size_t)n_channels_per_voxel];
+    for (size_t i = 0; i < n_good_voxels * (size_t)n_channels_per_voxel; i++) afI[i] = source.afI[i];
+    for (int iz = 0; iz < image_size[2]; iz++)
+      for (int iy = 0; iy < image_size[1]; iy++)
+        for (int ix = 0; ix < image_size[0]; ix++)
+          aaaafI[iz][iy][ix] = source.aaaafI[iz][iy][ix] ? afI + (source.aaaafI[iz][iy][ix] - source.afI) : nullptr;
+  }
+  void swap(CompactMultiChannelImage3D<Scalar>& other) {
+    std::swap(n_good_voxels, other.n_good_voxels);
+    std::swap(n_channels_per_voxel, other.n_channels_per_voxel);
+    for (int d = 0; d < 3; d++) std::swap(image_size[d], other.image_size[d]);
+    std::swap(afI, other.afI);
+    std::swap(aaaafI, other.aaaafI);
+  }
+  CompactMultiChannelImage3D(CompactMultiChannelImage3D<Scalar>&& other)
+      : afI(nullptr), n_good_voxels(0), n_channels_per_voxel(other.n_channels_per_voxel), aaaafI(nullptr) {
+    image_size[0] = image_size[1] = image_size[2] = 0;
+    this->swap(other);
+  }
+  CompactMultiChannelImage3D<Scalar>& operator=(CompactMultiChannelImage3D<Scalar> source) {
+    this->swap(source);
+    return *this;
+  }
+};
 
 // ---- lib/visfd/filter1d.hpp:26-390 (the fields the hot path's callers touch) -------------------
 template <typename Scalar, typename Integer>
@@ -447,6 +542,68 @@ inline void DiscardOverlappingBlobs(std::vector<std::array<float, 3> >& blob_crd
   if (pReportProgress) *pReportProgress << "done.\n";
 }
 
+// ---- BlobDogNM / _BlobDogNM: bin/filter_mrc/feature_variants.hpp:393-580 --------------------------------------
+// BlobDogD followed by non-max suppression of overlapping blobs (minima best-first by increasing score, maxima by
+// decreasing score); the `_` form takes the filter window either as a ratio or as a decay threshold.
+inline void BlobDogNM(int const image_size[3], float const* const* const* aaafSource,
+                      float const* const* const* aaafMask, const std::vector<float>& blob_diameters,
+                      std::vector<std::array<float, 3> >* pva_minima_crds = nullptr,
+                      std::vector<std::array<float, 3> >* pva_maxima_crds = nullptr,
+                      std::vector<float>* pv_minima_diameters = nullptr,
+                      std::vector<float>* pv_maxima_diameters = nullptr,
+                      std::vector<float>* pv_minima_scores = nullptr, std::vector<float>* pv_maxima_scores = nullptr,
+                      const float aspect_ratio[3] = nullptr, float delta_sigma_over_sigma = 0.02,
+                      float truncate_ratio = 2.5, float minima_threshold = 0.5, float maxima_threshold = 0.5,
+                      bool use_threshold_ratios = true, float sep_ratio_thresh = 1.0,
+                      float nonmax_max_overlap_large = 1.0, float nonmax_max_overlap_small = 1.0,
+                      std::ostream* pReportProgress = nullptr, float**** aaaafI = nullptr) {
+  std::vector<std::array<float, 3> > minima_crds, maxima_crds;
+  std::vector<float> minima_diameters, maxima_diameters, minima_scores, maxima_scores;
+  if (!pva_minima_crds) pva_minima_crds = &minima_crds;
+  if (!pva_maxima_crds) pva_maxima_crds = &maxima_crds;
+  if (!pv_minima_diameters) pv_minima_diameters = &minima_diameters;
+  if (!pv_maxima_diameters) pv_maxima_diameters = &maxima_diameters;
+  if (!pv_minima_scores) pv_minima_scores = &minima_scores;
+  if (!pv_maxima_scores) pv_maxima_scores = &maxima_scores;
+  const float default_aspect_ratio[3] = {1.0f, 1.0f, 1.0f};
+  BlobDogD(image_size, aaafSource, aaafMask, blob_diameters, pva_minima_crds, pva_maxima_crds, pv_minima_diameters,
+           pv_maxima_diameters, pv_minima_scores, pv_maxima_scores, aspect_ratio ? aspect_ratio : default_aspect_ratio,
+           delta_sigma_over_sigma, truncate_ratio, minima_threshold, maxima_threshold, use_threshold_ratios,
+           pReportProgress, aaaafI);
+  const bool discard_overlapping_blobs =
+      (sep_ratio_thresh > 0.0f) || (nonmax_max_overlap_small < 1.0f) || (nonmax_max_overlap_large < 1.0f);
+  if (!discard_overlapping_blobs) return;
+  if (pReportProgress)
+    *pReportProgress << "----------- Removing overlapping blobs -----------\n" << std::endl
+                     << "--- Discarding overlapping minima blobs ---\n";
+  DiscardOverlappingBlobs(*pva_minima_crds, *pv_minima_diameters, *pv_minima_scores, sep_ratio_thresh,
+                          nonmax_max_overlap_large, nonmax_max_overlap_small, SORT_INCREASING, pReportProgress);
+  if (pReportProgress) *pReportProgress << "done --\n" << "--- Discarding overlapping maxima blobs ---\n";
+  DiscardOverlappingBlobs(*pva_maxima_crds, *pv_maxima_diameters, *pv_maxima_scores, sep_ratio_thresh,
+                          nonmax_max_overlap_large, nonmax_max_overlap_small, SORT_DECREASING, pReportProgress);
+}
+
+inline void _BlobDogNM(int const image_size[3], float const* const* const* aaafSource,
+                       float const* const* const* aaafMask, const std::vector<float>& blob_diameters,
+                       std::vector<std::array<float, 3> >* pva_minima_crds = nullptr,
+                       std::vector<std::array<float, 3> >* pva_maxima_crds = nullptr,
+                       std::vector<float>* pv_minima_diameters = nullptr,
+                       std::vector<float>* pv_maxima_diameters = nullptr,
+                       std::vector<float>* pv_minima_scores = nullptr, std::vector<float>* pv_maxima_scores = nullptr,
+                       const float aspect_ratio[3] = nullptr, float delta_sigma_over_sigma = 0.02,
+                       float filter_truncate_ratio = 2.5, float filter_truncate_threshold = 0.02,
+                       float minima_threshold = 0.0, float maxima_threshold = 0.0, bool use_threshold_ratios = true,
+                       float sep_ratio_thresh = 1.0, float nonmax_max_overlap_large = 1.0,
+                       float nonmax_max_overlap_small = 1.0, std::ostream* pReportProgress = nullptr,
+                       float**** aaaafI = nullptr) {
+  if (filter_truncate_ratio <= 0)   // exp(-ratio^2 / 2) = threshold, evaluated in double as the reference does (:543)
+    filter_truncate_ratio = (float)std::sqrt(-2 * std::log((double)filter_truncate_threshold));
+  BlobDogNM(image_size, aaafSource, aaafMask, blob_diameters, pva_minima_crds, pva_maxima_crds, pv_minima_diameters,
+            pv_maxima_diameters, pv_minima_scores, pv_maxima_scores, aspect_ratio, delta_sigma_over_sigma,
+            filter_truncate_ratio, minima_threshold, maxima_threshold, use_threshold_ratios, sep_ratio_thresh,
+            nonmax_max_overlap_large, nonmax_max_overlap_small, pReportProgress, aaaafI);
+}
+
 // ---- LabelConnected: lib/visfd/connect.hpp:47-65, :168-197 ------------------------------------------------
 // The form bin/filter_mrc/handlers.cpp:1985-2013 calls: Scalar = float, Label = ptrdiff_t, Coordinate = float,
 // directions as array<float,3>*** (contiguous, Alloc3D), tensors as one float* per voxel (nullptr = no storage,
@@ -602,18 +759,27 @@ class TV3D {
   void SetExponent(Scalar e) { exponent = (Integer)e; }
   void SetSigma(Scalar s, Scalar filter_cutoff_ratio = 2.5) { sigma = s; cutoff = filter_cutoff_ratio; }
 
-  // aaaafV: array<float,3>*** ; aaaafDest: float**** (pointer per voxel, nullptr = no storage).
+  // aaaafV: array<float,3>*** ; aaaafDest: float**** (pointer per voxel, nullptr = no storage, e.g.
+  // CompactMultiChannelImage3D::aaaafI).  The optional steps run on the host after the votes, AS THE REFERENCE
+  // EXECUTES THEM (feature.hpp:1784-1901), oddities included:
+  //   normalize (the reference's default; filter_mrc passes false, handlers.cpp:1832):
+  //     nothing happens without a destination mask (the loops skip every voxel when aaafMaskDest is null, :1793, :1848);
+  //     with a source mask every tensor entry is divided by the sum of the vote weights w * mask_src the voxel
+  //     received, where that sum is positive; without one the divisor is (Dx*Dy)*Dz, D = GenFilterGauss1D(sigma, h)
+  //     summed over the in-image taps (a different kernel than the votes), and because the loop runs over all nine
+  //     (di, dj) the off-diagonal entries are divided TWICE (:1854-1858);
+  //   diagonalize_dest: DiagonalizeHessianImage with DECREASING_EIVALS -- interior voxels 1..n-2 only (:1380-1386).
+  // A null saliency array is refused: the reference then reads saliencies it never initialised (:1748-1756).
   void TVDenseStick(Integer const image_size[3], Scalar const* const* const* aaafSaliency,
                     VectorContainer const* const* const* aaaafV, TensorContainer*** aaaafDest,
                     Scalar const* const* const* aaafMaskSource = nullptr,
                     Scalar const* const* const* aaafMaskDest = nullptr, bool detect_curves_not_surfaces = false,
                     bool normalize = true, bool diagonalize_dest = false, std::ostream* pReportProgress = nullptr) {
-    if (normalize || diagonalize_dest)
-      throw VisfdErr("visfd_hip: TVDenseStick supports normalize=false, diagonalize_dest=false "
-                     "(the form filter_mrc uses, handlers.cpp:1826-1836)");
     if (!aaafSaliency) throw VisfdErr("visfd_hip: TVDenseStick needs an explicit saliency array");
     int size[3] = {(int)image_size[0], (int)image_size[1], (int)image_size[2]};
     hip_detail::require_contiguous(aaafSaliency, size);
+    hip_detail::require_contiguous(aaafMaskSource, size);
+    hip_detail::require_contiguous(aaafMaskDest, size);
     const size_t n = (size_t)size[0] * size[1] * size[2];
     std::vector<float> ten(6 * n, 0.0f);
     const float* dir = reinterpret_cast<const float*>(&aaaafV[0][0][0]);
@@ -622,11 +788,61 @@ class TV3D {
                                                ten.data(), hip_detail::flat(aaafMaskSource),
                                                hip_detail::flat(aaafMaskDest), size[0], size[1], size[2], sigma,
                                                (int)exponent, cutoff, detect_curves_not_surfaces ? 1 : 0));
+    const float* mdst = hip_detail::flat(aaafMaskDest);
+    if (normalize && mdst) {
+      if (pReportProgress) *pReportProgress << "  Normalizing the result of tensor voting...";
+      if (aaafMaskSource) {
+        std::vector<float> den(n, 0.0f);
+        hip_detail::check(visfd_hip_tv_weight_sum(hip_detail::context(), hip_detail::flat(aaafSaliency), den.data(),
+                                                  hip_detail::flat(aaafMaskSource), mdst, size[0], size[1], size[2],
+                                                  sigma, cutoff));
+        for (size_t v = 0; v < n; v++)
+          if (mdst[v] != 0.0f && den[v] > 0.0f)
+            for (int c = 0; c < 6; c++) ten[6 * v + c] /= den[v];
+      } else {
+        int h = 0;
+        hip_detail::check(visfd_hip_tv_tables(sigma, cutoff, &h, nullptr, nullptr));
+        std::vector<float> taps(2 * (size_t)h + 1), D[3];
+        hip_detail::check(visfd_hip_gauss_taps(sigma, h, taps.data()));
+        for (int d = 0; d < 3; d++) {          // Filter1D::Apply on a line of ones (filter1d.hpp:47-104)
+          D[d].resize((size_t)size[d]);
+          for (int i = 0; i < size[d]; i++) {
+            float a = 0.0f;
+            for (int j = -h; j <= h; j++)
+              if (i - j >= 0 && i - j < size[d]) a += taps[(size_t)(j + h)] * 1.0f;
+            D[d][(size_t)i] = a;
+          }
+        }
+        size_t v = 0;
+        for (int iz = 0; iz < size[2]; iz++)
+          for (int iy = 0; iy < size[1]; iy++)
+            for (int ix = 0; ix < size[0]; ix++, v++) {
+              if (mdst[v] == 0.0f) continue;
+              const float denominator = (D[0][(size_t)ix] * D[1][(size_t)iy]) * D[2][(size_t)iz];
+              float* T = &ten[6 * v];
+              for (int c = 0; c < 3; c++) T[c] /= denominator;                            // (0,0), (1,1), (2,2)
+              for (int c = 3; c < 6; c++) { T[c] /= denominator; T[c] /= denominator; }   // (di,dj) and (dj,di)
+            }
+      }
+      if (pReportProgress) *pReportProgress << "done." << std::endl;
+    }
+    if (diagonalize_dest) {
+      if (pReportProgress) *pReportProgress << "---- Diagonalizing Tensor Voting results ----" << std::endl;
+      for (int iz = 1; iz < size[2] - 1; iz++)
+        for (int iy = 1; iy < size[1] - 1; iy++)
+          for (int ix = 1; ix < size[0] - 1; ix++) {
+            const size_t v = ((size_t)iz * size[1] + iy) * size[0] + ix;
+            if (mdst && mdst[v] == 0.0f) continue;
+            float d6[6];
+            hip_detail::check(visfd_hip_diagonalize_flat_sym3_host(&ten[6 * v], d6, 1, VISFD_HIP_DECREASING_EIVALS));
+            for (int c = 0; c < 6; c++) ten[6 * v + c] = d6[c];
+          }
+    }
     size_t v = 0;
     for (int iz = 0; iz < size[2]; iz++)
       for (int iy = 0; iy < size[1]; iy++)
         for (int ix = 0; ix < size[0]; ix++, v++)
-          if (aaaafDest[iz][iy][ix])
+          if (aaaafDest[iz][iy][ix] && !(mdst && mdst[v] == 0.0f))
             for (int c = 0; c < 6; c++) aaaafDest[iz][iy][ix][c] = ten[6 * v + c];
   }
 };

@@ -61,7 +61,7 @@ class CpuLib:
             "threshold_fraction": (C.c_float, [_fp, _fp, C.c_int64, C.c_float]),
             "tv_tables": (C.c_int, [C.c_float, C.c_float, _fp, _fp, C.c_int]),
             "tv_dense_stick": (None, [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
-                                      C.c_float, C.c_int, C.c_int]),
+                                      C.c_float, C.c_int, C.c_int, C.c_int]),
             "tensor_saliency": (None, [_fp, _fp, C.c_int64, C.c_int, _fp]),
             "local_fluctuations": (None, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, C.c_float, C.c_float, C.c_int]),
             "bin_array3d": (C.c_int, [_fp, _ip, _fp, _ip, _ip]),
@@ -212,11 +212,12 @@ class CpuLib:
         return h, w, r
 
     def tv_dense_stick(self, sal, dirs, sigma_tv, exponent=4, cutoff=2.0 ** 0.5, mask_src=None, mask_dst=None,
-                       curves=False, normalize=False):
+                       curves=False, normalize=False, diagonalize=False):
         nz, ny, nx = sal.shape
         tensor = np.zeros((nz, ny, nx, 6), np.float32)
         self._fn["tv_dense_stick"](_f(sal), _f(dirs), _f(tensor), _f(mask_src), _f(mask_dst), nx, ny, nz,
-                                   float(sigma_tv), int(exponent), float(cutoff), int(curves), int(normalize))
+                                   float(sigma_tv), int(exponent), float(cutoff), int(curves), int(normalize),
+                                   int(diagonalize))
         return tensor
 
     def tensor_saliency(self, tensor, order, sal_inout, mask=None):

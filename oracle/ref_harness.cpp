@@ -212,7 +212,7 @@ void vr_hessian_saliency(const float* hess, const float* mask, int64_t n, int or
 void vr_tv_dense_stick(const float* saliency, const float* dir, float* tensor,
                        const float* mask_src, const float* mask_dst, int nx, int ny, int nz,
                        float sigma_tv, int exponent, float cutoff_ratio, int curves,
-                       int normalize) {
+                       int normalize, int diagonalize) {
   int size[3] = {nx, ny, nz};
   size_t n = (size_t)nx * ny * nz;
   View3<float> s(const_cast<float*>(saliency), nx, ny, nz),
@@ -224,7 +224,7 @@ void vr_tv_dense_stick(const float* saliency, const float* dir, float* tensor,
   View3<float*> t(tp.data(), nx, ny, nz);
   TV3D<float, int, array<float, 3>, float*> tv(sigma_tv, exponent, cutoff_ratio);
   tv.TVDenseStick(size, (cf3)s.p, (array<float, 3> const* const* const*)v.p, t.p, (cf3)ms.p,
-                  (cf3)md.p, curves != 0, normalize != 0, false, nullptr);
+                  (cf3)md.p, curves != 0, normalize != 0, diagonalize != 0, nullptr);
 }
 
 // filter3d.hpp:546 radial table as TV3D::Resize builds it (feature.hpp:2419-2428), plus the

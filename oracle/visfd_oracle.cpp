@@ -768,13 +768,20 @@ int vo_tv_tables(float sigma_tv, float cutoff_ratio, float* w, float* rhat, int 
   return h;
 }
 
-// A.10  lib/visfd/feature.hpp:1914-2037 and :2217-2384.  normalize is not restated (off the
-// CLI path): callers must pass normalize=0.
+// A.10  lib/visfd/feature.hpp:1914-2037 and :2217-2384; normalize / diagonalize: the public wrapper, :1761-1901, as the
+// reference EXECUTES it (off the CLI path, handlers.cpp:1832-1835 passes false, false):
+//   normalize with a source mask: each tensor entry /= sum of the vote weights, where that sum is > 0 -- but only at
+//     voxels with mask_dst != 0, and NOT AT ALL without a destination mask (the loop `continue`s on !aaafMaskDest, :1793);
+//   normalize without a source mask: again only with a destination mask (:1848); the divisor is the product of three 1-D
+//     Gaussian (GenFilterGauss1D(sigma_tv, h), NOT the vote weights) sums over the in-image taps, (Dx*Dy)*Dz, and the loop
+//     runs over all nine (di, dj): diagonal entries are divided once, off-diagonal entries TWICE (:1854-1858);
+//   diagonalize: DiagonalizeHessianImage (:1367-1471) with DECREASING_EIVALS, interior voxels 1..n-2 only, mask_dst != 0.
 void vo_tv_dense_stick(const float* saliency, const float* dir, float* tensor,
                        const float* mask_src, const float* mask_dst, int nx, int ny, int nz,
                        float sigma_tv, int exponent, float cutoff_ratio, int curves,
-                       int normalize) {
-  (void)normalize;
+                       int normalize, int diagonalize) {
+  std::vector<float> den;
+  if (normalize && mask_src) den.assign((size_t)nx * ny * nz, 0.0f);
   int h = tv_halfwidth(sigma_tv, cutoff_ratio);
   int nw = 2 * h + 1;
   std::vector<float> w((size_t)nw * nw * nw), rh((size_t)3 * nw * nw * nw);
@@ -786,6 +793,7 @@ void vo_tv_dense_stick(const float* saliency, const float* dir, float* tensor,
         i64 c = vox(ix, iy, iz, nx, ny);
         if (mask_dst && mask_dst[c] == 0.0f) continue;
         float T[6] = {0, 0, 0, 0, 0, 0};
+        float denominator = 0.0f;
         for (int jz = -h; jz <= h; jz++) {
           i64 sz = iz - jz;
           if (sz < 0 || sz >= nz) continue;
@@ -826,11 +834,50 @@ void vo_tv_dense_stick(const float* saliency, const float* dir, float* tensor,
               T[1] += (base * m[1]) * m[1];
               T[4] += (base * m[1]) * m[2];
               T[2] += (base * m[2]) * m[2];
+              denominator += fv;      // feature.hpp:2376-2377
             }
           }
         }
         for (int d = 0; d < 6; d++) tensor[6 * c + d] = T[d];
+        if (!den.empty()) den[c] = denominator;
       }
+  if (normalize && mask_dst) {
+    if (mask_src) {
+      for (i64 c = 0; c < (i64)nx * ny * nz; c++)
+        if (mask_dst[c] != 0.0f && den[c] > 0.0f)
+          for (int d = 0; d < 6; d++) tensor[6 * c + d] /= den[c];
+    } else {
+      std::vector<float> t(nw);
+      gauss_taps(sigma_tv, h, t.data());
+      std::vector<float> D[3];
+      const int dims[3] = {nx, ny, nz};
+      for (int d = 0; d < 3; d++) {
+        std::vector<float> ones((size_t)dims[d], 1.0f);
+        D[d].resize(dims[d]);
+        conv_line_plain(dims[d], ones.data(), 1, D[d].data(), 1, t.data(), h);   // Filter1D::Apply on a line of ones
+      }
+      for (i64 iz = 0; iz < nz; iz++)
+        for (i64 iy = 0; iy < ny; iy++)
+          for (i64 ix = 0; ix < nx; ix++) {
+            i64 c = vox(ix, iy, iz, nx, ny);
+            if (mask_dst[c] == 0.0f) continue;
+            const float denominator = (D[0][ix] * D[1][iy]) * D[2][iz];
+            float* T = tensor + 6 * c;
+            for (int d = 0; d < 3; d++) T[d] /= denominator;                              // (0,0), (1,1), (2,2)
+            for (int d = 3; d < 6; d++) { T[d] /= denominator; T[d] /= denominator; }   // (di,dj) and (dj,di)
+          }
+    }
+  }
+  if (diagonalize)
+    for (i64 iz = 1; iz < nz - 1; iz++)
+      for (i64 iy = 1; iy < ny - 1; iy++)
+        for (i64 ix = 1; ix < nx - 1; ix++) {
+          i64 c = vox(ix, iy, iz, nx, ny);
+          if (mask_dst && mask_dst[c] == 0.0f) continue;
+          float d6[6];
+          diagonalize_flat(tensor + 6 * c, d6, 1 /* DECREASING_EIVALS */);
+          for (int d = 0; d < 6; d++) tensor[6 * c + d] = d6[d];
+        }
 }
 
 // A.11  bin/filter_mrc/handlers.cpp:1870-1892 with lib/visfd/feature.hpp:1591-1598

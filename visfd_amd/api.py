@@ -95,6 +95,7 @@ _SIGS = {
     "visfd_hip_tv_dense_stick_slab_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
                                                     C.c_float, C.c_int, C.c_float, C.c_int]),
     "visfd_hip_tv_tables": (C.c_int, [C.c_float, C.c_float, _ip, _fp, _fp]),
+    "visfd_hip_tv_weight_sum": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, C.c_float, C.c_float]),
     "visfd_hip_membrane_detect": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, C.c_float, C.c_float, C.c_int, C.c_float,
                                             C.c_float, C.c_float, C.c_int, C.c_float, _vp, _vp, _vp, _fp]),
     "visfd_hip_membrane_detect_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, C.c_float, C.c_float, C.c_int,
@@ -546,6 +547,14 @@ class Context:
                                                    _np(mask_dst), nx, ny, nz, float(sigma_tv), int(exponent),
                                                    float(cutoff), int(curves)))
         return tensor
+
+    def tv_weight_sum(self, sal, sigma_tv, cutoff=2.0 ** 0.5, mask_src=None, mask_dst=None):
+        """The normalisation denominators of TVDenseStick(normalize=true) (feature.hpp:1761-1822); zeros where mask_dst == 0."""
+        nz, ny, nx = sal.shape
+        den = np.zeros_like(sal)
+        self._chk(self._L.visfd_hip_tv_weight_sum(self._h, _np(sal), _np(den), _np(mask_src), _np(mask_dst), nx, ny, nz,
+                                                  float(sigma_tv), float(cutoff)))
+        return den
 
     def tensor_saliency(self, tensor, order, sal_inout, mask=None):
         self._chk(self._L.visfd_hip_tensor_saliency(self._h, _np(tensor), _np(mask), sal_inout.size, int(order),

@@ -840,6 +840,24 @@ int visfd_hip_tv_dense_stick(visfd_hip_ctx* ctx, const float* sal, const float* 
   return download(ctx, ten, aos6, 6 * n);
 }
 
+// TVDenseStick's normalisation denominators (feature.hpp:1761-1822): den[voxel] = sum of w(j) * mask_src(sender) over
+// the votes the voxel receives; voxels with mask_dst == 0 keep the caller's value
+int visfd_hip_tv_weight_sum(visfd_hip_ctx* ctx, const float* sal, float* den, const float* mask_src, const float* mask_dst,
+                            int64_t nx, int64_t ny, int64_t nz, float sigma_tv, float cutoff) {
+  VH_REQUIRE(ctx && sal && den, "null argument");
+  VH_HIP(hipSetDevice(ctx->device));
+  VH_TRY(check_dims(nx, ny, nz));
+  const size_t n = (size_t)(nx * ny * nz);
+  float *dsal, *dden, *dms = nullptr, *dmd = nullptr;
+  VH_TRY(upload(ctx, WS_H2D_0, sal, n, &dsal));
+  VH_TRY(upload(ctx, WS_H2D_1, den, n, &dden));
+  VH_TRY(upload(ctx, WS_H2D_4, mask_src, n, &dms));
+  if (mask_dst == mask_src) dmd = dms;
+  else VH_TRY(upload(ctx, WS_A, mask_dst, n, &dmd));
+  VH_TRY(dev_tv_weight_sum(ctx, dsal, dden, dms, dmd, nx, ny, nz, sigma_tv, cutoff));
+  return download(ctx, den, dden, n);
+}
+
 // ---- HandleTV compute section ------------------------------------------------------------------
 int visfd_hip_membrane_detect_dev(visfd_hip_ctx* ctx, const float* src, const float* mask, int64_t nx,
                                   int64_t ny, int64_t nz, float sigma, float ratio, int order,

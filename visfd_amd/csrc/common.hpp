@@ -172,6 +172,9 @@ int dev_tv_dense_stick(visfd_hip_ctx* ctx, const float* sal, const float* dir_pl
                        i64 ny, i64 nz, i64 z_out0, i64 z_out1, float sigma_tv, int exponent,
                        float cutoff, bool curves);
 
+int dev_tv_weight_sum(visfd_hip_ctx* ctx, const float* sal, float* den, const float* mask_src, const float* mask_dst, i64 nx,
+                      i64 ny, i64 nz, float sigma_tv, float cutoff);
+
 // resample.hip (sizes are {nx, ny, nz}; offset nullable)
 int dev_bin_array3d(visfd_hip_ctx* ctx, const float* src, const int64_t size_src[3], float* dst,
                     const int64_t size_dst[3], const int* offset);

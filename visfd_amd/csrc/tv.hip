@@ -121,7 +121,7 @@ tv_dense_kernel(const float* __restrict__ sal, const float* __restrict__ dir,
 // declared in tv_tiled.hip
 int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* ten,
                  const float* mask_src, const float* mask_dst, i64 nx, i64 ny, i64 nz, i64 z_out0,
-                 i64 z_out1, int h, const float4* dtab, int exponent, bool curves, bool* handled);
+                 i64 z_out1, int h, const float4* dtab, int exponent, bool curves, bool weights_only, bool* handled);
 
 // The vote table of (sigma_tv, cutoff) on the device: float4 {w, rhat_x, rhat_y, rhat_z} per offset j in z, y, x order
 // (filter3d.hpp:563-578, feature.hpp:2470-2478).  Built on the host once and kept in the context: a launch with the same
@@ -167,7 +167,7 @@ int dev_tv_dense_stick(visfd_hip_ctx* ctx, const float* sal, const float* dir, f
   bool handled = false;
   if (!ctx->opt.tv_dense)
     VH_TRY(dev_tv_tiled(ctx, sal, dir, ten, mask_src, mask_dst, nx, ny, nz, z_out0, z_out1, h, dtab, exponent, curves,
-                        &handled));
+                        false, &handled));
   if (handled) return VISFD_HIP_OK;
 
   hipStream_t st = ctx->stream;
@@ -179,6 +179,22 @@ int dev_tv_dense_stick(visfd_hip_ctx* ctx, const float* sal, const float* dir, f
   if (nb > 0x7fffffffLL) return fail(VISFD_HIP_EINVAL, "volume too large for one launch");
   tv_dense_kernel<<<dim3((unsigned)nb), dim3(BLOCK), 0, st>>>(sal, dir, ten, mask_src, mask_dst, dtab, p);
   VH_HIP(hipGetLastError());
+  return VISFD_HIP_OK;
+}
+
+// The sum of the weights of the votes every receiver takes (one plane-sized volume): the "denominator" TVDenseStick
+// accumulates for its normalisation (feature.hpp:1761-1822, 2376-2382) -- w(j) * mask_src(sender) over the in-bounds
+// senders with non-zero saliency, source mask and weight, added in vote order.
+int dev_tv_weight_sum(visfd_hip_ctx* ctx, const float* sal, float* den, const float* mask_src, const float* mask_dst, i64 nx,
+                      i64 ny, i64 nz, float sigma_tv, float cutoff) {
+  VH_TRY(check_dims(nx, ny, nz));
+  const int h = host_tv_halfwidth(sigma_tv, cutoff);
+  VH_REQUIRE(h >= 1 && h <= 40, "tensor-voting window halfwidth out of range for the weight sums");
+  const float4* dtab = nullptr;
+  VH_TRY(tv_table_device(ctx, sigma_tv, cutoff, h, &dtab));
+  bool handled = false;
+  VH_TRY(dev_tv_tiled(ctx, sal, nullptr, den, mask_src, mask_dst, nx, ny, nz, 0, nz, h, dtab, 4, false, true, &handled));
+  if (!handled) return fail(VISFD_HIP_EINVAL, "volume shape not supported by the weight-sum kernel");
   return VISFD_HIP_OK;
 }
 

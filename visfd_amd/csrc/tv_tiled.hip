@@ -1,35 +1,35 @@
 // tv_tiled.hip -- LDS-tiled dense stick tensor voting for gfx950
 // (reference lib/visfd/feature.hpp:1914-2037 and :2217-2384).
 //
-// The reference walks, for every receiver voxel, the whole (2h+1)^3 window and skips senders whose
-// saliency is zero (typically 95 % of them, feature.hpp:1704-1709).  Here the skipping is done
-// once per workgroup instead of once per receiver:
+// The reference walks, for every receiver voxel, the whole (2h+1)^3 window and skips senders whose saliency is zero
+// (typically 95 % of them, feature.hpp:1704-1709).  Here the skipping is done once per workgroup instead of once per
+// receiver:
 //
-//   * workgroups are PERSISTENT: as many as the chip holds, each claiming units of work -- a 16 x 16 tile of
-//     receivers (one per thread; each wave an 8 x 8 patch) over a run of 32 consecutive receiver planes -- from
-//     a global counter until it is exhausted (a plain grid left wave slots empty on volumes whose sender
-//     density varies, see the kernel);
-//   * for a receiver plane z, sender planes are visited from z+h down to z-h (= jz ascending), in groups of up
-//     to G planes whose signed (2h+1)^2 table slices fit in LDS.  The salient, unmasked senders of the
-//     (16+2h)^2 region of a plane -- distance-test operand, saliency, normal, table offset, mask value -- are
-//     appended to an LDS list IN VOTE ORDER (ordered block-wide prefix sum: deterministic).  A plane is read
-//     from the volume and compacted only the first time the run meets it; its list then lives in a
-//     per-workgroup scratch ring in global memory and is replayed for the next 2h receiver planes;
-//   * when the list is full (or the group ends) it is flushed.  Phase A: every lane tests all
-//     listed senders against its own receiver -- sender operands from uniform-address LDS reads,
-//     jx^2+jy^2+jz^2 <= h^2 as ONE v_dot4_i32_i8 on signed bytes (see the kernel), an exact superset
-//     of the table's spherical support -- and writes one 32-bit hit word per 32 senders to its
-//     private LDS column.  Phase B: every lane walks ITS OWN hit words in order and accumulates the
-//     votes in a counted, branch-free, software-pipelined loop, so lanes spend their time on real
-//     votes instead of idling under a sparse exec mask;
-//   * weights and unit displacements come from LDS copies of the (2h+1)^2 table slices of the
-//     group's planes (w, rhat_x, rhat_y, rhat_z as one float4, signs included).  Because the table
-//     index is linear in the offset j = receiver - sender, the byte address of a vote's table entry
-//     is  R(lane) - E(sender):  one subtraction per vote, E precomputed when the sender is listed.
+//   * workgroups are PERSISTENT: as many as the chip holds, each claiming units of work -- a 16 x 16 tile of receivers
+//     (one per thread; each wave an 8 x 8 patch) over a run of 32 consecutive receiver planes -- from a global counter
+//     until it is exhausted (a plain grid left wave slots empty on volumes whose sender density varies, see the kernel);
+//   * for a receiver plane z, sender planes are visited from z+h down to z-h (= jz ascending).  The salient, unmasked
+//     senders of the (16+2h)^2 region of a plane -- saliency, normal, distance-test operand, table offset, mask value --
+//     are listed in LDS IN VOTE ORDER (ordered block-wide prefix sum: deterministic).  A plane is read from the volume
+//     and compacted only the first time the run meets it; its list then lives in a per-workgroup scratch ring in global
+//     memory and is replayed for the next 2h receiver planes;
+//   * the SWEEP: every wave walks the list in order.  A sender is tested against the wave's 64 receivers --
+//     jx^2+jy^2+jz^2 <= h^2 as ONE v_dot4_i32_i8 on signed bytes (see the kernel), an exact superset of the table's
+//     spherical support -- and voted at once by the lanes it reaches, under their execution mask.  The sender's data
+//     come from uniform-address (broadcast) LDS reads: no bank conflicts, no per-lane bookkeeping;
+//   * weights and unit displacements come from the LDS copy of the (2h+1)^2 table slice of the sender plane (w, rhat_x,
+//     rhat_y, rhat_z as one float4, signs included).  The table index is linear in j = receiver - sender, so the byte
+//     address of a vote's table entry is  R(lane) - E(sender):  one subtraction per vote.
 //
-// Order of accumulation per receiver: jz ascending (plane order), then jy, jx ascending, exactly
-// the reference's; each vote is the same chain of float multiplies and adds (no FMA), so tensors
-// are bit-identical to the CPU path for angular exponents 2 and 4.
+// Order of accumulation per receiver: jz ascending (plane order), then jy, jx ascending, exactly the reference's; each
+// vote is the same chain of float multiplies and adds (no FMA), so tensors are bit-identical to the CPU path for
+// angular exponents 2 and 4.  A tap of zero weight on the rim of the support votes +-0, which leaves the sums unchanged.
+//
+// Why a sweep and not per-lane hit lists (round 1): measured on MI355X (profiles/r02_tv_design.txt), the per-lane scheme
+// spent 46 VALU instructions per vote slot (a third of them v_ffbl/v_lshl_add/v_cmp and friends, which issue at half
+// rate on gfx950) on slots that were 64-70 % full, and its random 32-byte entry gathers made LDS bank conflicts a
+// quarter of all CU cycles; the sweep spends 35 per voted sender at 45 % lane use but needs 20 KB of LDS and 64 VGPRs,
+// i.e. eight workgroups per CU instead of four, and that occupancy is what the VALU needs to stay busy here.
 #include <vector>
 
 #include "common.hpp"
@@ -38,12 +38,6 @@ namespace vh {
 
 namespace {
 
-// VH_TV_SWEEP=1: the flush tests a listed sender against the wave's 64 receivers and votes it at once under the
-// resulting execution mask (sender data from uniform-address LDS reads); 0: the round-1 scheme (per-lane hit words,
-// every lane walks its own hits).
-#ifndef VH_TV_SWEEP
-#define VH_TV_SWEEP 1
-#endif
 constexpr int NT = 256;
 constexpr int TILE = 16;
 constexpr int VPT = 7;               // region voxels per thread per band
@@ -52,20 +46,9 @@ constexpr int BAND_CAP = NT * VPT;   // 1792 region voxels per band
 #define VH_TV_CAP 256
 #endif
 constexpr int CAP = VH_TV_CAP;       // list entries held in LDS between flushes
-constexpr int NWORDS = CAP / 32;
-constexpr int ENT_BYTES = 32;        // LDS bytes per list entry
-static_assert(NT * 4 == 32 * ENT_BYTES, "one hit-word row spans as many bytes as 32 list entries");
-constexpr unsigned SENT_BIT = 1u << NWORDS;   // sentinel "word" NWORDS: its only entry is the dummy entry CAP
-constexpr int SENT_WB = NWORDS << 10;
-static_assert(NWORDS < 31, "hit-word mask is 32 bits");
-#ifndef VH_TV_SLICE_KB
-#define VH_TV_SLICE_KB 21
-#endif
-#ifndef VH_TV_MAX_GROUP
-#define VH_TV_MAX_GROUP 4
-#endif
-constexpr int SLICE_BYTES = VH_TV_SLICE_KB * 1024;  // LDS budget for the table slices of one plane group
-constexpr int MAX_GROUP = VH_TV_MAX_GROUP;   // more planes per group lengthen the lists but cost LDS (occupancy)
+constexpr int RING_BYTES = 32;       // bytes per entry of the scratch rings
+constexpr int MAX_GROUP = 4;         // sender planes whose slices may share LDS (default 1, option tv_group)
+constexpr int SLICE_BYTES_MAX = 48 * 1024;
 constexpr unsigned OOB = 0x7ffffff0u;  // byte offset beyond any plane descriptor: reads give 0
 
 __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
@@ -73,10 +56,6 @@ __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rs, unsigned by
 }
 
 typedef float f4v __attribute__((ext_vector_type(4)));
-
-#ifdef VH_TV_STATS   // development build only (tools/build_variant.py): phase-B utilisation counters
-__device__ unsigned long long g_tv_stats[8];
-#endif
 
 // LDS (address space 3) pointers as 32-bit integers and back
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
@@ -90,11 +69,10 @@ __device__ __forceinline__ const __attribute__((address_space(3))) T* lds_ptr(un
 struct TiledParams {
   int nx, ny, nz;
   int z_out0, z_out1;    // receiver planes [z_out0, z_out1)
-  int h, hp1;            // halfwidth, h+1
+  int h;                 // window halfwidth
   int rw, rh;            // region width/height = TILE + 2h
   int band_rows, nbands;
   int group;             // planes per group (slices resident in LDS)
-  int slice_f4;          // float4 entries of the LDS slice area
   int tiles_x, tiles_y;
   int exponent, curves;
   int zrun;              // receiver planes per unit of work
@@ -105,9 +83,8 @@ __device__ __forceinline__ void acc(float& t, float x) {
 }
 
 // MODE 0: surfaces with angular exponent 4 (the CLI default, settings.cpp:154); MODE 2: surfaces with exponent 2;
-// MODE 1: general (any exponent through pow, curve mode).
-// The vote of one (sender, receiver) pair in two halves, so that the vote loop can put LDS reads
-// between them: vote_dir gives the magnitude and the voted direction, vote_acc adds the outer product.
+// MODE 1: general (any exponent through pow, curve mode); MODE 3: no tensor at all -- the sum of the vote weights
+// ("denominator" of feature.hpp:2376-2377) into channel 0.
 template <int MODE>
 __device__ __forceinline__ void vote_dir(float sal, float fv, float r0, float r1, float r2, float n0, float n1,
                                          float n2, int exponent, int curves, float& bse, float& m0, float& m1,
@@ -133,7 +110,7 @@ __device__ __forceinline__ void vote_dir(float sal, float fv, float r0, float r1
 
 __device__ __forceinline__ void vote_acc(float T[6], float bse, float m0, float m1, float m2) {
   const float b0 = bse * m0, b1 = bse * m1, b2 = bse * m2;
-  // accumulate in place (tied operands keep the six sums in fixed registers across the vote loop;
+  // accumulate in place (tied operands keep the six sums in fixed registers across the sweep;
   // v_add_f32 is the same IEEE add the compiler emits for "+")
   acc(T[0], b0 * m0);
   acc(T[3], b0 * m1);
@@ -143,66 +120,35 @@ __device__ __forceinline__ void vote_acc(float T[6], float bse, float m0, float 
   acc(T[2], b2 * m2);
 }
 
-// magnitude m (>= 0) with the sign of the integer j; j == 0 keeps +m (rhat components are +0.0 there)
-__device__ __forceinline__ float with_sign_of(float m, int j) {
-  return __uint_as_float(__float_as_uint(m) | ((unsigned)j & 0x80000000u));
-}
-
-template <bool MASKED_SRC, int MODE>
 #ifndef VH_TV_WAVES
 #define VH_TV_WAVES 8
 #endif
-#if VH_TV_SWEEP
+
+template <bool MASKED_SRC, int MODE>
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MODE != 1 ? VH_TV_WAVES : 2, 8)))
-#else
-__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MODE != 1 ? 4 : 2, 4)))
-#endif
 tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, float* __restrict__ ten,
                 const float* __restrict__ mask_src, const float* __restrict__ mask_dst,
                 const float4* __restrict__ table /* [(2h+1)^3] : w, rhat_x, rhat_y, rhat_z at j */,
                 TiledParams p, unsigned* __restrict__ tile_counter, unsigned ntiles,
                 unsigned char* __restrict__ scratch /* per-workgroup rings of compacted sender planes, or null */) {
   // Static LDS (compile-time addresses fold into the DS instructions' immediate offsets):
-  // list entry e (32 bytes): float4 {sal, n0, n1, n2} | int e16 | float mask value | pad.
-  // Entry CAP is a permanent dummy (zero saliency and normal): lanes that have run out of hits vote
-  // it, which adds +-0 to their accumulators and leaves them bit-for-bit unchanged.
-  // (one static block with the entry list first: its LDS address is then 0 and drops out of the vote loop's
-  // address arithmetic)
-#if VH_TV_SWEEP
-  constexpr int OFF_POS = ENT_BYTES * (CAP + 1), OFF_HITW = OFF_POS + 8 * (CAP + 8), OFF_TOT = OFF_HITW;
-#else
-  constexpr int OFF_POS = ENT_BYTES * (CAP + 1), OFF_HITW = OFF_POS + 4 * CAP, OFF_TOT = OFF_HITW + 4 * (NWORDS + 1) * NT;
-#endif
-  constexpr int OFF_TILE = OFF_TOT + 2 * (NT / 64) * 4;
-  constexpr int OFF_PCNT = OFF_TILE + 16;       // entries per cached sender plane, [2h+1] ints (h <= 40)
-  __shared__ __attribute__((aligned(16))) unsigned char lds_static[OFF_PCNT + 4 * 84];
-  unsigned char* l_ent = lds_static;
-  // distance-test operand of the listed senders (see phase A): packed signed bytes
-  // (e'x, e'y, -(|e'|^2 >> 7), |e'|^2 & 127) with e' = sender position relative to the tile centre
-  unsigned* l_pos = reinterpret_cast<unsigned*>(lds_static + OFF_POS);
-  unsigned char* hitw = lds_static + OFF_HITW;                                    // [NWORDS + sentinel][NT]
-  int (*wave_tot)[NT / 64] = reinterpret_cast<int (*)[NT / 64]>(lds_static + OFF_TOT);
-  unsigned* claimed_tile = reinterpret_cast<unsigned*>(lds_static + OFF_TILE);
-  int* plane_cnt = reinterpret_cast<int*>(lds_static + OFF_PCNT);
+  //   l_ent[e]  float4 {sal, n0, n1, n2} of list entry e
+  //   l_pos[e]  {distance-test operand, table offset E}: packed signed bytes (e'x, e'y, -(|e'|^2 >> 7), |e'|^2 & 127)
+  //             with e' = sender position relative to the tile centre and the plane of the receivers; 8 entries of
+  //             slack past the list hold a never-hit operand, so the sweep runs in whole batches of four and may
+  //             prefetch one batch past the end
+  //   l_mv[e]   source-mask value of the entry (masked kernels)
+  __shared__ __attribute__((aligned(16))) float4 l_ent[CAP];
+  __shared__ __attribute__((aligned(16))) uint2 l_pos[CAP + 8];
+  __shared__ float l_mv[MASKED_SRC ? CAP : 1];
+  __shared__ int wave_tot[2][NT / 64];
+  __shared__ unsigned claimed_tile;
+  __shared__ int plane_cnt[84];              // entries per cached sender plane, [2h+1] (h <= 40)
   // dynamic LDS: the table slices of the current plane group, [group][(2h+1)^2] float4
   extern __shared__ __attribute__((aligned(16))) unsigned char slices[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-
-  // ---- once per workgroup: dummy entry, sentinel row, zero-filled slice area -------------------------------
-  // dummy entry: zero saliency/normal; its table address R16 - E16 = 16*((ly+h)*S + lx+h) stays inside
-  // the slice area (sized for it by the host), which is zero-filled once so that it is always finite
-  if (tid == 0) {
-    unsigned char* ent = l_ent + ENT_BYTES * CAP;
-    *reinterpret_cast<float4*>(ent) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    *reinterpret_cast<int*>(ent + 16) = 16 * (p.h * (2 * p.h + 1) + p.h);
-    *reinterpret_cast<float*>(ent + 20) = 0.0f;
-  }
-#if !VH_TV_SWEEP
-  *reinterpret_cast<unsigned*>(hitw + SENT_WB + (tid << 2)) = 1u;   // sentinel row
-#endif
-  for (int i = tid; i < p.slice_f4; i += NT) reinterpret_cast<float4*>(slices)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 
   // ---- persistent workgroups: tiles are claimed from a global counter ---------------------------------------
   // The time a tile takes follows the local density of senders (membranes: tens of times the average), and the
@@ -211,9 +157,9 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
   // noise: 47.5 and 100 %).  Here the grid is just large enough to fill the chip and every workgroup keeps
   // claiming the next tile until the counter passes the last one -- an exit every wave reaches.
   for (;;) {
-  if (tid == 0) *claimed_tile = atomicAdd(tile_counter, 1u);
-  __syncthreads();   // also: the previous tile's flushes are complete, the one-time initialisation is visible
-  unsigned b = *claimed_tile;
+  if (tid == 0) claimed_tile = atomicAdd(tile_counter, 1u);
+  __syncthreads();   // also: the previous tile's sweeps are complete
+  unsigned b = claimed_tile;
   __syncthreads();   // everyone has read it before thread 0 claims again
   if (b >= ntiles) break;
   const int tile_x = b % p.tiles_x;
@@ -245,14 +191,11 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
   const int rpx = lx - 8, rpy = ly - 8;
   const unsigned recv4 = (unsigned)((-2 * rpx) & 0xff) | ((unsigned)((-2 * rpy) & 0xff) << 8) | (0x80u << 16) | (1u << 24);
   const int recv_c = rpx * rpx + rpy * rpy - h2 - 1;
+  constexpr unsigned NEVER_HIT = 0x009c0000u;   // operand whose dot product is positive for every receiver (-128 * -100)
 
   // (jy+h)*S + (jx+h) with jx = lx+h-ex, jy = ly+h-ey  =  [(ly+2h)*S + lx+2h] - [ey*S + ex]
-  const int r16 = 16 * ((ly + 2 * h) * S + lx + 2 * h);
-
-  // LDS addresses as integers (see phase B)
+  const unsigned r16s = lds_addr(slices) + (unsigned)(16 * ((ly + 2 * h) * S + lx + 2 * h));
   const unsigned ent_base = lds_addr(l_ent);
-  const unsigned hitw_lane = lds_addr(hitw) + ((unsigned)tid << 2);
-  const unsigned r16s = lds_addr(slices) + (unsigned)r16;
 
   float T[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 
@@ -293,33 +236,31 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
     }
   };
 
-#if VH_TV_SWEEP
-  // ---- flush: every wave sweeps the list entries [0, n) in vote order; a sender is tested against the wave's 64
-  // receivers (one v_dot4_i32_i8, see above) and voted at once by the lanes it reaches, under their execution mask.
-  // Sender data (saliency, normal, table offset) come from uniform-address LDS reads, the table entry of
-  // j = receiver - sender from the lane's own address R - E.  Receivers that take no votes never hit: their
-  // accumulator operand is a large positive number.  The pos words of up to three entries past the end of the list
-  // hold a never-hit pattern (written with the list), so the sweep runs in whole batches of four.
-  auto flush = [&](int n, int ez_first) {
-    (void)ez_first;
+  // ---- the sweep over list entries [0, n), in vote order ----------------------------------------------------
+  // Receivers that take no votes never hit: their accumulator operand is a large positive number.
+  auto sweep = [&](int n) {
     const int recv_c_live = r_live ? recv_c : 0x100000;
-    // the table entry is requested with the sender's own data: its address needs only e16, which comes with the batch
+    // the table entry is requested together with the sender's own data: its address needs only E, which came with
+    // the batch
     auto vote_one = [&](int s, unsigned e16) {
-      const unsigned ent = ent_base + ((unsigned)s << 5);
       const f4v tw = *lds_ptr<f4v>(r16s - e16);
-      const f4v d = *lds_ptr<f4v>(ent);
       float fv = tw.x;
-      if (MASKED_SRC) fv = fv * *lds_ptr<float>(ent + 20);
-      float bse, m0, m1, m2;
-      vote_dir<MODE>(d.x, fv, tw.y, tw.z, tw.w, d.y, d.z, d.w, p.exponent, p.curves, bse, m0, m1, m2);
-      vote_acc(T, bse, m0, m1, m2);
+      if (MASKED_SRC) fv = fv * l_mv[s];    // fv = w * mask value first (feature.hpp:2262-2275), then sal * fv
+      if (MODE == 3) {
+        acc(T[0], fv);                      // "denominator += filter_val" (feature.hpp:2376-2377)
+      } else {
+        const f4v d = *lds_ptr<f4v>(ent_base + ((unsigned)s << 4));
+        float bse, m0, m1, m2;
+        vote_dir<MODE>(d.x, fv, tw.y, tw.z, tw.w, d.y, d.z, d.w, p.exponent, p.curves, bse, m0, m1, m2);
+        vote_acc(T, bse, m0, m1, m2);
+      }
     };
-    // batches of four senders: {pos, e16} pairs; the next batch is in flight while this one is tested and voted
+    // batches of four senders; the next batch is in flight while this one is tested and voted
     const uint4* pq = reinterpret_cast<const uint4*>(l_pos);
     uint4 qa = pq[0], qb = pq[1];
     for (int s0 = 0; s0 < n; s0 += 4) {   // uniform
       const uint4 ca = qa, cb = qb;
-      qa = pq[(s0 >> 1) + 2];             // (at most 8 entries past the list: inside the array)
+      qa = pq[(s0 >> 1) + 2];
       qb = pq[(s0 >> 1) + 3];
       int d0, d1, d2, d3;
       // four dots back to back: a dot result may be read by the VALU three instructions later at the earliest, and
@@ -336,132 +277,7 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
       if (d3 < 0) vote_one(s0 + 3, cb.w);
     }
   };
-#else
-  // ---- flush: phase A (tests) + phase B (votes) over list entries [0, n) in vote order ---------
-  // slot_of_plane0: region-relative z (ez) of the group's first plane; slice slot = ez_first - ez
-  auto flush = [&](int n, int ez_first) {
-    const int nwords = (n + 31) >> 5;
-    // phase A: one hit word per 32 listed senders; nz collects which words are non-empty.  Sender
-    // positions come four at a time from uniform-address (broadcast) LDS reads.
-    unsigned nz = SENT_BIT;
-    unsigned nhits = 0u;
-    for (int w = 0; w < nwords; w++) {
-      const uint4* pp = reinterpret_cast<const uint4*>(l_pos + (w << 5));
-      unsigned bits = 0u;
-#pragma unroll
-      for (int k4 = 7; k4 >= 0; k4--) {
-        const uint4 q = pp[k4];
-        // d = |r-e|^2 - h^2 - 1 < 0 <=> hit; bits = bits << 1 | sign(d).  A dot result may be read by
-        // the VALU three instructions later at the earliest: four dots back to back, then the
-        // shift-in chain in the same order, keep exactly that distance (the compiler does not
-        // see hazards of instructions inside an asm block).
-        unsigned d0, d1, d2, d3;
-        asm("v_dot4_i32_i8 %1, %5, %7, %6\n\t"
-            "v_dot4_i32_i8 %2, %5, %8, %6\n\t"
-            "v_dot4_i32_i8 %3, %5, %9, %6\n\t"
-            "v_dot4_i32_i8 %4, %5, %10, %6\n\t"
-            "v_alignbit_b32 %0, %0, %1, 31\n\t"
-            "v_alignbit_b32 %0, %0, %2, 31\n\t"
-            "v_alignbit_b32 %0, %0, %3, 31\n\t"
-            "v_alignbit_b32 %0, %0, %4, 31"
-            : "+v"(bits), "=&v"(d3), "=&v"(d2), "=&v"(d1), "=&v"(d0)
-            : "v"(recv4), "v"(recv_c), "v"(q.w), "v"(q.z), "v"(q.y), "v"(q.x));
-      }
-      const int valid = n - (w << 5);
-      if (valid < 32) bits &= (1u << valid) - 1u;
-      if (!r_live) bits = 0u;
-      *reinterpret_cast<unsigned*>(hitw + (w << 10) + (tid << 2)) = bits;
-      nz |= (bits != 0u ? 1u : 0u) << w;
-      nhits += (unsigned)__builtin_popcount(bits);
-    }
-    // phase B: every lane walks its own hit words (its LDS column is private: no barrier needed).
-    // The loop is wave-uniform -- it runs as many times as the busiest lane has hits -- and there is no divergent
-    // control flow around the vote: a lane that has run out of hits keeps refilling from the
-    // sentinel word (row NWORDS, value 1), i.e. keeps voting the dummy entry CAP.
-    // LDS addresses are formed as integers so that the (link-time) base of the dynamic segment is
-    // folded into per-lane constants instead of being re-added on every vote.
-    unsigned cur = 0u;
-    unsigned wbe = 0u;    // LDS address of the current word's first list entry (= ent_base + 1024 * word)
-    auto refill = [&]() {
-      if (cur == 0u) {                         // next non-empty word, or the sentinel
-        const unsigned wb = (unsigned)__builtin_ctz(nz) << 10;
-        nz = (nz & (nz - 1u)) | SENT_BIT;
-        cur = *lds_ptr<unsigned>(hitw_lane + wb);
-        wbe = ent_base + wb;
-      }
-    };
-    auto next_ent = [&]() -> unsigned {       // LDS address of the lane's next hit entry (cur != 0 after refill)
-      const unsigned ent = ((unsigned)__builtin_ctz(cur) << 5) + wbe;
-      cur &= cur - 1u;
-      return ent;
-    };
-    unsigned mx = nhits;                    // hits of the busiest lane of the wave
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, d));
-    const int niter = __builtin_amdgcn_readfirstlane((int)mx);
-#ifdef VH_TV_STATS
-    {
-      unsigned sum = nhits;
-      for (int d = 32; d >= 1; d >>= 1) sum += (unsigned)__shfl_xor((int)sum, d);
-      if (lane == 0) {
-        atomicAdd(&g_tv_stats[0], (unsigned long long)niter * 64ull);   // lane-iterations of phase B
-        atomicAdd(&g_tv_stats[1], (unsigned long long)sum);             // real votes
-        atomicAdd(&g_tv_stats[2], (unsigned long long)n * 64ull);       // distance tests
-        atomicAdd(&g_tv_stats[3], 1ull);                                // wave-flushes
-        atomicMax(&g_tv_stats[4], (unsigned long long)niter);
-      }
-    }
-#endif
-    // Software pipeline, unrolled twice (A/B): while vote i is computed, the entry of vote i+1 is
-    // being read, and its table entry is requested half-way through.
-    f4v dA, dB, twA, twB;
-    int eA, eB;
-    float mvA = 1.0f, mvB = 1.0f;
-    auto read_entry = [&](unsigned ent, f4v& d, int& e16, float& mv) {
-      d = *lds_ptr<f4v>(ent);
-      e16 = *lds_ptr<int>(ent + 16);
-      if (MASKED_SRC) mv = *lds_ptr<float>(ent + 20);
-    };
-    // table entry of j = receiver - sender in the sender's plane slice: address R16 - E16
-    auto read_table = [&](int e16) -> f4v { return *lds_ptr<f4v>(r16s - (unsigned)e16); };
-    // A zero weight (taps on the rim of the spherical support, feature.hpp:2276) needs no branch: the
-    // vote is then (+-0)*m*m and adding +-0 leaves the accumulators bit-for-bit unchanged.
-    auto half1 = [&](const f4v& d, const f4v& tw, float mv, float& bse, float& m0, float& m1, float& m2) {
-      float fv = tw.x;
-      if (MASKED_SRC) fv = fv * mv;
-      vote_dir<MODE>(d.x, fv, tw.y, tw.z, tw.w, d.y, d.z, d.w, p.exponent, p.curves, bse, m0, m1, m2);
-    };
-    refill();
-    read_entry(next_ent(), dA, eA, mvA);
-    refill();
-    twA = read_table(eA);
-    const int npairs = niter >> 1;   // an odd count ends with the single vote after the loop (the pair loop's
-                                     // prefetches beyond the last hit read the dummy entry: harmless)
-    for (int it = 0; it < npairs; it++) {
-      float bse, m0, m1, m2;
-      read_entry(next_ent(), dB, eB, mvB);
-      refill();
-      half1(dA, twA, mvA, bse, m0, m1, m2);
-      __builtin_amdgcn_sched_barrier(0);   // keep the table request between the two halves
-      twB = read_table(eB);
-      __builtin_amdgcn_sched_barrier(0);
-      vote_acc(T, bse, m0, m1, m2);
-      read_entry(next_ent(), dA, eA, mvA);
-      refill();
-      half1(dB, twB, mvB, bse, m0, m1, m2);
-      __builtin_amdgcn_sched_barrier(0);
-      twA = read_table(eA);
-      __builtin_amdgcn_sched_barrier(0);
-      vote_acc(T, bse, m0, m1, m2);
-    }
-    if (niter & 1) {   // uniform
-      float bse, m0, m1, m2;
-      half1(dA, twA, mvA, bse, m0, m1, m2);
-      vote_acc(T, bse, m0, m1, m2);
-    }
-  };
 
-#endif
   // ---- the unit's receiver planes, bottom up --------------------------------------------------------------
   // Consecutive receiver planes share 2h of their 2h+1 sender planes.  The compacted sender list of a plane
   // (entries in vote order) is therefore written to a per-workgroup scratch ring in global memory when the plane
@@ -470,7 +286,7 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
   // scratch entry (32 bytes): float4 {sal, n0, n1, n2} | ex + 256 ey | mask value | pad.  Ring slot of plane
   // sz: sz mod (2h+1); cached planes: [cached_lo, cached_hi].
   const int P = 2 * h + 1;
-  const size_t plane_stride = (size_t)p.rw * p.rh * ENT_BYTES;
+  const size_t plane_stride = (size_t)p.rw * p.rh * RING_BYTES;
   unsigned char* const ring = scratch ? scratch + (size_t)blockIdx.x * plane_stride * P : nullptr;
   int cached_lo = 1, cached_hi = 0;     // empty
   int npar = 0;                         // parity of the wave-total buffers
@@ -484,21 +300,29 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
 
   int n_list = 0;         // entries currently in the LDS list
   int ez_first = 0;       // region-relative z of the first plane of the current group
-  constexpr unsigned NEVER_HIT = 0x009c0000u;   // pos word whose dot product is positive for every receiver
-  auto flush_full = [&]() {
-#if VH_TV_SWEEP
-    if (tid < 8) l_pos[2 * (n_list + tid)] = NEVER_HIT;
-#endif
+  // list entry `slot`: sender at region position (ex, ey) of the plane at offset epz from the receivers' plane, table
+  // slice slot e16_plane / nsl of the group
+  auto put_entry = [&](int slot, const float4& a, int ex, int ey, int epz, int e16_plane, unsigned mv) {
+    l_ent[slot] = a;
+    const int epx = ex - h - 8, epy = ey - h - 8;
+    const int e2 = epx * epx + epy * epy + epz * epz;
+    const unsigned posw = (unsigned)(epx & 0xff) | ((unsigned)(epy & 0xff) << 8) | ((unsigned)((-(e2 >> 7)) & 0xff) << 16) |
+                          ((unsigned)(e2 & 127) << 24);
+    l_pos[slot] = make_uint2(posw, (unsigned)(16 * (ey * S + ex - e16_plane)));
+    if (MASKED_SRC) l_mv[slot] = __uint_as_float(mv);
+  };
+  auto flush = [&]() {
+    if (tid < 8) l_pos[n_list + tid] = make_uint2(NEVER_HIT, 0u);
     __syncthreads();   // list complete
-    flush(n_list, ez_first);
+    if (n_list > 0) sweep(n_list);
     n_list = 0;
-    __syncthreads();   // everyone done reading before the list is refilled
+    __syncthreads();   // everyone done reading before the list (or the slices) are refilled
   };
   for (int pl = 0; pl < nplanes; pl++) {                    // plane counter, 0 = z+h side
     const int sz = sz_hi - pl;
     const int ez = sz - (rz - h);                           // 0..2h
     if (pl % p.group == 0) {
-      // previous group completely flushed (n_list == 0, barrier at the end of the flush block below):
+      // previous group completely swept (n_list == 0, barrier at the end of flush):
       // copy the table slices of this group's planes (plane s of the group: ez = ez_first - s, jz = h - ez)
       ez_first = ez;
       const int g_planes = min(p.group, nplanes - pl);
@@ -520,28 +344,14 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
       while (done < cnt) {   // uniform
         const int take = min(CAP - n_list, cnt - done);
         for (int i = tid; i < take; i += NT) {
-          const unsigned char* src_e = ring_plane + (size_t)(done + i) * ENT_BYTES;
+          const unsigned char* src_e = ring_plane + (size_t)(done + i) * RING_BYTES;
           const float4 a = *reinterpret_cast<const float4*>(src_e);
           const uint2 m = *reinterpret_cast<const uint2*>(src_e + 16);
-          const int slot = n_list + i;
-          unsigned char* ent = l_ent + ENT_BYTES * slot;
-          *reinterpret_cast<float4*>(ent) = a;
-          const int ex = (int)(m.x & 0xffu), ey = (int)(m.x >> 8);
-          const int epx = ex - h - 8, epy = ey - h - 8;
-          const int e2 = epx * epx + epy * epy + epz * epz;
-          const unsigned posw = (unsigned)(epx & 0xff) | ((unsigned)(epy & 0xff) << 8) | ((unsigned)((-(e2 >> 7)) & 0xff) << 16) |
-                                ((unsigned)(e2 & 127) << 24);
-#if VH_TV_SWEEP
-          *reinterpret_cast<uint2*>(l_pos + 2 * slot) = make_uint2(posw, (unsigned)(16 * (ey * S + ex - e16_plane)));
-#else
-          l_pos[slot] = posw;
-          *reinterpret_cast<int*>(ent + 16) = 16 * (ey * S + ex - e16_plane);
-#endif
-          if (MASKED_SRC) *reinterpret_cast<unsigned*>(ent + 20) = m.y;
+          put_entry(n_list + i, a, (int)(m.x & 0xffu), (int)(m.x >> 8), epz, e16_plane, m.y);
         }
         n_list += take;
         done += take;
-        if (n_list == CAP) flush_full();
+        if (n_list == CAP) flush();
       }
     } else {
       // ---- read the plane from the volume: ordered compaction of its salient senders, band by band -------
@@ -586,28 +396,14 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
             if (cur[v] != 0.0f) {
               if (q >= done && q < done + take) {
                 const unsigned off = voff_of(v, row0, rows);
-                const int slot = n_list + (q - done);
-                unsigned char* ent = l_ent + ENT_BYTES * slot;
-                const float4 a = make_float4(cur[v], buf_load(rd0, off), buf_load(rd1, off), buf_load(rd2, off));
-                *reinterpret_cast<float4*>(ent) = a;
+                float4 a = make_float4(cur[v], 0.0f, 0.0f, 0.0f);
+                if (MODE != 3) { a.y = buf_load(rd0, off); a.z = buf_load(rd1, off); a.w = buf_load(rd2, off); }
                 const int ex = rc_[v] & 0xff, ey = row0 + (rc_[v] >> 8);
-                const int epx = ex - h - 8, epy = ey - h - 8;
-                const int e2 = epx * epx + epy * epy + epz * epz;
-                const unsigned posw = (unsigned)(epx & 0xff) | ((unsigned)(epy & 0xff) << 8) | ((unsigned)((-(e2 >> 7)) & 0xff) << 16) |
-                                      ((unsigned)(e2 & 127) << 24);
-#if VH_TV_SWEEP
-                *reinterpret_cast<uint2*>(l_pos + 2 * slot) = make_uint2(posw, (unsigned)(16 * (ey * S + ex - e16_plane)));
-#else
-                l_pos[slot] = posw;
-                *reinterpret_cast<int*>(ent + 16) = 16 * (ey * S + ex - e16_plane);
-#endif
                 unsigned mv = 0u;
-                if (MASKED_SRC) {
-                  mv = __float_as_uint(buf_load(plane_rsrc(mask_src, sz), off));
-                  *reinterpret_cast<unsigned*>(ent + 20) = mv;
-                }
+                if (MASKED_SRC) mv = __float_as_uint(buf_load(plane_rsrc(mask_src, sz), off));
+                put_entry(n_list + (q - done), a, ex, ey, epz, e16_plane, mv);
                 if (ring_plane) {
-                  unsigned char* dst_e = ring_plane + (size_t)(plane_fill + q) * ENT_BYTES;
+                  unsigned char* dst_e = ring_plane + (size_t)(plane_fill + q) * RING_BYTES;
                   *reinterpret_cast<float4*>(dst_e) = a;
                   *reinterpret_cast<uint2*>(dst_e + 16) = make_uint2((unsigned)ex | ((unsigned)ey << 8), mv);
                 }
@@ -617,7 +413,7 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
           }
           n_list += take;
           done += take;
-          if (n_list == CAP) flush_full();
+          if (n_list == CAP) flush();
         }
         plane_fill += len;
       }
@@ -630,21 +426,17 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
         if (cached_hi - cached_lo + 1 > P) cached_lo = cached_hi - P + 1;   // the slot of the oldest plane was reused
       }
     }
-    // end of group (or of all planes): flush what is left
-    if (((pl + 1) % p.group == 0) || (pl + 1 == nplanes)) {
-#if VH_TV_SWEEP
-      if (tid < 8) l_pos[2 * (n_list + tid)] = NEVER_HIT;
-#endif
-      __syncthreads();
-      if (n_list > 0) flush(n_list, ez_first);
-      n_list = 0;
-      __syncthreads();     // list and slices free for the next group
-    }
+    // end of group (or of all planes): sweep what is left; list and slices are free afterwards
+    if (((pl + 1) % p.group == 0) || (pl + 1 == nplanes)) flush();
   }
 
   if (r_live) {
+    if (MODE == 3) {
+      ten[rc] = T[0];
+    } else {
 #pragma unroll
-    for (int k = 0; k < 6; k++) ten[k * nvox + rc] = T[k];
+      for (int k = 0; k < 6; k++) ten[k * nvox + rc] = T[k];
+    }
   }
   }   // next receiver plane of the run
   }   // next tile
@@ -652,32 +444,31 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
 
 }  // namespace
 
+// dtab: the vote table on the device (tv.hip: tv_table_device).  weights_only: ten receives ONE plane, the sum of the
+// weights of the votes each receiver takes (the normalisation denominator of feature.hpp:1784-1822) instead of tensors.
 int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* ten,
                  const float* mask_src, const float* mask_dst, i64 nx, i64 ny, i64 nz, i64 z_out0,
-                 i64 z_out1, int h, const float4* dtab /* device: w, rhat_x, rhat_y, rhat_z per offset */, int exponent,
-                 bool curves, bool* handled) {
+                 i64 z_out1, int h, const float4* dtab, int exponent, bool curves, bool weights_only, bool* handled) {
   *handled = false;
   if (h < 1 || h > 40) return VISFD_HIP_OK;  // table slices in LDS + byte-packed coordinates limits
   if (nx * ny >= (1LL << 29)) return VISFD_HIP_OK;  // plane descriptors are 32-bit
-  const int hp1 = h + 1, n = 2 * h + 1;
+  const int n = 2 * h + 1;
   hipStream_t st = ctx->stream;
 
   TiledParams p;
   p.nx = (int)nx; p.ny = (int)ny; p.nz = (int)nz;
   p.z_out0 = (int)z_out0; p.z_out1 = (int)z_out1;
-  p.h = h; p.hp1 = hp1;
+  p.h = h;
   p.rw = TILE + 2 * h; p.rh = TILE + 2 * h;
   p.band_rows = BAND_CAP / p.rw;
   if (p.band_rows > p.rh) p.band_rows = p.rh;
   p.nbands = (p.rh + p.band_rows - 1) / p.band_rows;
-  const int slice_bytes = (int)sizeof(float4) * n * n;
-  p.group = SLICE_BYTES / slice_bytes;
-  if (p.group > MAX_GROUP) p.group = MAX_GROUP;
-  if (p.group < 1) p.group = 1;
-#if VH_TV_SWEEP
-  p.group = 1;   // the sweep gains nothing from longer lists; one slice leaves LDS for eight workgroups per CU
-#endif
-  if (ctx->opt.tv_group >= 1 && ctx->opt.tv_group <= MAX_GROUP && (size_t)ctx->opt.tv_group * slice_bytes <= (size_t)SLICE_BYTES) p.group = ctx->opt.tv_group;
+  const size_t slice_bytes = sizeof(float4) * (size_t)n * n;
+  // one sender plane per sweep: the sweep gains nothing from longer lists, and one slice leaves LDS for eight
+  // workgroups per CU (measured at 1024^3: 953 ms with two planes and five workgroups, 803 ms with one and eight)
+  p.group = 1;
+  if (ctx->opt.tv_group >= 1 && ctx->opt.tv_group <= MAX_GROUP && (size_t)ctx->opt.tv_group * slice_bytes <= (size_t)SLICE_BYTES_MAX)
+    p.group = ctx->opt.tv_group;
   p.tiles_x = (int)((nx + TILE - 1) / TILE);
   p.tiles_y = (int)((ny + TILE - 1) / TILE);
   p.exponent = exponent;
@@ -690,37 +481,27 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
   const i64 nruns = (z_out1 - z_out0 + p.zrun - 1) / p.zrun;
   const i64 nblk = (i64)p.tiles_x * p.tiles_y * nruns;
   if (nblk > 0x7fffffffLL) return fail(VISFD_HIP_EINVAL, "volume too large for one launch");
-  // slice area: the group's slices, and at least the span the dummy entry's table reads can touch
-  size_t slice_f4 = (size_t)p.group * n * n;
-  const size_t dummy_span = (size_t)(TILE - 1 + h) * n + (TILE - 1 + h) + 1;
-  if (slice_f4 < dummy_span) slice_f4 = dummy_span;
-  p.slice_f4 = (int)slice_f4;
-  const size_t lds = sizeof(float4) * slice_f4;   // dynamic part
-#if VH_TV_SWEEP
-  const size_t lds_static = (size_t)ENT_BYTES * (CAP + 1) + (size_t)8 * (CAP + 8) + 64 + 16 + 4 * 84;
-  const size_t max_wg = 8;
-#else
-  const size_t lds_static = (size_t)ENT_BYTES * (CAP + 1) + (size_t)4 * CAP + (size_t)4 * (NWORDS + 1) * NT + 64 + 16 + 4 * 84;
-  const size_t max_wg = 4;
-#endif
+  const size_t lds = (size_t)p.group * slice_bytes;   // dynamic part
+  const size_t lds_static = sizeof(float4) * CAP + sizeof(uint2) * (CAP + 8) + sizeof(float) * (mask_src ? CAP : 1) + 512;
   if (lds + lds_static > 150 * 1024) return VISFD_HIP_OK;   // window too wide for the LDS slices: baseline kernel
-  const int mode = curves ? 1 : (exponent == 4 ? 0 : (exponent == 2 ? 2 : 1));
+  const int mode = weights_only ? 3 : (curves ? 1 : (exponent == 4 ? 0 : (exponent == 2 ? 2 : 1)));
   // persistent workgroups (see the kernel): as many as the chip holds at once -- LDS allows 160 KB / (static +
-  // dynamic) per CU, registers four waves per SIMD = 4 workgroups -- each claiming tiles from a counter
+  // dynamic) per CU, registers eight waves per SIMD = 8 workgroups -- each claiming tiles from a counter
   unsigned* counter = nullptr;
   VH_TRY(ws(ctx, WS_COUNTER, 16, &counter));
   VH_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned), st));
   size_t wg_per_cu = (160 * 1024) / (lds + lds_static);
+  const size_t max_wg = mode == 1 ? 2 : 8;
   if (wg_per_cu > max_wg) wg_per_cu = max_wg;
   if (wg_per_cu < 1) wg_per_cu = 1;
   i64 ngrid = (i64)ctx->num_cus * (i64)wg_per_cu;
   if (ctx->opt.tv_max_wg > 0 && ngrid > ctx->opt.tv_max_wg) ngrid = ctx->opt.tv_max_wg;   // tests: many units per workgroup
   if (ngrid > nblk) ngrid = nblk;
-  // scratch rings: (2h+1) planes x (TILE+2h)^2 entries of 32 bytes per workgroup (1.3 GB for h = 12 on 256 CUs);
+  // scratch rings: (2h+1) planes x (TILE+2h)^2 entries of 32 bytes per workgroup (2.6 GB for h = 12 on 256 CUs);
   // beyond 16 GB (very wide windows) the kernel runs without them and compacts every plane from the volume
   unsigned char* scratch = nullptr;
   {
-    const size_t per_wg = (size_t)n * p.rw * p.rh * ENT_BYTES;
+    const size_t per_wg = (size_t)n * p.rw * p.rh * RING_BYTES;
     const size_t total = per_wg * (size_t)ngrid;
     if (total <= ((size_t)16 << 30) && p.zrun > 1 && !ctx->opt.tv_no_replay) {
       // the kernel also runs without rings (it then compacts every plane from the volume): out of memory is not an error
@@ -735,22 +516,15 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
                                                                           mask_dst, dtab, p, counter, \
                                                                           (unsigned)nblk, scratch);  \
   } while (0)
-  if (mask_src) { if (mode == 0) VH_TV_LAUNCH(true, 0); else if (mode == 2) VH_TV_LAUNCH(true, 2); else VH_TV_LAUNCH(true, 1); }
-  else          { if (mode == 0) VH_TV_LAUNCH(false, 0); else if (mode == 2) VH_TV_LAUNCH(false, 2); else VH_TV_LAUNCH(false, 1); }
+  if (mask_src) {
+    if (mode == 0) VH_TV_LAUNCH(true, 0); else if (mode == 2) VH_TV_LAUNCH(true, 2); else if (mode == 3) VH_TV_LAUNCH(true, 3);
+    else VH_TV_LAUNCH(true, 1);
+  } else {
+    if (mode == 0) VH_TV_LAUNCH(false, 0); else if (mode == 2) VH_TV_LAUNCH(false, 2); else if (mode == 3) VH_TV_LAUNCH(false, 3);
+    else VH_TV_LAUNCH(false, 1);
+  }
 #undef VH_TV_LAUNCH
   VH_HIP(hipGetLastError());
-#ifdef VH_TV_STATS
-  {
-    unsigned long long st8[8];
-    VH_HIP(hipStreamSynchronize(st));
-    VH_HIP(hipMemcpyFromSymbol(st8, HIP_SYMBOL(g_tv_stats), sizeof(st8)));
-    fprintf(stderr, "[tv stats] lane-iterations %llu votes %llu (util %.3f) tests %llu wave-flushes %llu max-iter %llu; cross-wave util %.3f\n",
-            st8[0], st8[1], st8[0] ? (double)st8[1] / (double)st8[0] : 0.0, st8[2], st8[3], st8[4],
-            st8[5] ? (double)st8[6] / (double)st8[5] : 0.0);
-    unsigned long long z8[8] = {};
-    VH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tv_stats), z8, sizeof(z8)));
-  }
-#endif
   *handled = true;
   return VISFD_HIP_OK;
 }
