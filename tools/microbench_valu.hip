@@ -65,7 +65,8 @@ typedef float v2 __attribute__((ext_vector_type(2)));
 enum Mode { MUL, ADD, FMA, MULADD, MUL_E64, PKMUL, PKFMA, MUL_SGPR, CHAIN1, CHAIN2, CHAIN4, DOT4, INT_AND,
             MUL_F64, FMA_F64, ADD_F64, VOTE_LDS,
             MUL_INLINE, MUL_LITERAL, ADD_SGPR, MUL_SGPR_E64, FMAC, DOT4_ONLY, ALIGNBIT_ONLY, FFBL, LSHL_ADD, CMP_VCC, CNDMASK,
-            SUB_INLINE, MOV_DPP, ADD_DPP, MAD_U24, ADD_U32, BPERMUTE, SWIZZLE, PERM, BFE, MAX3, READFIRSTLANE, PKADD, NMODES };
+            SUB_INLINE, MOV_DPP, ADD_DPP, MAD_U24, ADD_U32, BPERMUTE, SWIZZLE, PERM, BFE, MAX3, READFIRSTLANE, PKADD,
+            BANK_SAME, BANK_DIFF, BANK_MIX, NMODES };
 static const char* mode_name[NMODES] = {
     "v_mul_f32 (16 independent)", "v_add_f32 (16 independent)", "v_fma_f32 (16 independent)", "v_mul_f32/v_add_f32 alternating",
     "v_mul_f32_e64 (VOP3 encoding)", "v_pk_mul_f32 (2 lanes-ops each)", "v_pk_fma_f32 (2 fma each)", "v_mul_f32 SGPR operand",
@@ -75,16 +76,18 @@ static const char* mode_name[NMODES] = {
     "v_mul_f32 inline constant 2.0", "v_mul_f32 32-bit literal", "v_add_f32 SGPR operand", "v_mul_f32_e64 SGPR operand", "v_fmac_f32 (VOP2 fma)",
     "v_dot4_i32_i8", "v_alignbit_b32", "v_ffbl_b32", "v_lshl_add_u32", "v_cmp_eq_u32 -> vcc", "v_cndmask_b32 (vcc)",
     "v_sub_f32 inline constant 1.0", "v_mov_b32_dpp row_shr:1", "v_add_f32_dpp quad_perm", "v_mad_u32_u24", "v_add_u32", "ds_bpermute_b32",
-    "ds_swizzle_b32", "v_perm_b32", "v_bfe_u32", "v_max3_f32", "v_readfirstlane_b32", "v_pk_add_f32 (2 lane-ops each)"};
+    "ds_swizzle_b32", "v_perm_b32", "v_bfe_u32", "v_max3_f32", "v_readfirstlane_b32", "v_pk_add_f32 (2 lane-ops each)",
+    "v_add_f32 vD, vA, vB: A, B, D all = 0 mod 4", "v_add_f32 vD, vA, vB: A, B, D in three banks (mod 4)",
+    "v_mul/v_add pairs, sources A = 0, B = 1 mod 4, 2 mod 4 dest"};
 // lane-operations per instruction (packed = 2) and instructions per loop trip
-static const int mode_ops[NMODES] = {1, 1, 1, 1, 1, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,  1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2};
+static const int mode_ops[NMODES] = {1, 1, 1, 1, 1, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,  1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1};
 static const int mode_inst[NMODES] = {256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 128, 128, 128, 280,
-                                      256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256};
+                                      256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256};
 
 struct Stamp { unsigned long long c0, c1, r0, r1; unsigned hwid, pad; };
 
 template <int MODE>
-__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) k(float* out, Stamp* stamps, int iters, float a, float b) {
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 8))) k(float* out, Stamp* stamps, int iters, float a, float b) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
   float x8 = x0 + 8, x9 = x0 + 9, x10 = x0 + 10, x11 = x0 + 11, x12 = x0 + 12, x13 = x0 + 13, x14 = x0 + 14, x15 = x0 + 15;
@@ -212,6 +215,9 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)
     GEN(BFE, OP_BFE, "v"(a), "v"(b))
     GEN(MAX3, OP_MAX3, "v"(a), "v"(b))
     GEN(READFIRSTLANE, OP_READLANE, "v"(a), "v"(b))
+    else if (MODE == BANK_SAME) { _Pragma("unroll") for (int u = 0; u < 16; u++) asm volatile("v_add_f32 v16, v48, v68\n v_add_f32 v20, v52, v72\n v_add_f32 v24, v56, v76\n v_add_f32 v28, v60, v64\n v_add_f32 v32, v48, v68\n v_add_f32 v36, v52, v72\n v_add_f32 v40, v56, v76\n v_add_f32 v44, v60, v64\n v_add_f32 v16, v48, v68\n v_add_f32 v20, v52, v72\n v_add_f32 v24, v56, v76\n v_add_f32 v28, v60, v64\n v_add_f32 v32, v48, v68\n v_add_f32 v36, v52, v72\n v_add_f32 v40, v56, v76\n v_add_f32 v44, v60, v64" ::: "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83"); }
+    else if (MODE == BANK_DIFF) { _Pragma("unroll") for (int u = 0; u < 16; u++) asm volatile("v_add_f32 v16, v49, v70\n v_add_f32 v20, v53, v74\n v_add_f32 v24, v57, v78\n v_add_f32 v28, v61, v66\n v_add_f32 v32, v49, v70\n v_add_f32 v36, v53, v74\n v_add_f32 v40, v57, v78\n v_add_f32 v44, v61, v66\n v_add_f32 v16, v49, v70\n v_add_f32 v20, v53, v74\n v_add_f32 v24, v57, v78\n v_add_f32 v28, v61, v66\n v_add_f32 v32, v49, v70\n v_add_f32 v36, v53, v74\n v_add_f32 v40, v57, v78\n v_add_f32 v44, v61, v66" ::: "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83"); }
+    else if (MODE == BANK_MIX) { _Pragma("unroll") for (int u = 0; u < 16; u++) asm volatile("v_mul_f32 v18, v48, v69\n v_add_f32 v22, v52, v73\n v_mul_f32 v26, v56, v77\n v_add_f32 v30, v60, v65\n v_mul_f32 v34, v48, v69\n v_add_f32 v38, v52, v73\n v_mul_f32 v42, v56, v77\n v_add_f32 v46, v60, v65\n v_mul_f32 v18, v48, v69\n v_add_f32 v22, v52, v73\n v_mul_f32 v26, v56, v77\n v_add_f32 v30, v60, v65\n v_mul_f32 v34, v48, v69\n v_add_f32 v38, v52, v73\n v_mul_f32 v42, v56, v77\n v_add_f32 v46, v60, v65" ::: "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83"); }
     else if (MODE == PKADD) { _Pragma("unroll") for (int u = 0; u < 16; u++) asm volatile(R16(OP_PKADD) : P16 : "v"(ab), "v"(ab)); }
     else if (MODE == BPERMUTE) { _Pragma("unroll") for (int u = 0; u < 16; u++) { asm volatile(R16(OP_BPERM) : X16 : "v"(laddr), "v"(b)); asm volatile("s_waitcnt lgkmcnt(0)" : X16); } }
     else if (MODE == SWIZZLE) { _Pragma("unroll") for (int u = 0; u < 16; u++) { asm volatile(R16(OP_SWIZ) : X16 : "v"(laddr), "v"(b)); asm volatile("s_waitcnt lgkmcnt(0)" : X16); } }
@@ -303,7 +309,7 @@ int main(int argc, char** argv) {
                         k<CHAIN4>, k<DOT4>, k<INT_AND>, k<MUL_F64>, k<FMA_F64>, k<ADD_F64>, k<VOTE_LDS>,
                         k<MUL_INLINE>, k<MUL_LITERAL>, k<ADD_SGPR>, k<MUL_SGPR_E64>, k<FMAC>, k<DOT4_ONLY>, k<ALIGNBIT_ONLY>, k<FFBL>,
                         k<LSHL_ADD>, k<CMP_VCC>, k<CNDMASK>, k<SUB_INLINE>, k<MOV_DPP>, k<ADD_DPP>, k<MAD_U24>, k<ADD_U32>, k<BPERMUTE>,
-                        k<SWIZZLE>, k<PERM>, k<BFE>, k<MAX3>, k<READFIRSTLANE>, k<PKADD>};
+                        k<SWIZZLE>, k<PERM>, k<BFE>, k<MAX3>, k<READFIRSTLANE>, k<PKADD>, k<BANK_SAME>, k<BANK_DIFF>, k<BANK_MIX>};
   const int m0 = argc > 2 ? atoi(argv[2]) : 0;
   for (int m = m0; m < NMODES; m++)
     for (int w : {1, 2, 4, 8}) run(m, fns[m], w, num_cus, out, dstamps, f);
