@@ -221,7 +221,12 @@ int visfd_hip_discard_overlapping_blobs(float* crds, float* diameters, float* sc
  * handlers.cpp:1985-2013).  Per-cluster outputs (each nullable; cluster_capacity entries): seed position
  * x,y,z in final cluster order; sizes and seed saliencies in the provisional (seed-height) order -- the
  * reference only permutes the positions (connect.hpp:1294-1348).  Every dimension must be >= 3.
- * Not provided: must-link constraints, voxel weights. */
+ * The _ex form adds the reference's remaining optional arguments:
+ *   voxel_weights [nz][ny][nx] (nullable): a cluster's "size" is the sum of its voxels' weights (connect.hpp:1154-1183);
+ *   must-link constraints (connect.hpp:829-1045): n groups of locations (x,y,z, voxels; must_link_crds[total][3],
+ *   must_link_group_sizes[n]); the clusters of the clustered voxels nearest to consecutive locations of a group are
+ *   merged.  must_link_directions (nullable, one per location): 0 = the two surfaces face the same way, 1 = opposite,
+ *   2 = decide from the angles their normals make with the joining line (DirectionPairType). */
 int visfd_hip_label_connected(const float* saliency, int64_t* labels, const float* mask, int64_t nx, int64_t ny,
                               int64_t nz, float threshold_saliency, float* direction,
                               float threshold_vector_saliency, float threshold_vector_neighbor,
@@ -231,6 +236,18 @@ int visfd_hip_label_connected(const float* saliency, int64_t* labels, const floa
                               int64_t label_undefined, int sort_by_size, int standardize_directions,
                               int start_from_saliency_maxima, int64_t* n_clusters, float* cluster_maxima,
                               float* cluster_sizes, float* cluster_saliencies, int64_t cluster_capacity);
+int visfd_hip_label_connected_ex(const float* saliency, int64_t* labels, const float* mask, int64_t nx, int64_t ny,
+                              int64_t nz, float threshold_saliency, float* direction,
+                              float threshold_vector_saliency, float threshold_vector_neighbor,
+                              int consider_dot_product_sign, const float* tensor,
+                              float threshold_tensor_saliency, float threshold_tensor_neighbor,
+                              int tensor_is_positive_definite_near_target, int connectivity,
+                              int64_t label_undefined, int sort_by_size, int standardize_directions,
+                              int start_from_saliency_maxima, int64_t* n_clusters, float* cluster_maxima,
+                              float* cluster_sizes, float* cluster_saliencies, int64_t cluster_capacity,
+                                 const float* voxel_weights, const float* must_link_crds,
+                                 const int64_t* must_link_group_sizes, int64_t must_link_ngroups,
+                                 const int* must_link_directions);
 
 /* Principal eigenvector (eigenvector row 0 of ConvertFlatSym2Evects3 in the given order) of nvox flat tensors
  * [nvox][6] -> direction [nvox][3], computed on the HOST in the reference's arithmetic (the loop of

@@ -607,7 +607,7 @@ inline void _BlobDogNM(int const image_size[3], float const* const* const* aaafS
 // ---- LabelConnected: lib/visfd/connect.hpp:47-65, :168-197 ------------------------------------------------
 // The form bin/filter_mrc/handlers.cpp:1985-2013 calls: Scalar = float, Label = ptrdiff_t, Coordinate = float,
 // directions as array<float,3>*** (contiguous, Alloc3D), tensors as one float* per voxel (nullptr = no storage,
-// e.g. CompactMultiChannelImage3D::aaaafI).  Must-link constraints and voxel weights are not provided.
+// e.g. CompactMultiChannelImage3D::aaaafI).
 typedef enum eRegionSortCriteria { SORT_BY_VALUE, SORT_BY_SIZE } RegionSortCriteria;
 typedef enum eDirectionPairType { SAME_DIRECTION, OPPOSITE_DIRECTION, AUTO } DirectionPairType;
 
@@ -629,9 +629,24 @@ inline size_t LabelConnected(
     const std::vector<std::vector<DirectionPairType> >* pMustLinkDirections = nullptr,
     bool start_from_saliency_maxima = true, std::ostream* pReportProgress = nullptr) {
   static_assert(sizeof(ptrdiff_t) == sizeof(int64_t), "labels travel as 64-bit integers");
-  if (aaafVoxelWeights || pMustLinkConstraints || pMustLinkDirections)
-    throw VisfdErr("visfd_hip: LabelConnected does not provide voxel weights or must-link constraints");
   hip_detail::require_contiguous(aaafSaliency, image_size);
+  hip_detail::require_contiguous(aaafVoxelWeights, image_size);
+  // must-link constraints as the flat arrays of the C ABI (connect.hpp:829-1045)
+  std::vector<float> ml_crds;
+  std::vector<int64_t> ml_sizes;
+  std::vector<int> ml_dirs;
+  if (pMustLinkConstraints) {
+    for (size_t g = 0; g < pMustLinkConstraints->size(); g++) {
+      ml_sizes.push_back((int64_t)(*pMustLinkConstraints)[g].size());
+      for (size_t k = 0; k < (*pMustLinkConstraints)[g].size(); k++) {
+        for (int d = 0; d < 3; d++) ml_crds.push_back((*pMustLinkConstraints)[g][k][d]);
+        if (pMustLinkDirections) {
+          const DirectionPairType how = (*pMustLinkDirections)[g][k];
+          ml_dirs.push_back(how == SAME_DIRECTION ? 0 : (how == OPPOSITE_DIRECTION ? 1 : 2));
+        }
+      }
+    }
+  }
   const size_t n = (size_t)image_size[0] * image_size[1] * image_size[2];
   // directions: the standardized output array if one is given (it starts as a copy of the input), else a copy
   std::vector<float> dir_copy;
@@ -658,14 +673,16 @@ inline size_t LabelConnected(
   }
   std::vector<float> cm(pv_cluster_maxima ? 3 * n : 0), cs(pv_cluster_sizes ? n : 0), csal(pv_cluster_saliencies ? n : 0);
   int64_t n_clusters = 0;
-  hip_detail::check(visfd_hip_label_connected(
+  hip_detail::check(visfd_hip_label_connected_ex(
       hip_detail::flat(aaafSaliency), reinterpret_cast<int64_t*>(&aaaiDest[0][0][0]), hip_detail::flat(aaafMask),
       image_size[0], image_size[1], image_size[2], threshold_saliency, dir, threshold_vector_saliency,
       threshold_vector_neighbor, consider_dot_product_sign ? 1 : 0, aaaafSymmetricTensor ? ten.data() : nullptr,
       threshold_tensor_saliency, threshold_tensor_neighbor, tensor_is_positive_definite_near_target ? 1 : 0, connectivity,
       (int64_t)label_undefined, sort_criteria == SORT_BY_SIZE ? 1 : 0, aaaafVectorStandardized ? 1 : 0,
       start_from_saliency_maxima ? 1 : 0, &n_clusters, cm.empty() ? nullptr : cm.data(), cs.empty() ? nullptr : cs.data(),
-      csal.empty() ? nullptr : csal.data(), (int64_t)n));
+      csal.empty() ? nullptr : csal.data(), (int64_t)n, hip_detail::flat(aaafVoxelWeights),
+      ml_crds.empty() ? nullptr : ml_crds.data(), ml_sizes.empty() ? nullptr : ml_sizes.data(), (int64_t)ml_sizes.size(),
+      ml_dirs.empty() ? nullptr : ml_dirs.data()));
   if (pReportProgress) *pReportProgress << "Number of clusters found: " << n_clusters << "\n";
   if (pv_cluster_maxima) {
     pv_cluster_maxima->resize((size_t)n_clusters);

@@ -74,6 +74,11 @@ class CpuLib:
                                                 C.c_float, C.c_float, C.c_int, _fp, C.c_float, C.c_float, C.c_int,
                                                 C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp,
                                                 C.c_int64]),
+                "label_connected_ex": (C.c_int64, [_fp, C.POINTER(C.c_int64), _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp,
+                                                   C.c_float, C.c_float, C.c_int, _fp, C.c_float, C.c_float, C.c_int,
+                                                   C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp,
+                                                   C.c_int64, _fp, _fp, C.POINTER(C.c_int64), C.c_int64,
+                                                   C.POINTER(C.c_int)]),
                 "trace_product_sym3": (C.c_float, [_fp, _fp]),
                 "diagonalize_sym3_f32": (None, [_fp, C.c_int, _fp, _fp]),
                 "convert_flat_sym2_evects3": (None, [_fp, C.c_int, _fp, _fp]),
@@ -246,11 +251,30 @@ class CpuLib:
                         consider_dot_product_sign=True, threshold_tensor_saliency=-np.inf,
                         threshold_tensor_neighbor=-np.inf, tensor_is_positive_definite_near_target=True, connectivity=1,
                         label_undefined=-1, sort_by_size=True, standardize_directions=False,
-                        start_from_saliency_maxima=True):
+                        start_from_saliency_maxima=True, voxel_weights=None, must_link=None, must_link_directions=None):
         nz, ny, nx = saliency.shape
         labels = np.empty((nz, ny, nx), np.int64)
         cap = int(saliency.size)
         cm, cs, csal = np.zeros((cap, 3), np.float32), np.zeros(cap, np.float32), np.zeros(cap, np.float32)
+        if voxel_weights is not None or must_link:
+            ml_c = ml_n = ml_d = None
+            ngroups = 0
+            if must_link:
+                ngroups = len(must_link)
+                ml_c = np.ascontiguousarray(np.concatenate([np.asarray(g_, np.float32).reshape(-1, 3) for g_ in must_link], 0))
+                ml_n = np.array([len(g_) for g_ in must_link], np.int64)
+                if must_link_directions is not None:
+                    ml_d = np.ascontiguousarray(np.concatenate([np.asarray(d_, np.int32).ravel() for d_ in must_link_directions]))
+            k = self._fn["label_connected_ex"](
+                _f(saliency), labels.ctypes.data_as(C.POINTER(C.c_int64)), _f(mask), nx, ny, nz, threshold_saliency,
+                _f(direction), threshold_vector_saliency, threshold_vector_neighbor, int(bool(consider_dot_product_sign)),
+                _f(tensor), threshold_tensor_saliency, threshold_tensor_neighbor,
+                int(bool(tensor_is_positive_definite_near_target)), int(connectivity), int(label_undefined),
+                int(bool(sort_by_size)), int(bool(standardize_directions)), int(bool(start_from_saliency_maxima)),
+                _f(cm), _f(cs), _f(csal), cap, _f(voxel_weights), _f(ml_c),
+                None if ml_n is None else ml_n.ctypes.data_as(C.POINTER(C.c_int64)), ngroups,
+                None if ml_d is None else ml_d.ctypes.data_as(C.POINTER(C.c_int)))
+            return labels, int(k), cm[:k], cs[:k], csal[:k]
         k = self._fn["label_connected"](
             _f(saliency), labels.ctypes.data_as(C.POINTER(C.c_int64)), _f(mask), nx, ny, nz, threshold_saliency,
             _f(direction), threshold_vector_saliency, threshold_vector_neighbor, int(bool(consider_dot_product_sign)),

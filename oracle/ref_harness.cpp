@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <cstring>
 #include <cmath>
+#include <sstream>
 #include <vector>
 #include <array>
 #include <limits>
@@ -357,12 +358,50 @@ int vr_unbin_array3d(const float* src, const int* ssz, float* dst, const int* ds
 // ---- LabelConnected: connect.hpp:168-1427, called as bin/filter_mrc/handlers.cpp:1985-2013 does --------
 // (Label = ptrdiff_t, Coordinate = float, per-voxel pointers into the caller's AoS arrays; the
 // standardized-direction argument aliases the direction argument as in the handler.)
+int64_t vr_label_connected_ex(const float* saliency, int64_t* labels, const float* mask, int nx, int ny, int nz,
+                              float thr_saliency, float* direction, float thr_vs, float thr_vn, int consider_sign,
+                              float* tensor, float thr_ts, float thr_tn, int tensor_posdef, int connectivity,
+                              int64_t label_undefined, int sort_by_size, int standardize, int from_maxima,
+                              float* cluster_maxima, float* cluster_sizes, float* cluster_saliencies, int64_t capacity,
+                              const float* voxel_weights, const float* ml_crds, const int64_t* ml_group_sizes,
+                              int64_t ml_ngroups, const int* ml_directions);
+
 int64_t vr_label_connected(const float* saliency, int64_t* labels, const float* mask, int nx, int ny, int nz,
                            float thr_saliency, float* direction, float thr_vs, float thr_vn, int consider_sign,
                            float* tensor, float thr_ts, float thr_tn, int tensor_posdef, int connectivity,
                            int64_t label_undefined, int sort_by_size, int standardize, int from_maxima,
                            float* cluster_maxima, float* cluster_sizes, float* cluster_saliencies, int64_t capacity) {
+  return vr_label_connected_ex(saliency, labels, mask, nx, ny, nz, thr_saliency, direction, thr_vs, thr_vn, consider_sign,
+                               tensor, thr_ts, thr_tn, tensor_posdef, connectivity, label_undefined, sort_by_size, standardize,
+                               from_maxima, cluster_maxima, cluster_sizes, cluster_saliencies, capacity, nullptr, nullptr,
+                               nullptr, 0, nullptr);
+}
+
+int64_t vr_label_connected_ex(const float* saliency, int64_t* labels, const float* mask, int nx, int ny, int nz,
+                              float thr_saliency, float* direction, float thr_vs, float thr_vn, int consider_sign,
+                              float* tensor, float thr_ts, float thr_tn, int tensor_posdef, int connectivity,
+                              int64_t label_undefined, int sort_by_size, int standardize, int from_maxima,
+                              float* cluster_maxima, float* cluster_sizes, float* cluster_saliencies, int64_t capacity,
+                              const float* voxel_weights, const float* ml_crds, const int64_t* ml_group_sizes,
+                              int64_t ml_ngroups, const int* ml_directions) {
   const int size[3] = {nx, ny, nz};
+  View3<const float> vw(voxel_weights, nx, ny, nz);
+  std::vector<std::vector<std::array<float, 3> > > ml;
+  std::vector<std::vector<DirectionPairType> > mld;
+  {
+    int64_t at = 0;
+    for (int64_t gi = 0; gi < ml_ngroups; gi++) {
+      ml.push_back(std::vector<std::array<float, 3> >());
+      mld.push_back(std::vector<DirectionPairType>());
+      for (int64_t k = 0; k < ml_group_sizes[gi]; k++, at++) {
+        std::array<float, 3> c = {{ml_crds[3 * at], ml_crds[3 * at + 1], ml_crds[3 * at + 2]}};
+        ml.back().push_back(c);
+        const int how = ml_directions ? ml_directions[at] : 2;
+        mld.back().push_back(how == 0 ? SAME_DIRECTION : (how == 1 ? OPPOSITE_DIRECTION : AUTO));
+      }
+    }
+  }
+  std::ostringstream progress;   // the must-link code dereferences its progress stream unconditionally (connect.hpp:865)
   View3<const float> vs(saliency, nx, ny, nz), vm(mask, nx, ny, nz);
   static_assert(sizeof(ptrdiff_t) == sizeof(int64_t), "labels are ptrdiff_t");
   View3<ptrdiff_t> vl(reinterpret_cast<ptrdiff_t*>(labels), nx, ny, nz);
@@ -379,10 +418,10 @@ int64_t vr_label_connected(const float* saliency, int64_t* labels, const float* 
                              (float* const* const* const*)vt.p, thr_ts, thr_tn, tensor_posdef != 0, connectivity,
                              (ptrdiff_t)label_undefined, &centers, &sizes, &sals,
                              sort_by_size ? RegionSortCriteria::SORT_BY_SIZE : RegionSortCriteria::SORT_BY_VALUE,
-                             static_cast<float***>(nullptr), standardize ? vd.p : static_cast<float****>(nullptr),
-                             static_cast<const std::vector<std::vector<std::array<float, 3> > >*>(nullptr),
-                             static_cast<const std::vector<std::vector<DirectionPairType> >*>(nullptr),
-                             from_maxima != 0, (std::ostream*)nullptr);
+                             (cf3)vw.p, standardize ? vd.p : static_cast<float****>(nullptr),
+                             ml_ngroups > 0 ? &ml : static_cast<const std::vector<std::vector<std::array<float, 3> > >*>(nullptr),
+                             (ml_ngroups > 0 && ml_directions) ? &mld : static_cast<const std::vector<std::vector<DirectionPairType> >*>(nullptr),
+                             from_maxima != 0, ml_ngroups > 0 ? (std::ostream*)&progress : (std::ostream*)nullptr);
   for (size_t k = 0; k < nc && (int64_t)k < capacity; k++) {
     if (cluster_maxima) { cluster_maxima[3 * k] = centers[k][0]; cluster_maxima[3 * k + 1] = centers[k][1]; cluster_maxima[3 * k + 2] = centers[k][2]; }
     if (cluster_sizes) cluster_sizes[k] = sizes[k];

@@ -15,11 +15,11 @@ post, ten, direction = tc.tv_outputs(O)
 import zlib  # noqa: E402
 
 out = {"post_crc": np.int64(zlib.crc32(post.tobytes()))}
-for i, case in enumerate(tc.cases(post)):
+for i, case in enumerate(tc.cases(post) + tc.must_link_cases(post)):
     labels, k, cm, cs, csal, d = tc.run(R, post, ten, direction, case)
     out["labels%d" % i] = labels.astype(np.int32)
     out["n%d" % i] = np.int64(k)
     if d is not None:
         out["dir%d_crc" % i] = np.int64(zlib.crc32(d.tobytes()))
 np.savez_compressed(os.path.join(HERE, "connect.npz"), **out)
-print("wrote connect.npz; clusters:", [int(out["n%d" % i]) for i in range(len(tc.cases(post)))])
+print("wrote connect.npz; clusters:", [int(out["n%d" % i]) for i in range(len(tc.cases(post)) + len(tc.must_link_cases(post)))])

@@ -415,6 +415,43 @@ def test_cli_clustering_and_normals_host_path_equal_reference_program(cli, ref_c
     assert int(pb.split("element vertex ")[1].split()[0]) > 20
 
 
+@pytest.mark.parametrize("notation", ["physical", "imod"])
+def test_cli_must_link_equal_reference_program(cli, ref_cli, tmp_path, notation):
+    """-must-link FILE (settings.cpp:3183-3195, file_io.hpp:667-747, connect.hpp:829-1045): two parallel membranes form
+    two clusters; a must-link group with one location on each merges them.  Host path only (the vote tensors are
+    written once by the reference's -save-progress): label volumes and the oriented point cloud identical to the
+    reference program's, for coordinates in physical units (with an explicit direction column) and in IMOD's
+    "Pixel (x, y, z) = v" notation (1-based voxels)."""
+    import shutil
+    rng = np.random.default_rng(3)
+    n = 24
+    v = rng.normal(100, 2, (n, n, n)).astype(np.float32)
+    z = np.arange(n, dtype=np.float32)[:, None, None]
+    for z0 in (6.0, 17.0):
+        v -= (60 * np.exp(-((z - z0) ** 2) / 2.0)).astype(np.float32)
+    for tag in ("mine", "ref"):
+        (tmp_path / tag).mkdir()
+        volgen.write_mrc(str(tmp_path / tag / "two.rec"), v, voxel_width=1.0)
+        with open(tmp_path / tag / "ml.txt", "w") as f:
+            f.write("12 12 6   # first membrane\n11 13 17 1\n" if notation == "physical" else
+                    "Pixel (13, 13, 7) = 3.2\n(12, 14, 18)\n")
+    base = ["-w", 1, "-in", "two.rec", "-membrane", "minima", 2, "-tv", 3, "-tv-angle-exponent", 4, "-bin", 1]
+    r = subprocess.run([ref_cli] + [str(a) for a in base + ["-save-progress", "prog", "-out", "s.rec"]],
+                       cwd=str(tmp_path / "ref"), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for c in range(6):
+        shutil.copy(str(tmp_path / "ref" / ("prog_tensor_%d.rec" % c)), str(tmp_path / "mine" / ("prog_tensor_%d.rec" % c)))
+    cluster = base + ["-load-progress", "prog", "-connect", 5, "-connect-angle", 30]
+    counts = {}
+    for name, extra in (("free", []), ("linked", ["-must-link", "ml.txt", "-normals-file", "n.ply", "-select-cluster", 1])):
+        mine, ref = both(cli, ref_cli, tmp_path, cluster + extra, name + ".rec")
+        a, b = volgen.read_mrc(str(mine / (name + ".rec"))), volgen.read_mrc(str(ref / (name + ".rec")))
+        assert_bits_equal(a, b, "cluster labels, " + name)
+        counts[name] = len(np.unique(b))
+    assert counts["free"] == 3 and counts["linked"] == 2      # two membranes + "undefined" -> one cluster + "undefined"
+    assert open(mine / "n.ply").read() == open(ref / "n.ply").read()
+
+
 @pytest.mark.gpu
 def test_cli_normals_file_reference_scenario(cli, ref_cli, tmp_path):
     """The second command of tests/test_membrane_detection.sh including -normals-file: 58 vertices,

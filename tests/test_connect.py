@@ -46,6 +46,23 @@ def cases(post):
     ]
 
 
+# strict angle thresholds split the voted surface into seven islands; the must-link groups name seed voxels of some of
+# them (the second group starts 0.4 voxels off a voxel centre: locations are rounded, connect.hpp:862-864)
+_STRICT = 0.985
+_MUST_LINK = [[(17.0, 21.0, 16.0), (22.0, 17.0, 13.0), (12.0, 19.0, 1.0)], [(19.4, 27.4, 13.4), (20.0, 19.0, 1.0), (20.0, 17.0, 2.0)]]
+
+
+def must_link_cases(post):
+    thr = float(np.sort(post.ravel())[int(0.9 * post.size)])
+    base = dict(threshold_saliency=thr, use="vt", threshold_vector_saliency=_STRICT, threshold_vector_neighbor=_STRICT,
+                threshold_tensor_saliency=0.9, threshold_tensor_neighbor=0.9, consider_dot_product_sign=False,
+                standardize_directions=True)
+    w = np.random.default_rng(5).uniform(0.5, 2.0, post.shape).astype(np.float32)
+    extras = [dict(), dict(must_link=_MUST_LINK), dict(must_link=_MUST_LINK, must_link_directions=[[2, 0, 1], [2, 1, 0]]),
+              dict(voxel_weights=w), dict(voxel_weights=w, must_link=_MUST_LINK), dict(must_link=_MUST_LINK, mask=True)]
+    return [dict(base, **e) for e in extras]
+
+
 def run(lib, post, ten, direction, case):
     kw = dict(case)
     use = kw.pop("use", "")
@@ -85,12 +102,26 @@ def test_label_connected_vs_reference(oracle, ref):
         same(got, want, "case %d" % i)
 
 
+def test_must_link_and_voxel_weights_vs_reference(oracle, ref):
+    """LabelConnected's remaining optional arguments (connect.hpp:829-1045 and :1154-1290): must-link groups merge the
+    islands nearest to the given locations (with and without explicit direction pairs, polarity bookkeeping included),
+    voxel weights change the size ranking and the outward orientation -- labels, sizes, seeds and standardized
+    directions bit for bit against the compiled reference."""
+    post, ten, direction = tv_outputs(oracle)
+    counts = []
+    for i, case in enumerate(must_link_cases(post)):
+        got, want = run(api, post, ten, direction, case), run(ref, post, ten, direction, case)
+        same(got, want, "must-link case %d" % i)
+        counts.append(got[1])
+    assert counts[0] >= 5 and counts[1] < counts[0] and counts[3] == counts[0]     # merges happened; weights merge nothing
+
+
 def test_label_connected_golden(oracle):
     g = np.load(GOLD)
     post, ten, direction = tv_outputs(oracle)
     import zlib
     assert zlib.crc32(post.tobytes()) == int(g["post_crc"]), "oracle pipeline changed: regenerate goldens"
-    for i, case in enumerate(cases(post)):
+    for i, case in enumerate(cases(post) + must_link_cases(post)):
         got = run(api, post, ten, direction, case)
         assert got[1] == int(g["n%d" % i])
         assert np.array_equal(got[0], g["labels%d" % i]), "case %d" % i

@@ -110,6 +110,9 @@ _SIGS = {
     "visfd_hip_label_connected": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, C.c_float, _vp, C.c_float, C.c_float, C.c_int,
                                             _vp, C.c_float, C.c_float, C.c_int, C.c_int, _i64, C.c_int, C.c_int, C.c_int,
                                             C.POINTER(_i64), _vp, _vp, _vp, _i64]),
+    "visfd_hip_label_connected_ex": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, C.c_float, _vp, C.c_float, C.c_float, C.c_int,
+                                               _vp, C.c_float, C.c_float, C.c_int, C.c_int, _i64, C.c_int, C.c_int, C.c_int,
+                                               C.POINTER(_i64), _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
     "visfd_hip_principal_directions_host": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp]),
     "visfd_hip_tensor_saliency_host": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp]),
     "visfd_hip_diagonalize_sym3_f32_host": (C.c_int, [_vp, C.c_int, _vp, _vp]),
@@ -234,7 +237,8 @@ def label_connected(saliency, threshold_saliency, mask=None, direction=None, ten
                     threshold_vector_saliency=-np.inf, threshold_vector_neighbor=-np.inf, consider_dot_product_sign=True,
                     threshold_tensor_saliency=-np.inf, threshold_tensor_neighbor=-np.inf,
                     tensor_is_positive_definite_near_target=True, connectivity=1, label_undefined=-1, sort_by_size=True,
-                    standardize_directions=False, start_from_saliency_maxima=True):
+                    standardize_directions=False, start_from_saliency_maxima=True, voxel_weights=None, must_link=None,
+                    must_link_directions=None):
     """LabelConnected (connect.hpp:168-1427).  saliency [nz,ny,nx]; direction [nz,ny,nx,3] (rewritten in place when
     standardize_directions); tensor [nz,ny,nx,6].  Returns (labels int64 [nz,ny,nx], n_clusters, seed positions
     [n,3] in final order, sizes [n] and seed saliencies [n] in provisional order)."""
@@ -246,13 +250,25 @@ def label_connected(saliency, threshold_saliency, mask=None, direction=None, ten
     cm, cs, csal = np.zeros((cap, 3), np.float32), np.zeros(cap, np.float32), np.zeros(cap, np.float32)
     for a in (direction, tensor):
         assert a is None or (a.dtype == np.float32 and a.flags["C_CONTIGUOUS"])
-    _chk_host(L, L.visfd_hip_label_connected(
+    # must_link: list of groups, each a list of (x, y, z) locations in voxels; must_link_directions: the same shape of
+    # 0 / 1 / 2 (same / opposite / automatic, connect.hpp DirectionPairType) or None
+    ml_c = ml_n = ml_d = None
+    ngroups = 0
+    if must_link:
+        ngroups = len(must_link)
+        ml_c = np.ascontiguousarray(np.concatenate([np.asarray(g_, np.float32).reshape(-1, 3) for g_ in must_link], 0))
+        ml_n = np.array([len(g_) for g_ in must_link], np.int64)
+        if must_link_directions is not None:
+            ml_d = np.ascontiguousarray(np.concatenate([np.asarray(d_, np.int32).ravel() for d_ in must_link_directions]))
+    ptr = lambda a: None if a is None else a.ctypes.data
+    _chk_host(L, L.visfd_hip_label_connected_ex(
         _np(saliency), labels.ctypes.data, _np(mask), nx, ny, nz, threshold_saliency,
         None if direction is None else direction.ctypes.data, threshold_vector_saliency, threshold_vector_neighbor,
         int(bool(consider_dot_product_sign)), None if tensor is None else tensor.ctypes.data, threshold_tensor_saliency,
         threshold_tensor_neighbor, int(bool(tensor_is_positive_definite_near_target)), int(connectivity),
         int(label_undefined), int(bool(sort_by_size)), int(bool(standardize_directions)),
-        int(bool(start_from_saliency_maxima)), C.byref(n), cm.ctypes.data, cs.ctypes.data, csal.ctypes.data, cap))
+        int(bool(start_from_saliency_maxima)), C.byref(n), cm.ctypes.data, cs.ctypes.data, csal.ctypes.data, cap,
+        _np(voxel_weights), ptr(ml_c), ptr(ml_n), ngroups, ptr(ml_d)))
     k = n.value
     return labels, k, cm[:k], cs[:k], csal[:k]
 

@@ -159,6 +159,11 @@ struct Settings {
   float nonmax_max_overlap_small = std::numeric_limits<float>::infinity();
   // clustering of the detected surface (-connect ...), settings.cpp:163-178
   bool cluster_connected_voxels = false;
+  string must_link_filename;                       // -must-link FILE (settings.cpp:3183-3195)
+  vector<float> must_link_crds;                    // flat x,y,z of every location, group after group
+  vector<int64_t> must_link_group_sizes;
+  vector<int> must_link_directions;                // 0 same, 1 opposite, 2 automatic (one per location)
+  bool must_link_in_voxels = false;
   float connect_threshold_saliency = std::numeric_limits<float>::infinity();
   float connect_threshold_vector_saliency = (float)std::cos(M_PI * 15 / 180.0);
   float connect_threshold_vector_neighbor = (float)std::cos(M_PI * 15 / 180.0);
@@ -180,6 +185,8 @@ struct Settings {
   int tv_exponent = 4;                                        // settings.cpp:154
   float tv_truncate = std::sqrt(2.0);                         // settings.cpp:155
 };
+
+bool read_must_link_file(const string& path, Settings& s);
 
 float num(const vector<string>& v, size_t i, const string& flag) {
   if (i >= v.size() || v[i].empty()) throw VisfdErr("Error: The " + flag + " argument must be followed by a number.\n");
@@ -316,6 +323,7 @@ Settings parse(int argc, char** argv) {
       s.connect_threshold_tensor_saliency = s.connect_threshold_tensor_neighbor = c;
       i += 2;
     }
+    else if (f == "-must-link") { need(1); s.must_link_filename = v[i + 1]; i += 2; }
     else if (f == "-connect-vector-saliency") { need(1); s.cluster_connected_voxels = true; s.connect_threshold_vector_saliency = num(v, i + 1, f); i += 2; }
     else if (f == "-connect-vector-neighbor") { need(1); s.cluster_connected_voxels = true; s.connect_threshold_vector_neighbor = num(v, i + 1, f); i += 2; }
     else if (f == "-connect-tensor-saliency") { need(1); s.cluster_connected_voxels = true; s.connect_threshold_tensor_saliency = num(v, i + 1, f); i += 2; }
@@ -347,6 +355,7 @@ Settings parse(int argc, char** argv) {
     else throw VisfdErr("Error: Unrecognized (or unsupported on the GPU hot path) argument: \"" + f + "\"\n");
   }
   if (s.in.empty()) throw VisfdErr("Error: You must specify an input file (-in).\n");
+  if (!s.must_link_filename.empty()) s.must_link_in_voxels = read_must_link_file(s.must_link_filename, s);
   if (s.type == Settings::SURFACE_RIDGE) s.tv_sigma *= s.width_a[0];   // settings.cpp:3535-3540
   if (s.cluster_connected_voxels && s.type != Settings::SURFACE_RIDGE)
     throw VisfdErr("Error: this build clusters voxels (-connect) only after \"-membrane ... -tv ...\".\n");
@@ -361,6 +370,68 @@ Settings parse(int argc, char** argv) {
 
 // Blob list file (bin/filter_mrc/file_io.hpp:413-493): 3-5 numbers per line (x y z [diameter [score]]), '#'
 // starts a comment; coordinates written IMOD-style in parentheses mean "units of voxels".  Returns that flag.
+// The -must-link file (bin/filter_mrc/file_io.hpp:82-214, :667-747): groups of locations separated by blank lines; a
+// line holds x y z and optionally a fourth number (> 0: the two surfaces face the same way, < 0: opposite, else
+// automatic); text after '#' is ignored.  IMOD's notation -- "Pixel (x, y, z) = value" or any line whose numbers sit in
+// parentheses -- means 1-based voxel indices: floor(x) - 1.  Returns whether the coordinates are voxels already.
+bool read_must_link_file(const string& path, Settings& s) {
+  std::ifstream f(path.c_str());
+  if (!f) throw VisfdErr("Error: unable to open \"" + path + "\" for reading.\n");
+  bool imod_any = false;
+  vector<std::array<float, 3> > group;
+  vector<int> group_dirs;
+  auto close_group = [&]() {
+    if (group.empty()) return;
+    if (group.size() < 2 || group[0] == group[1])
+      throw VisfdErr("Error: Format error in file \"" + path + "\".\n"
+                     "       Each group must contain at least 2 voxels.  (Voxels appear on different\n"
+                     "       lines, so blank-line delimters must not separate SINGLE non-blank lines)\n"
+                     "       Furthermore, the voxels in each set must be unique.\n");
+    s.must_link_group_sizes.push_back((int64_t)group.size());
+    for (size_t k = 0; k < group.size(); k++) {
+      for (int d = 0; d < 3; d++) s.must_link_crds.push_back(group[k][d]);
+      s.must_link_directions.push_back(group_dirs[k]);
+    }
+    group.clear();
+    group_dirs.clear();
+  };
+  string line;
+  while (std::getline(f, line)) {
+    const size_t hash = line.find('#');
+    if (hash != string::npos) line = line.substr(0, hash);
+    bool parens = false, imod = false;
+    for (size_t k = 0; k < line.size(); k++) {
+      if (line[k] == '(' || line[k] == ')') { parens = true; line[k] = ' '; }
+      else if (line[k] == ',') line[k] = ' ';
+    }
+    std::istringstream ws(line);
+    vector<string> words;
+    string w;
+    while (ws >> w) words.push_back(w);
+    if (!words.empty() && words[0] == "Pixel") { imod = parens = true; words.erase(words.begin()); }
+    vector<float> xyz;
+    for (size_t d = 0; d < words.size(); d++) {
+      if (d >= 3 && imod) break;                       // "= value" of IMOD's line
+      std::istringstream num(words[d]);
+      float x;
+      if (!(num >> x)) throw VisfdErr("Error: File read error (invalid entry?) on line:\n      " + line + "\n");
+      if (parens && xyz.size() < 3) x = std::floor(x) - 1.0f;   // IMOD counts voxels from 1
+      xyz.push_back(x);
+    }
+    imod_any = imod_any || parens;
+    if (xyz.empty()) { close_group(); continue; }
+    if (xyz.size() != 3 && xyz.size() != 4)
+      throw VisfdErr("Error: Each line of file \"" + path + "\"\n       should contain either 3 numbers, 4 numbers, or 0 numbers.\n");
+    std::array<float, 3> c = {{xyz[0], xyz[1], xyz[2]}};
+    group.push_back(c);
+    group_dirs.push_back(xyz.size() == 4 ? (xyz[3] > 0 ? 0 : (xyz[3] < 0 ? 1 : 2)) : 2);
+  }
+  close_group();
+  if (s.must_link_group_sizes.empty())
+    throw VisfdErr("Error: Format error in file \"" + path + "\".\n       File contains no voxel coordinates.\n");
+  return imod_any;
+}
+
 bool read_blob_file(const string& path, vector<std::array<float, 3> >& crds, vector<float>& diameters,
                     vector<float>& scores) {
   std::ifstream f(path.c_str());
@@ -531,6 +602,8 @@ int main(int argc, char** argv) {
       else for (int d = 0; d < 3; d++) vw[d] = tomo_in.cella[d] / size[d];
     }
     cerr << "voxel width = " << vw[0] << "\n";
+    for (size_t k = 0; k < s.must_link_crds.size(); k++)      // filter_mrc.cpp:372-379: physical units -> voxels, or
+      s.must_link_crds[k] /= s.must_link_in_voxels ? (float)bin : vw[k % 3];   // voxels of the unbinned image -> binned
     for (int d = 0; d < 3; d++) { s.width_a[d] /= vw[d]; s.width_b[d] /= vw[d]; s.log_width[d] /= vw[d]; s.template_background_radius[d] /= vw[d]; }
     s.tv_sigma /= vw[0];
     for (size_t k = 0; k < s.blob_diameters.size(); k++) s.blob_diameters[k] /= vw[0];
@@ -646,11 +719,13 @@ int main(int argc, char** argv) {
         hip_detail::check(visfd_hip_principal_directions_host(tensor.data(), mptr, (int64_t)n, order, direction.data()));
         vector<int64_t> labels(n);
         int64_t n_clusters = 0;
-        hip_detail::check(visfd_hip_label_connected(
+        hip_detail::check(visfd_hip_label_connected_ex(
             tomo_out.data(), labels.data(), mptr, size[0], size[1], size[2], s.connect_threshold_saliency,
             direction.data(), s.connect_threshold_vector_saliency, s.connect_threshold_vector_neighbor, 0, tensor.data(),
             s.connect_threshold_tensor_saliency, s.connect_threshold_tensor_neighbor, 1, 1, -1, 1, 1, 1, &n_clusters,
-            nullptr, nullptr, nullptr, 0));
+            nullptr, nullptr, nullptr, 0, nullptr, s.must_link_crds.empty() ? nullptr : s.must_link_crds.data(),
+            s.must_link_group_sizes.empty() ? nullptr : s.must_link_group_sizes.data(),
+            (int64_t)s.must_link_group_sizes.size(), s.must_link_directions.empty() ? nullptr : s.must_link_directions.data()));
         cerr << "Number of clusters found: " << n_clusters << "\n";
         int64_t max_label = labels[0];
         for (size_t i = 0; i < n; i++)

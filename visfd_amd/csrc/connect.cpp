@@ -21,7 +21,7 @@
 // is  a0*b0 + a0*b1 + a1*b2 + a1*b0 + a1*b1 + a2*b2 + a2*b1 + a2*b2 + a0*b0  (only the diagonal
 // entries enter).  That effective formula -- pinned against the compiled reference by
 // tests/test_connect.py -- is what is evaluated here, since the thresholds act on it.
-// Not provided: must-link constraints and voxel weights (off the CLI's default path).
+// Must-link constraints (connect.hpp:829-1045) and voxel weights (:1154-1290) are honoured by the _ex entry.
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -140,16 +140,18 @@ inline float sqr(float x) { return x * x; }
 
 }  // namespace
 
-extern "C" int visfd_hip_label_connected(const float* saliency, int64_t* labels, const float* mask, int64_t nx64,
-                                         int64_t ny64, int64_t nz64, float threshold_saliency, float* direction,
-                                         float threshold_vector_saliency, float threshold_vector_neighbor,
-                                         int consider_dot_product_sign, const float* tensor,
-                                         float threshold_tensor_saliency, float threshold_tensor_neighbor,
-                                         int tensor_is_positive_definite_near_target, int connectivity,
-                                         int64_t label_undefined, int sort_by_size, int standardize_directions,
-                                         int start_from_saliency_maxima, int64_t* n_clusters_out,
-                                         float* cluster_maxima, float* cluster_sizes, float* cluster_saliencies,
-                                         int64_t cluster_capacity) {
+extern "C" int visfd_hip_label_connected_ex(const float* saliency, int64_t* labels, const float* mask, int64_t nx64,
+                                            int64_t ny64, int64_t nz64, float threshold_saliency, float* direction,
+                                            float threshold_vector_saliency, float threshold_vector_neighbor,
+                                            int consider_dot_product_sign, const float* tensor,
+                                            float threshold_tensor_saliency, float threshold_tensor_neighbor,
+                                            int tensor_is_positive_definite_near_target, int connectivity,
+                                            int64_t label_undefined, int sort_by_size, int standardize_directions,
+                                            int start_from_saliency_maxima, int64_t* n_clusters_out,
+                                            float* cluster_maxima, float* cluster_sizes, float* cluster_saliencies,
+                                            int64_t cluster_capacity, const float* voxel_weights,
+                                            const float* must_link_crds, const int64_t* must_link_group_sizes,
+                                            int64_t must_link_ngroups, const int* must_link_directions) {
   if (!saliency || !labels) return vh::fail(VISFD_HIP_EINVAL, "label_connected: null image");
   VH_TRY(vh::check_dims(nx64, ny64, nz64));
   if (nx64 < 3 || ny64 < 3 || nz64 < 3)   // visfd_utils.hpp:585-587 (asserted there)
@@ -286,6 +288,78 @@ extern "C" int visfd_hip_label_connected(const float* saliency, int64_t* labels,
     }
   }
 
+  // ---- must-link constraints (connect.hpp:829-1045): for every group of locations, the clusters of the clustered
+  // voxels nearest to consecutive locations are merged (the smaller id absorbs the other), with the polarity of the
+  // absorbed basins flipped when the two contact voxels face incompatibly (given per location, or inferred from the
+  // angles their normals make with the line joining them).
+  if (must_link_crds && must_link_ngroups > 0) {
+    if (!must_link_group_sizes) return vh::fail(VISFD_HIP_EINVAL, "label_connected: must-link group sizes missing");
+    i64 at = 0;
+    for (i64 grp = 0; grp < must_link_ngroups; grp++) {
+      i64 basin_j = -1;
+      int rj[3] = {-1, -1, -1};
+      for (i64 loc = 0; loc < must_link_group_sizes[grp]; loc++, at++) {
+        const int want[3] = {(int)std::floor(must_link_crds[3 * at] + 0.5), (int)std::floor(must_link_crds[3 * at + 1] + 0.5),
+                             (int)std::floor(must_link_crds[3 * at + 2] + 0.5)};
+        // FindNearestVoxel (visfd_utils.hpp:147-186): scan order, strictly closer wins, distances in double
+        int ri[3] = {-1, -1, -1};
+        double r_min_sq = -1.0;
+        for (int z = 0; z < g.nz; z++)
+          for (int y = 0; y < g.ny; y++)
+            for (int x = 0; x < g.nx; x++) {
+              const i64 c = g.at(x, y, z);
+              if (M && M[c] == 0.0f) continue;
+              if (labels[c] == UNDEFINED) continue;
+              const double dx = want[0] - x, dy = want[1] - y, dz = want[2] - z;
+              const double r_sq = dx * dx + dy * dy + dz * dz;
+              if (r_min_sq == -1.0 || r_sq < r_min_sq) { r_min_sq = r_sq; ri[0] = x; ri[1] = y; ri[2] = z; }
+            }
+        if (ri[0] == -1)
+          return vh::fail(VISFD_HIP_EINVAL, "Error: No voxels clustered. Empty image. Your cluster criteria are too strict.\n"
+                                            "       (Attempting the find the nearest voxel from an empty set.)\n");
+        const i64 basin_i = labels[g.at(ri[0], ri[1], ri[2])];
+        if (basin_j != -1 && basin_i != basin_j) {
+          const i64 ci = basin2cluster[(size_t)basin_i], cj = basin2cluster[(size_t)basin_j];
+          if (ci != cj && ci >= 0 && cj >= 0) {
+            const i64 keep = std::min(ci, cj), gone = std::max(ci, cj);
+            bool flip = false;
+            if (V) {
+              const float* n_i = V + 3 * g.at(ri[0], ri[1], ri[2]);
+              const float* n_j = V + 3 * g.at(rj[0], rj[1], rj[2]);
+              float r_ij[3] = {(float)(ri[0] - rj[0]), (float)(ri[1] - rj[1]), (float)(ri[2] - rj[2])};
+              {   // Normalize3 (lin3_utils.hpp:143-155)
+                const float len = std::sqrt(r_ij[0] * r_ij[0] + r_ij[1] * r_ij[1] + r_ij[2] * r_ij[2]);
+                if (len > 0) { const float inv = (float)(1.0 / (double)len); for (int d = 0; d < 3; d++) r_ij[d] *= inv; }
+                else { r_ij[0] = 1.0f; r_ij[1] = 0.0f; r_ij[2] = 0.0f; }
+              }
+              bool polarity_match;
+              const int how = must_link_directions ? must_link_directions[at] : 2;   // 0 same, 1 opposite, 2 auto
+              if (how == 0) polarity_match = dot3(n_i, n_j) > 0;
+              else if (how == 1) polarity_match = dot3(n_i, n_j) < 0;
+              else {
+                const float ni_dot_rij = dot3(n_i, r_ij), nj_dot_rij = dot3(n_j, r_ij);
+                const float theta0 = (float)(M_PI / 4);
+                const float theta_i = std::asin(std::abs(ni_dot_rij)), theta_j = std::asin(std::abs(nj_dot_rij));
+                if (theta_i < theta0 && theta_j < theta0) polarity_match = dot3(n_i, n_j) > 0;
+                else polarity_match = (ni_dot_rij * nj_dot_rij <= 0);
+              }
+              flip = polarity_match != (polarity[(size_t)basin_i] == polarity[(size_t)basin_j]);
+            }
+            for (size_t k = 0; k < cluster2basins[(size_t)gone].size(); k++) {
+              const i64 b = cluster2basins[(size_t)gone][k];
+              cluster2basins[(size_t)keep].push_back(b);
+              basin2cluster[(size_t)b] = keep;
+              if (standardize && flip) polarity[(size_t)b] = (signed char)-polarity[(size_t)b];
+            }
+            cluster2basins[(size_t)gone].clear();
+          }
+        }
+        basin_j = basin_i;
+        for (int d = 0; d < 3; d++) rj[d] = ri[d];
+      }
+    }
+  }
+
   // provisional cluster numbers 0..n_clusters-1 in basin order (connect.hpp:1049-1075)
   std::vector<i64> old2new((size_t)nseeds), deepest;
   i64 n_clusters = 0;
@@ -305,8 +379,9 @@ extern "C" int visfd_hip_label_connected(const float* saliency, int64_t* labels,
   for (i64 c = 0; c < n; c++)
     if (live(c)) labels[c] = basin2cluster[(size_t)labels[c]];
   std::vector<long double> sizes((size_t)n_clusters, 0.0L);
+  const float* W = voxel_weights;   // connect.hpp:1154-1183: the "size" of a cluster is then the sum of its voxels' weights
   for (i64 c = 0; c < n; c++)
-    if (live(c)) sizes[(size_t)labels[c]] += 1.0L;
+    if (live(c)) sizes[(size_t)labels[c]] += W ? (long double)W[c] : 1.0L;
   if (standardize) {   // outward orientation by the sign of sum (r - r_com).n (connect.hpp:1192-1290)
     std::vector<std::array<long double, 3> > com((size_t)n_clusters, std::array<long double, 3>{{0.0L, 0.0L, 0.0L}});
     for (int z = 0; z < g.nz; z++)
@@ -314,7 +389,11 @@ extern "C" int visfd_hip_label_connected(const float* saliency, int64_t* labels,
         for (int x = 0; x < g.nx; x++) {
           const i64 c = g.at(x, y, z);
           if (!live(c)) continue;
-          com[(size_t)labels[c]][0] += x; com[(size_t)labels[c]][1] += y; com[(size_t)labels[c]][2] += z;
+          if (W) {   // connect.hpp:1211-1224: int * float products in float, summed in long double
+            com[(size_t)labels[c]][0] += x * W[c]; com[(size_t)labels[c]][1] += y * W[c]; com[(size_t)labels[c]][2] += z * W[c];
+          } else {
+            com[(size_t)labels[c]][0] += x; com[(size_t)labels[c]][1] += y; com[(size_t)labels[c]][2] += z;
+          }
         }
     for (i64 k = 0; k < n_clusters; k++)
       for (int d = 0; d < 3; d++) com[(size_t)k][d] /= sizes[(size_t)k];
@@ -326,7 +405,9 @@ extern "C" int visfd_hip_label_connected(const float* saliency, int64_t* labels,
           if (!live(c)) continue;
           const i64 k = labels[c];
           const float r[3] = {(float)(x - com[(size_t)k][0]), (float)(y - com[(size_t)k][1]), (float)(z - com[(size_t)k][2])};
-          sum_dot[(size_t)k] += (long double)dot3(r, V + 3 * c);
+          long double delta_sum = (long double)dot3(r, V + 3 * c);
+          if (W) delta_sum *= W[c];
+          sum_dot[(size_t)k] += delta_sum;
         }
     for (i64 c = 0; c < n; c++)
       if (live(c) && sum_dot[(size_t)labels[c]] < 0.0L) { V[3 * c] *= -1.0f; V[3 * c + 1] *= -1.0f; V[3 * c + 2] *= -1.0f; }
@@ -366,6 +447,24 @@ extern "C" int visfd_hip_label_connected(const float* saliency, int64_t* labels,
     }
   }
   return VISFD_HIP_OK;
+}
+
+extern "C" int visfd_hip_label_connected(const float* saliency, int64_t* labels, const float* mask, int64_t nx64,
+                                         int64_t ny64, int64_t nz64, float threshold_saliency, float* direction,
+                                         float threshold_vector_saliency, float threshold_vector_neighbor,
+                                         int consider_dot_product_sign, const float* tensor,
+                                         float threshold_tensor_saliency, float threshold_tensor_neighbor,
+                                         int tensor_is_positive_definite_near_target, int connectivity,
+                                         int64_t label_undefined, int sort_by_size, int standardize_directions,
+                                         int start_from_saliency_maxima, int64_t* n_clusters_out,
+                                         float* cluster_maxima, float* cluster_sizes, float* cluster_saliencies,
+                                         int64_t cluster_capacity) {
+  return visfd_hip_label_connected_ex(saliency, labels, mask, nx64, ny64, nz64, threshold_saliency, direction,
+                                      threshold_vector_saliency, threshold_vector_neighbor, consider_dot_product_sign, tensor,
+                                      threshold_tensor_saliency, threshold_tensor_neighbor,
+                                      tensor_is_positive_definite_near_target, connectivity, label_undefined, sort_by_size,
+                                      standardize_directions, start_from_saliency_maxima, n_clusters_out, cluster_maxima,
+                                      cluster_sizes, cluster_saliencies, cluster_capacity, nullptr, nullptr, nullptr, 0, nullptr);
 }
 
 namespace {
