@@ -176,6 +176,33 @@ def test_gauss_sparse_and_empty_mask(ctx, oracle):
     assert_bits_equal(a, b, "all-zero mask")
 
 
+@pytest.mark.parametrize("h", [2, 5])
+def test_gauss_fused_signed_zeros(ctx, oracle, h):
+    """The single-sweep kernel starts its sums from the first product instead of from +0.0 and adds +0.0 once at the
+    end: regions of -0.0 samples (alone, next to +0.0, next to data, under negative taps) must still come out with the
+    reference's zero signs."""
+    rng = np.random.default_rng(40 + h)
+    shape = (24, 36, 72)
+    src = np.full(shape, -0.0, np.float32)
+    src[:, :, 36:] = 0.0
+    src[8:12, 10:20, 20:50] = rng.standard_normal((4, 10, 30)).astype(np.float32)
+    src[rng.random(shape) < 0.02] = np.float32(-3.5)
+    sigma = (h / 2.6,) * 3
+    for norm in (True, False):
+        a, _ = ctx.gauss_hw(src, sigma, (h, h, h), None, norm)
+        b, _ = oracle.gauss_hw(src, sigma, (h, h, h), None, norm)
+        assert np.signbit(src).any() and (b == 0).any()
+        assert_bits_equal(a, b, "signed zeros h=%d norm=%d" % (h, norm))
+    half = rng.normal(0.0, 1.0, h + 1).astype(np.float32)
+    sym = np.ascontiguousarray(np.concatenate([half[:0:-1], half]), np.float32)
+    a, _ = ctx.separable3d(src, [sym, -np.abs(sym), sym], None, False)
+    b, _ = _oracle_separable(oracle, src, [sym, -np.abs(sym), sym], False)
+    assert_bits_equal(a, b, "signed zeros under signed taps h=%d" % h)
+    allneg = np.full(shape, -0.0, np.float32)
+    a, _ = ctx.gauss_hw(allneg, sigma, (h, h, h), None, False)
+    assert_bits_equal(a, np.zeros(shape, np.float32), "all -0.0 gives +0.0")
+
+
 def test_separable_generic_taps(ctx, oracle):
     """ApplySeparable with caller-supplied (non-Gaussian, signed) taps."""
     src = volgen.noise_volume((20, 21, 22), seed=8)

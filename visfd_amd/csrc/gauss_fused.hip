@@ -281,7 +281,7 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
 #pragma unroll
       for (int j = -H; j <= H; j++) {
         const int s = (u + H - j) % W;
-        if (j == -H) ring[c][s] = 0.0f + pr[H];          // "acc = 0; acc += term" (filter1d.hpp:96-101)
+        if (j == -H) ring[c][s] = pr[H];                 // first term of the sum (see "signed zeros" below)
         else ring[c][s] = ring[c][s] + pr[j < 0 ? -j : j];
       }
     }
@@ -303,8 +303,8 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
                 const float t = tap_y(jj);
                 const float p0 = t * v[jj].x;
                 const float p1 = t * v[jj].y;
-                a0 = a0 + p0;
-                a1 = a1 + p1;
+                a0 = jj == 0 ? p0 : a0 + p0;
+                a1 = jj == 0 ? p1 : a1 + p1;
               }
               *reinterpret_cast<float2*>(reinterpret_cast<char*>(sY) + y_off[r]) = make_float2(a0, a1);
             } else {
@@ -315,7 +315,7 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
 #pragma unroll
               for (int jj = 0; jj < W; jj++) {
                 const float p0 = tap_y(jj) * v[jj];
-                a0 = a0 + p0;
+                a0 = jj == 0 ? p0 : a0 + p0;
               }
               *reinterpret_cast<float*>(reinterpret_cast<char*>(sY) + y_off[r]) = a0;
             }
@@ -367,9 +367,17 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
 #pragma unroll
             for (int k = 0; k < C::XV; k++) {
               const float pr = t * v[2 * H - jj + k];
-              a[k] = a[k] + pr;
+              a[k] = jj == 0 ? pr : a[k] + pr;
             }
           }
+          // Signed zeros.  The reference starts every sum from +0.0 ("acc = 0; acc += term", filter1d.hpp:96-101); the
+          // three passes above start from the first product instead, which saves one add per output and pass.  The two
+          // differ only when every product of a sum is -0.0: the sum is then -0.0 here and +0.0 there.  A zero of either
+          // sign contributes the same (zero) products to the next pass, so no non-zero value downstream can change, and a
+          // final result can only be -0.0 where the reference has +0.0; adding +0.0 once, here, restores exactly that
+          // (x + 0.0 == x for every other x).
+#pragma unroll
+          for (int k = 0; k < C::XV; k++) a[k] = a[k] + 0.0f;
           if (NORMALIZE) {
             // dest /= (Dx*Dy)*Dz (filter3d.hpp:1016-1018), one correctly rounded division.  On planes with the
             // interior Dz the divisor is a per-lane constant whose correctly rounded reciprocal y is known, and
