@@ -119,6 +119,20 @@ def cpu_baseline(sample=96):
 STAGE_BYTES_PER_VOXEL = {"gauss": 8.0, "blob_dog": 216.0, "membrane_tv": 112.0}
 
 
+def offline_traffic(stem, shape):
+    """HBM bytes per launch from PMC counters, measured offline (tools/profile_round.sh) and committed under profiles/:
+    the newest round's file for this shape, or (None, None)."""
+    for rnd in range(9, 0, -1):
+        name = "r%02d_%s.json" % (rnd, stem)
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if list(tr["shape"]) == list(shape):
+                return tr["traffic_bytes"], "profiles/" + name
+        except Exception:
+            continue
+    return None, None
+
+
 def pipeline_roofline(stage_ms, ms_per_step, nvox):
     total_b = sum(STAGE_BYTES_PER_VOXEL.values())
     out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_voxel": total_b,
@@ -271,18 +285,12 @@ def main():
         achieved = 8.0 * nv / (g_ms * 1e-3) / 1e9  # algorithmic 8 B/voxel
         # HBM bytes per launch from PMC counters: measured offline with rocprofv3 (separate --pmc passes,
         # tools/pmc_traffic.py) and committed under profiles/; only quoted for the shape it was measured on
-        traffic = None
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_gauss_traffic.json")))
-            if list(tr["shape"]) == [shape[0], shape[1], shape[2]]:
-                traffic = tr["traffic_bytes"]
-        except Exception:
-            pass
+        traffic, traffic_file = offline_traffic("gauss_traffic", shape)
         roofline = {"bound": "hbm", "kernel": "gauss_fused_kernel<H=5> (separable 3-D Gaussian, sigma=2)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "traffic_unit": "bytes per launch, measured OFFLINE (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE in separate passes, "
-                                    "profiles/r01_gauss_traffic.json), not in this run",
+                                    "%s), not in this run" % traffic_file,
                     "algorithmic_bytes": 8 * nv,
                     "ms_per_launch": round(g_ms, 4), "voxels_per_launch": nv,
                     "note": "exact mul+add arithmetic (no FMA) makes this kernel VALU-bound, see DESIGN.md"}
@@ -299,13 +307,7 @@ def main():
             torch.cuda.synchronize()
         p_ms = e0.elapsed_time(e1) / reps / 3.0
         p_ach = 8.0 * nv / (p_ms * 1e-3) / 1e9
-        p_traffic = None   # PMC bytes per launch, average of the three passes (profiles/r01_gauss_pass_traffic.json)
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_gauss_pass_traffic.json")))
-            if list(tr["shape"]) == [shape[0], shape[1], shape[2]]:
-                p_traffic = tr["traffic_bytes"]
-        except Exception:
-            pass
+        p_traffic, _ = offline_traffic("gauss_pass_traffic", shape)   # average of the three passes
         roofline_pass = {"bound": "hbm", "kernel": "conv_march_kernel<5> (Z, Y) / conv_row_kernel<5> (X): one 1-D pass of "
                                                    "the separable Gaussian, sigma=2",
                          "achieved": round(p_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -330,13 +332,7 @@ def main():
         torch.cuda.synchronize()
         tv_ms = e0.elapsed_time(e1)
         votes = float(n_salient) * n_taps
-        tv_traffic = None   # HBM bytes per launch from PMC counters, measured offline (profiles/r01_tv_traffic.json)
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_tv_traffic.json")))
-            if list(tr["shape"]) == [shape[0], shape[1], shape[2]]:
-                tv_traffic = tr["traffic_bytes"]
-        except Exception:
-            pass
+        tv_traffic, tv_traffic_file = offline_traffic("tv_traffic", shape)
         tv_tflops = 45.0 * votes / (tv_ms * 1e-3) / 1e12
         roofline_tv = {"bound": "valu", "kernel": "tv_tiled_kernel (dense stick tensor voting, sigma_tv=8.66, h=12)",
                        "achieved": round(tv_tflops, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tv_tflops / 157.3, 4),
@@ -344,7 +340,7 @@ def main():
                        "flop_per_vote": 45, "salient_senders": n_salient, "nonzero_taps": n_taps,
                        "algorithmic_bytes": 40 * nv, "hbm_achieved_gbs": round(40.0 * nv / (tv_ms * 1e-3) / 1e9, 1),
                        "hbm_frac": round(40.0 * nv / (tv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                       "traffic_unit": "bytes per launch, measured OFFLINE for the round-1 kernel (profiles/r01_tv_traffic.json)",
+                       "traffic_unit": "bytes per launch, measured OFFLINE (%s), not in this run" % tv_traffic_file,
                        "note": "peak = nominal FP32 vector rate, which counts an FMA as 2 flop; the reference's operation order "
                                "forbids FMA, so the reachable rate is the 70 T scalar lane-operations/s the VALU issues "
                                "(profiles/r02_microbench_valu.txt): 32 of them per vote, DESIGN.md 4.2"}

@@ -65,8 +65,8 @@ int visfd_hip_abi_version(void);   /* 5: entry points only get added between ver
  *   gauss_3pass      1: the separable filter always takes its three single-axis passes
  *   gauss_wg_per_cu  workgroups per CU the single-sweep filter cuts the volume into (default 2)
  *   tv_dense         1: tensor voting by the baseline kernel
- *   tv_zrun          receiver planes per unit of work (default 32);  tv_group: sender planes per LDS group
- *   tv_no_replay     1: no scratch rings (every sender plane is compacted from the volume)
+ *   tv_zrun          receiver planes per unit of work (default 32)
+ *   tv_no_replay     1: every sender plane is listed again for every receiver plane (no reuse within a run)
  *   tv_max_wg        cap on the number of persistent workgroups (tests: forces many units of work per workgroup)
  *   blob_test_cap    tests: capacity the pipelined blob scan pretends to have (exercises its overflow path)
  *   gauss_cfg, debug development aids */

@@ -468,7 +468,7 @@ def test_tensor_voting_unit_shapes_agree(ctx, oracle, monkeypatch):
     want = oracle.tv_dense_stick(sal, dirs, 3.0, 4, 2.0 ** 0.5)
     want_m = oracle.tv_dense_stick(sal, dirs, 3.0, 4, 2.0 ** 0.5, mask, mask)
     for opts in ({}, {"tv_zrun": 1}, {"tv_zrun": 5}, {"tv_no_replay": 1}, {"tv_max_wg": 3}, {"tv_max_wg": 3, "tv_zrun": 1},
-                 {"tv_max_wg": 2, "tv_zrun": 5}, {"tv_max_wg": 1, "tv_no_replay": 1}, {"tv_group": 2, "tv_max_wg": 5}):
+                 {"tv_max_wg": 2, "tv_zrun": 5}, {"tv_max_wg": 1, "tv_no_replay": 1}, {"tv_zrun": 2, "tv_max_wg": 5}):
         with ctx.options(**opts):
             assert_bits_equal(ctx.tv_dense_stick(sal, dirs, 3.0, 4, 2.0 ** 0.5), want, "tensor %s" % opts)
             assert_bits_equal(ctx.tv_dense_stick(sal, dirs, 3.0, 4, 2.0 ** 0.5, mask, mask), want_m, "masked tensor %s" % opts)

@@ -66,7 +66,7 @@ enum Mode { MUL, ADD, FMA, MULADD, MUL_E64, PKMUL, PKFMA, MUL_SGPR, CHAIN1, CHAI
             MUL_F64, FMA_F64, ADD_F64, VOTE_LDS,
             MUL_INLINE, MUL_LITERAL, ADD_SGPR, MUL_SGPR_E64, FMAC, DOT4_ONLY, ALIGNBIT_ONLY, FFBL, LSHL_ADD, CMP_VCC, CNDMASK,
             SUB_INLINE, MOV_DPP, ADD_DPP, MAD_U24, ADD_U32, BPERMUTE, SWIZZLE, PERM, BFE, MAX3, READFIRSTLANE, PKADD,
-            BANK_SAME, BANK_DIFF, BANK_MIX, NMODES };
+            BANK_SAME, BANK_DIFF, BANK_MIX, MUL_EXEC_LO32, MUL_EXEC_HI32, MUL_EXEC_LO16, MUL_EXEC_ALT, NMODES };
 static const char* mode_name[NMODES] = {
     "v_mul_f32 (16 independent)", "v_add_f32 (16 independent)", "v_fma_f32 (16 independent)", "v_mul_f32/v_add_f32 alternating",
     "v_mul_f32_e64 (VOP3 encoding)", "v_pk_mul_f32 (2 lanes-ops each)", "v_pk_fma_f32 (2 fma each)", "v_mul_f32 SGPR operand",
@@ -78,11 +78,13 @@ static const char* mode_name[NMODES] = {
     "v_sub_f32 inline constant 1.0", "v_mov_b32_dpp row_shr:1", "v_add_f32_dpp quad_perm", "v_mad_u32_u24", "v_add_u32", "ds_bpermute_b32",
     "ds_swizzle_b32", "v_perm_b32", "v_bfe_u32", "v_max3_f32", "v_readfirstlane_b32", "v_pk_add_f32 (2 lane-ops each)",
     "v_add_f32 vD, vA, vB: A, B, D all = 0 mod 4", "v_add_f32 vD, vA, vB: A, B, D in three banks (mod 4)",
-    "v_mul/v_add pairs, sources A = 0, B = 1 mod 4, 2 mod 4 dest"};
+    "v_mul/v_add pairs, sources A = 0, B = 1 mod 4, 2 mod 4 dest",
+    "v_mul_f32 with exec = lanes 0-31 only", "v_mul_f32 with exec = lanes 32-63 only", "v_mul_f32 with exec = lanes 0-15 only",
+    "v_mul_f32 with exec = every other lane"};
 // lane-operations per instruction (packed = 2) and instructions per loop trip
-static const int mode_ops[NMODES] = {1, 1, 1, 1, 1, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,  1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1};
+static const int mode_ops[NMODES] = {1, 1, 1, 1, 1, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,  1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1};
 static const int mode_inst[NMODES] = {256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 128, 128, 128, 280,
-                                      256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256};
+                                      256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256};
 
 struct Stamp { unsigned long long c0, c1, r0, r1; unsigned hwid, pad; };
 
@@ -195,6 +197,13 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 8)
       }
     }
 #define GEN(M, OP, A, B) else if (MODE == M) { _Pragma("unroll") for (int u = 0; u < 16; u++) asm volatile(R16(OP) : X16 : A, B : "vcc", "s20"); }
+#define GENX(M, LO, HI) else if (MODE == M) { _Pragma("unroll") for (int u = 0; u < 16; u++) asm volatile( \
+      "s_mov_b64 s[20:21], exec\n s_mov_b32 exec_lo, " LO "\n s_mov_b32 exec_hi, " HI "\n" R16(OP_MUL) "s_mov_b64 exec, s[20:21]\n" \
+      : X16 : "v"(a), "v"(b) : "s20", "s21"); }
+    GENX(MUL_EXEC_LO32, "-1", "0")
+    GENX(MUL_EXEC_HI32, "0", "-1")
+    GENX(MUL_EXEC_LO16, "0xffff", "0")
+    GENX(MUL_EXEC_ALT, "0x55555555", "0x55555555")
     GEN(MUL_INLINE, OP_MULINL, "v"(a), "v"(b))
     GEN(MUL_LITERAL, OP_MULLIT, "v"(a), "v"(b))
     GEN(ADD_SGPR, OP_ADDS, "s"(a), "s"(b))
@@ -309,7 +318,7 @@ int main(int argc, char** argv) {
                         k<CHAIN4>, k<DOT4>, k<INT_AND>, k<MUL_F64>, k<FMA_F64>, k<ADD_F64>, k<VOTE_LDS>,
                         k<MUL_INLINE>, k<MUL_LITERAL>, k<ADD_SGPR>, k<MUL_SGPR_E64>, k<FMAC>, k<DOT4_ONLY>, k<ALIGNBIT_ONLY>, k<FFBL>,
                         k<LSHL_ADD>, k<CMP_VCC>, k<CNDMASK>, k<SUB_INLINE>, k<MOV_DPP>, k<ADD_DPP>, k<MAD_U24>, k<ADD_U32>, k<BPERMUTE>,
-                        k<SWIZZLE>, k<PERM>, k<BFE>, k<MAX3>, k<READFIRSTLANE>, k<PKADD>, k<BANK_SAME>, k<BANK_DIFF>, k<BANK_MIX>};
+                        k<SWIZZLE>, k<PERM>, k<BFE>, k<MAX3>, k<READFIRSTLANE>, k<PKADD>, k<BANK_SAME>, k<BANK_DIFF>, k<BANK_MIX>, k<MUL_EXEC_LO32>, k<MUL_EXEC_HI32>, k<MUL_EXEC_LO16>, k<MUL_EXEC_ALT>};
   const int m0 = argc > 2 ? atoi(argv[2]) : 0;
   for (int m = m0; m < NMODES; m++)
     for (int w : {1, 2, 4, 8}) run(m, fns[m], w, num_cus, out, dstamps, f);

@@ -20,6 +20,13 @@ if len(sys.argv) > 2 and sys.argv[2] == "synth":
 else:
     src = torch.randn((n, n, n), device=dev, generator=g) * 100 + 1000
 sal = torch.empty_like(src)
+if n >= 512:   # calibration launches of known traffic for FETCH_SIZE / WRITE_SIZE (see tools/pmc_traffic.py)
+    import numpy as np
+    torch.cuda.synchronize()
+    ctx.apply_threshold_dev(src, -np.inf)
+    torch.cuda.synchronize()
+    ctx.apply_threshold_dev(sal, np.inf)
+    torch.cuda.synchronize()
 dirs = torch.empty((3, n, n, n), device=dev)
 ctx.ridge_saliency_dev(src, sal, dirs, 1.732, 2.6482, 1)
 ctx.threshold_fraction_dev(sal, 0.05)

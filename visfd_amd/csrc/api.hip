@@ -249,7 +249,7 @@ struct OptionDesc { const char* name; int visfd_hip_options::*i; int64_t visfd_h
 const OptionDesc kOptions[] = {
     {"gauss_3pass", &visfd_hip_options::gauss_3pass, nullptr},   {"gauss_cfg", &visfd_hip_options::gauss_cfg, nullptr},
     {"gauss_wg_per_cu", &visfd_hip_options::gauss_wg_per_cu, nullptr}, {"tv_dense", &visfd_hip_options::tv_dense, nullptr},
-    {"tv_group", &visfd_hip_options::tv_group, nullptr},         {"tv_zrun", &visfd_hip_options::tv_zrun, nullptr},
+    {"tv_zrun", &visfd_hip_options::tv_zrun, nullptr},
     {"tv_no_replay", &visfd_hip_options::tv_no_replay, nullptr}, {"tv_max_wg", &visfd_hip_options::tv_max_wg, nullptr},
     {"blob_test_cap", nullptr, &visfd_hip_options::blob_test_cap}, {"debug", &visfd_hip_options::debug, nullptr},
 };

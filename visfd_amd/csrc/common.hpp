@@ -62,9 +62,8 @@ struct visfd_hip_options {
   int gauss_cfg = 0;        // development builds: alternative tilings of the single-sweep filter
   int gauss_wg_per_cu = 2;  // workgroups per CU the single-sweep filter cuts the volume into
   int tv_dense = 0;         // 1: tensor voting by the baseline kernel (csrc/tv.hip)
-  int tv_group = 0;         // sender planes per LDS group (0: default)
   int tv_zrun = 0;          // receiver planes per unit of work (0: default)
-  int tv_no_replay = 0;     // 1: compact every sender plane from the volume (no scratch rings)
+  int tv_no_replay = 0;     // 1: list every sender plane again for every receiver plane (nothing reused from the rings)
   int tv_max_wg = 0;        // cap on the persistent grid (0: fill the chip); tests use it to make workgroups claim many units
   int64_t blob_test_cap = 0;   // pretend the pipelined blob scan's buffers hold this many entries (0: off)
   int debug = 0;

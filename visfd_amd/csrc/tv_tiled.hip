@@ -8,28 +8,28 @@
 //   * workgroups are PERSISTENT: as many as the chip holds, each claiming units of work -- a 16 x 16 tile of receivers
 //     (one per thread; each wave an 8 x 8 patch) over a run of 32 consecutive receiver planes -- from a global counter
 //     until it is exhausted (a plain grid left wave slots empty on volumes whose sender density varies, see the kernel);
-//   * for a receiver plane z, sender planes are visited from z+h down to z-h (= jz ascending).  The salient, unmasked
-//     senders of the (16+2h)^2 region of a plane -- saliency, normal, distance-test operand, table offset, mask value --
-//     are listed in LDS IN VOTE ORDER (ordered block-wide prefix sum: deterministic).  A plane is read from the volume
-//     and compacted only the first time the run meets it; its list then lives in a per-workgroup scratch ring in global
-//     memory and is replayed for the next 2h receiver planes;
+//   * LISTING: the salient, unmasked senders of the (16+2h)^2 region of a sender plane -- saliency, normal, position
+//     bytes, table offset, mask value: 32 bytes -- are compacted IN VOTE ORDER (ordered, ballot-based prefix sums:
+//     deterministic) into a per-workgroup ring of 2h+1 planes in global memory, once per unit and plane: consecutive
+//     receiver planes share 2h of their 2h+1 sender planes, so all but the first plane of a run list one new plane;
+//   * for a receiver plane z, sender planes are visited from z+h down to z-h (= jz ascending): the plane's list is
+//     read back from the ring (L2) into LDS together with the (2h+1)^2 slice of the vote table for that jz;
 //   * the SWEEP: every wave walks the list in order.  A sender is tested against the wave's 64 receivers --
 //     jx^2+jy^2+jz^2 <= h^2 as ONE v_dot4_i32_i8 on signed bytes (see the kernel), an exact superset of the table's
 //     spherical support -- and voted at once by the lanes it reaches, under their execution mask.  The sender's data
 //     come from uniform-address (broadcast) LDS reads: no bank conflicts, no per-lane bookkeeping;
-//   * weights and unit displacements come from the LDS copy of the (2h+1)^2 table slice of the sender plane (w, rhat_x,
-//     rhat_y, rhat_z as one float4, signs included).  The table index is linear in j = receiver - sender, so the byte
-//     address of a vote's table entry is  R(lane) - E(sender):  one subtraction per vote.
+//   * weights and unit displacements come from the LDS copy of the table slice (w, rhat_x, rhat_y, rhat_z as one
+//     float4, signs included).  The table index is linear in j = receiver - sender, so the byte address of a vote's
+//     table entry is  R(lane) - E(sender):  one subtraction per vote.
 //
 // Order of accumulation per receiver: jz ascending (plane order), then jy, jx ascending, exactly the reference's; each
 // vote is the same chain of float multiplies and adds (no FMA), so tensors are bit-identical to the CPU path for
 // angular exponents 2 and 4.  A tap of zero weight on the rim of the support votes +-0, which leaves the sums unchanged.
 //
-// Why a sweep and not per-lane hit lists (round 1): measured on MI355X (profiles/r02_tv_design.txt), the per-lane scheme
-// spent 46 VALU instructions per vote slot (a third of them v_ffbl/v_lshl_add/v_cmp and friends, which issue at half
-// rate on gfx950) on slots that were 64-70 % full, and its random 32-byte entry gathers made LDS bank conflicts a
-// quarter of all CU cycles; the sweep spends 35 per voted sender at 45 % lane use but needs 20 KB of LDS and 64 VGPRs,
-// i.e. eight workgroups per CU instead of four, and that occupancy is what the VALU needs to stay busy here.
+// Listing and sweeping are separate phases that share no registers (round 2): the first sweep kernel compacted planes
+// straight into the LDS list from inside the plane loop, and the state of that code -- seven region voxels per thread,
+// five buffer descriptors -- stayed live across the sweeps: 140 VGPRs and 130 SGPRs spilled to scratch memory, whose
+// loads and stores were most of the kernel's 2 TB of memory traffic per 1024^3 launch (profiles/r02_tv_design.txt).
 #include <vector>
 
 #include "common.hpp"
@@ -39,16 +39,14 @@ namespace vh {
 namespace {
 
 constexpr int NT = 256;
+constexpr int NW = NT / 64;
 constexpr int TILE = 16;
-constexpr int VPT = 7;               // region voxels per thread per band
-constexpr int BAND_CAP = NT * VPT;   // 1792 region voxels per band
 #ifndef VH_TV_CAP
 #define VH_TV_CAP 256
 #endif
-constexpr int CAP = VH_TV_CAP;       // list entries held in LDS between flushes
+constexpr int CAP = VH_TV_CAP;       // list entries held in LDS per sweep (one per thread)
+static_assert(CAP == NT, "the replay loads one entry per thread");
 constexpr int RING_BYTES = 32;       // bytes per entry of the scratch rings
-constexpr int MAX_GROUP = 4;         // sender planes whose slices may share LDS (default 1, option tv_group)
-constexpr int SLICE_BYTES_MAX = 48 * 1024;
 constexpr unsigned OOB = 0x7ffffff0u;  // byte offset beyond any plane descriptor: reads give 0
 
 __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
@@ -70,12 +68,13 @@ struct TiledParams {
   int nx, ny, nz;
   int z_out0, z_out1;    // receiver planes [z_out0, z_out1)
   int h;                 // window halfwidth
-  int rw, rh;            // region width/height = TILE + 2h
-  int band_rows, nbands;
-  int group;             // planes per group (slices resident in LDS)
+  int rw;                // region width = height = TILE + 2h
+  int rw_magic;          // q / rw == (q * rw_magic) >> 20 for every region position q (checked by the launcher)
+  int nchunk;            // 64-voxel chunks of the region per wave
   int tiles_x, tiles_y;
   int exponent, curves;
   int zrun;              // receiver planes per unit of work
+  int relist;            // 1: list every sender plane for every receiver plane (option tv_no_replay; tests)
 };
 
 __device__ __forceinline__ void acc(float& t, float x) {
@@ -130,7 +129,7 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
                 const float* __restrict__ mask_src, const float* __restrict__ mask_dst,
                 const float4* __restrict__ table /* [(2h+1)^3] : w, rhat_x, rhat_y, rhat_z at j */,
                 TiledParams p, unsigned* __restrict__ tile_counter, unsigned ntiles,
-                unsigned char* __restrict__ scratch /* per-workgroup rings of compacted sender planes, or null */) {
+                unsigned char* __restrict__ scratch /* per-workgroup rings of compacted sender planes */) {
   // Static LDS (compile-time addresses fold into the DS instructions' immediate offsets):
   //   l_ent[e]  float4 {sal, n0, n1, n2} of list entry e
   //   l_pos[e]  {distance-test operand, table offset E}: packed signed bytes (e'x, e'y, -(|e'|^2 >> 7), |e'|^2 & 127)
@@ -141,305 +140,246 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
   __shared__ __attribute__((aligned(16))) float4 l_ent[CAP];
   __shared__ __attribute__((aligned(16))) uint2 l_pos[CAP + 8];
   __shared__ float l_mv[MASKED_SRC ? CAP : 1];
-  __shared__ int wave_tot[2][NT / 64];
+  __shared__ int wave_tot[2][NW];
   __shared__ unsigned claimed_tile;
-  __shared__ int plane_cnt[84];              // entries per cached sender plane, [2h+1] (h <= 40)
-  // dynamic LDS: the table slices of the current plane group, [group][(2h+1)^2] float4
+  __shared__ int plane_cnt[84];              // entries per ring slot, [2h+1] (h <= 40)
+  // dynamic LDS: the table slice of the current sender plane, [(2h+1)^2] float4
   extern __shared__ __attribute__((aligned(16))) unsigned char slices[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
+  const int h = p.h;
+  const int S = 2 * h + 1;       // table row length = planes per ring
+  const int nsl = S * S;         // float4 entries per slice
+  const int R = p.rw * p.rw;     // region positions per plane
+  const i64 plane = (i64)p.nx * p.ny;
+  const i64 nvox = plane * p.nz;
+  const int plane_bytes = (int)(plane * 4);
+  const size_t plane_stride = (size_t)R * RING_BYTES;
+  unsigned char* const ring = scratch + (size_t)blockIdx.x * plane_stride * S;
+  int npar = 0;                  // parity of the wave-total buffers
 
-  // ---- persistent workgroups: tiles are claimed from a global counter ---------------------------------------
-  // The time a tile takes follows the local density of senders (membranes: tens of times the average), and the
+  // ---- persistent workgroups: units are claimed from a global counter ---------------------------------------
+  // The time a unit takes follows the local density of senders (membranes: tens of times the average), and the
   // hardware hands out workgroups of a plain grid in order, round-robin over the XCDs: on membrane-rich volumes
   // that left a fifth of the wave slots empty (rocprofv3 OccupancyPercent 40 of 50, VALUBusy 80 %; uniform
   // noise: 47.5 and 100 %).  Here the grid is just large enough to fill the chip and every workgroup keeps
-  // claiming the next tile until the counter passes the last one -- an exit every wave reaches.
+  // claiming the next unit until the counter passes the last one -- an exit every wave reaches.
   for (;;) {
-  if (tid == 0) claimed_tile = atomicAdd(tile_counter, 1u);
-  __syncthreads();   // also: the previous tile's sweeps are complete
-  unsigned b = claimed_tile;
-  __syncthreads();   // everyone has read it before thread 0 claims again
-  if (b >= ntiles) break;
-  const int tile_x = b % p.tiles_x;
-  b /= p.tiles_x;
-  const int tile_y = b % p.tiles_y;
-  // a unit of work: one 16 x 16 tile over a run of consecutive receiver planes [z_run0, z_run1)
-  const int z_run0 = p.z_out0 + (int)(b / p.tiles_y) * p.zrun;
-  const int z_run1 = min(z_run0 + p.zrun, p.z_out1);
-  const int x0 = tile_x * TILE, y0 = tile_y * TILE;
-  const int h = p.h;
-  const int S = 2 * h + 1;       // table row length
-  const int nsl = S * S;         // float4 entries per slice
-  const i64 plane = (i64)p.nx * p.ny;
-  const i64 nvox = plane * p.nz;
+    if (tid == 0) claimed_tile = atomicAdd(tile_counter, 1u);
+    __syncthreads();   // also: the previous unit's sweeps are complete
+    unsigned b = claimed_tile;
+    __syncthreads();   // everyone has read it before thread 0 claims again
+    if (b >= ntiles) break;
+    const int tile_x = b % p.tiles_x;
+    b /= p.tiles_x;
+    const int tile_y = b % p.tiles_y;
+    // a unit of work: one 16 x 16 tile over a run of consecutive receiver planes [z_run0, z_run1)
+    const int z_run0 = p.z_out0 + (int)(b / p.tiles_y) * p.zrun;
+    const int z_run1 = min(z_run0 + p.zrun, p.z_out1);
+    const int x0 = tile_x * TILE, y0 = tile_y * TILE;
 
-  // receiver of this thread: wave w owns the 8x8 patch (w&1, w>>1).  Region-relative coordinates:
-  // the sender region starts at (x0-h, y0-h, rz-h), so the receiver sits at (lx+h, ly+h, h).
-  const int lx = (wave & 1) * 8 + (lane & 7), ly = (wave >> 1) * 8 + (lane >> 3);
-  const int rx = x0 + lx, ry = y0 + ly;
-  const bool r_in = rx < p.nx && ry < p.ny;
-  i64 rc = 0;             // this thread's receiver voxel and whether it takes votes: set per receiver plane
-  bool r_live = false;
-  const int h2 = h * h;
-  // Distance test  |r - e|^2 <= h^2  as ONE dot product per (receiver, sender): with coordinates
-  // relative to the tile centre (r' = (lx-8, ly-8, 0), e' = (ex-h-8, ey-h-8, ez-h)) and
-  // |e'|^2 = 128 q + m,
-  //   |r'-e'|^2 - h^2 - 1  =  (-2r'x, -2r'y, -128, 1) . (e'x, e'y, -q, m)  +  (|r'|^2 - h^2 - 1),
-  // every factor a signed byte (|e'| <= h+8 <= 48, so q <= 54), the last term a per-lane accumulator.
-  const int rpx = lx - 8, rpy = ly - 8;
-  const unsigned recv4 = (unsigned)((-2 * rpx) & 0xff) | ((unsigned)((-2 * rpy) & 0xff) << 8) | (0x80u << 16) | (1u << 24);
-  const int recv_c = rpx * rpx + rpy * rpy - h2 - 1;
-  constexpr unsigned NEVER_HIT = 0x009c0000u;   // operand whose dot product is positive for every receiver (-128 * -100)
+    // receiver of this thread: wave w owns the 8x8 patch (w&1, w>>1).  Region-relative coordinates:
+    // the sender region starts at (x0-h, y0-h, rz-h), so the receiver sits at (lx+h, ly+h, h).
+    const int lx = (wave & 1) * 8 + (lane & 7), ly = (wave >> 1) * 8 + (lane >> 3);
+    const int rx = x0 + lx, ry = y0 + ly;
+    const bool r_in = rx < p.nx && ry < p.ny;
+    // Distance test  |r - e|^2 <= h^2  as ONE dot product per (receiver, sender): with coordinates
+    // relative to the tile centre (r' = (lx-8, ly-8, 0), e' = (ex-h-8, ey-h-8, ez-h)) and
+    // |e'|^2 = 128 q + m,
+    //   |r'-e'|^2 - h^2 - 1  =  (-2r'x, -2r'y, -128, 1) . (e'x, e'y, -q, m)  +  (|r'|^2 - h^2 - 1),
+    // every factor a signed byte (|e'| <= h+8 <= 48, so q <= 54), the last term a per-lane accumulator.
+    const int rpx = lx - 8, rpy = ly - 8;
+    const unsigned recv4 = (unsigned)((-2 * rpx) & 0xff) | ((unsigned)((-2 * rpy) & 0xff) << 8) | (0x80u << 16) | (1u << 24);
+    const int recv_c = rpx * rpx + rpy * rpy - h * h - 1;
+    constexpr unsigned NEVER_HIT = 0x009c0000u;   // operand whose dot product is positive for every receiver (-128 * -100)
+    // (jy+h)*S + (jx+h) with jx = lx+h-ex, jy = ly+h-ey  =  [(ly+2h)*S + lx+2h] - [ey*S + ex]
+    const unsigned r16s = lds_addr(slices) + (unsigned)(16 * ((ly + 2 * h) * S + lx + 2 * h));
+    const unsigned ent_base = lds_addr(l_ent);
 
-  // (jy+h)*S + (jx+h) with jx = lx+h-ex, jy = ly+h-ey  =  [(ly+2h)*S + lx+2h] - [ey*S + ex]
-  const unsigned r16s = lds_addr(slices) + (unsigned)(16 * ((ly + 2 * h) * S + lx + 2 * h));
-  const unsigned ent_base = lds_addr(l_ent);
-
-  float T[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-
-  // region voxels owned by this thread inside a band: VPT consecutive positions, (row << 8) | column
-  int rc_[VPT];
-#pragma unroll
-  for (int v = 0; v < VPT; v++) {
-    const int q = tid * VPT + v;
-    const int er = q / p.rw;
-    rc_[v] = (er << 8) | (q - er * p.rw);
-  }
-  // Region reads are buffer loads with hardware range checking: a per-plane descriptor (scalar) plus
-  // a 32-bit byte offset per voxel; voxels outside the image or the band use an out-of-range offset
-  // and read as 0.0f (= not salient) without branches.
-  const int plane_bytes = (int)(plane * 4);
-  auto plane_rsrc = [&](const float* base, int sz) {
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (i64)sz * plane), 0, plane_bytes, 0x00020000);
-  };
-  auto voff_of = [&](int v, int row0, int rows) -> unsigned {
-    const int er = rc_[v] >> 8, ec = rc_[v] & 0xff;
-    const int sx = x0 - h + ec, sy = y0 - h + row0 + er;
-    const bool ok = er < rows && sx >= 0 && sx < p.nx && sy >= 0 && sy < p.ny;
-    return ok ? (unsigned)(sy * p.nx + sx) * 4u : OOB;
-  };
-  auto fetch = [&](int sz, int band, float out[VPT]) {
-    const int row0 = band * p.band_rows;
-    const int rows = min(p.band_rows, p.rh - row0);
-    const __amdgpu_buffer_rsrc_t rs = plane_rsrc(sal, sz);
-#pragma unroll
-    for (int v = 0; v < VPT; v++) {
-      const unsigned off = voff_of(v, row0, rows);
-      float s = buf_load(rs, off);
-      if (MASKED_SRC) {
-        const float m = buf_load(plane_rsrc(mask_src, sz), off);
-        if (m == 0.0f) s = 0.0f;
+    // ---- LISTING: sender plane sz of this tile's region into its ring slot, in vote order -------------------
+    // Vote order inside a plane is DESCENDING region position (jy, jx ascending = sender y, x descending).  Wave w
+    // owns the positions [w, w+1) * 64 nchunk, lane l of chunk j the position 64 (w nchunk + j) + l: two passes over
+    // the saliencies (the second one hits in L1/L2) instead of state kept in registers.  Region reads are buffer loads
+    // with hardware range checking: a per-plane descriptor (scalar) plus a 32-bit byte offset per voxel; positions
+    // outside the image or the region use an out-of-range offset and read as 0.0f (= not salient) without branches.
+    auto list_plane = [&](int sz) {
+      const __amdgpu_buffer_rsrc_t rs =
+          __builtin_amdgcn_make_buffer_rsrc((void*)(sal + (i64)sz * plane), 0, plane_bytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)((MASKED_SRC ? mask_src : sal) + (i64)sz * plane), 0, plane_bytes, 0x00020000);
+      const int q0 = wave * p.nchunk * 64 + lane;
+      auto voff_of = [&](int q, int& ex, int& ey) -> unsigned {
+        ey = (int)(((unsigned)q * (unsigned)p.rw_magic) >> 20);
+        ex = q - ey * p.rw;
+        const int sx = x0 - h + ex, sy = y0 - h + ey;
+        const bool ok = q < R && sx >= 0 && sx < p.nx && sy >= 0 && sy < p.ny;
+        return ok ? (unsigned)(sy * p.nx + sx) * 4u : OOB;
+      };
+      auto salient = [&](unsigned off) -> float {
+        float s = buf_load(rs, off);
+        if (MASKED_SRC) {
+          if (buf_load(rm, off) == 0.0f) s = 0.0f;
+        }
+        return s;
+      };
+      int cnt = 0;
+#pragma unroll 1
+      for (int j = 0; j < p.nchunk; j++) {
+        int ex, ey;
+        const float s = salient(voff_of(q0 + 64 * j, ex, ey));
+        cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(s != 0.0f));
       }
-      out[v] = s;
-    }
-  };
+      const int par = (npar++) & 1;
+      if (lane == 0) wave_tot[par][wave] = cnt;
+      __syncthreads();
+      int running = 0, total = 0;   // entries at higher positions than this wave's; entries of the plane
+#pragma unroll
+      for (int w = 0; w < NW; w++) {
+        const int t = wave_tot[par][w];
+        running += (w > wave) ? t : 0;
+        total += t;
+      }
+      running = __builtin_amdgcn_readfirstlane(running);
+      const int slot = sz % S;
+      unsigned char* const ring_plane = ring + (size_t)slot * plane_stride;
+      if (cnt > 0) {
+        const __amdgpu_buffer_rsrc_t rd0 =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(dir + (i64)sz * plane), 0, plane_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rd1 =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(dir + nvox + (i64)sz * plane), 0, plane_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rd2 =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(dir + 2 * nvox + (i64)sz * plane), 0, plane_bytes, 0x00020000);
+#pragma unroll 1
+        for (int j = p.nchunk - 1; j >= 0; j--) {
+          int ex, ey;
+          const unsigned off = voff_of(q0 + 64 * j, ex, ey);
+          const float s = salient(off);
+          const bool f = s != 0.0f;
+          const unsigned long long bal = __builtin_amdgcn_ballot_w64(f);
+          if (bal == 0ull) continue;   // uniform
+          const int tb = __builtin_popcountll(bal);
+          const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+          if (f) {
+            const int idx = running + (tb - below - 1);      // salient lanes above this one come first
+            float4 a = make_float4(s, 0.0f, 0.0f, 0.0f);
+            if (MODE != 3) { a.y = buf_load(rd0, off); a.z = buf_load(rd1, off); a.w = buf_load(rd2, off); }
+            unsigned mv = 0u;
+            if (MASKED_SRC) mv = __float_as_uint(buf_load(rm, off));
+            const int epx = ex - h - 8, epy = ey - h - 8;
+            unsigned char* dst_e = ring_plane + (size_t)idx * RING_BYTES;
+            *reinterpret_cast<float4*>(dst_e) = a;
+            *reinterpret_cast<uint4*>(dst_e + 16) =
+                make_uint4((unsigned)(epx & 0xff) | ((unsigned)(epy & 0xff) << 8), (unsigned)(epx * epx + epy * epy),
+                           (unsigned)(16 * (ey * S + ex)), mv);
+          }
+          running += tb;
+        }
+      }
+      if (tid == 0) plane_cnt[slot] = total;
+    };
 
-  // ---- the sweep over list entries [0, n), in vote order ----------------------------------------------------
-  // Receivers that take no votes never hit: their accumulator operand is a large positive number.
-  auto sweep = [&](int n) {
-    const int recv_c_live = r_live ? recv_c : 0x100000;
-    // the table entry is requested together with the sender's own data: its address needs only E, which came with
-    // the batch
-    auto vote_one = [&](int s, unsigned e16) {
-      const f4v tw = *lds_ptr<f4v>(r16s - e16);
-      float fv = tw.x;
-      if (MASKED_SRC) fv = fv * l_mv[s];    // fv = w * mask value first (feature.hpp:2262-2275), then sal * fv
-      if (MODE == 3) {
-        acc(T[0], fv);                      // "denominator += filter_val" (feature.hpp:2376-2377)
-      } else {
-        const f4v d = *lds_ptr<f4v>(ent_base + ((unsigned)s << 4));
-        float bse, m0, m1, m2;
-        vote_dir<MODE>(d.x, fv, tw.y, tw.z, tw.w, d.y, d.z, d.w, p.exponent, p.curves, bse, m0, m1, m2);
-        vote_acc(T, bse, m0, m1, m2);
+    float T[6];
+    int recv_c_live = 0x100000;   // receivers that take no votes never hit: their accumulator operand is large and positive
+
+    // ---- the SWEEP over list entries [0, n), in vote order --------------------------------------------------
+    auto sweep = [&](int n) {
+      // the table entry is requested together with the sender's own data: its address needs only E, which came with
+      // the batch
+      auto vote_one = [&](int s, unsigned e16) {
+        const f4v tw = *lds_ptr<f4v>(r16s - e16);
+        float fv = tw.x;
+        if (MASKED_SRC) fv = fv * l_mv[s];    // fv = w * mask value first (feature.hpp:2262-2275), then sal * fv
+        if (MODE == 3) {
+          acc(T[0], fv);                      // "denominator += filter_val" (feature.hpp:2376-2377)
+        } else {
+          const f4v d = *lds_ptr<f4v>(ent_base + ((unsigned)s << 4));
+          float bse, m0, m1, m2;
+          vote_dir<MODE>(d.x, fv, tw.y, tw.z, tw.w, d.y, d.z, d.w, p.exponent, p.curves, bse, m0, m1, m2);
+          vote_acc(T, bse, m0, m1, m2);
+        }
+      };
+      // batches of four senders; the next batch is in flight while this one is tested and voted
+      const uint4* pq = reinterpret_cast<const uint4*>(l_pos);
+      uint4 qa = pq[0], qb = pq[1];
+      for (int s0 = 0; s0 < n; s0 += 4) {   // uniform
+        const uint4 ca = qa, cb = qb;
+        qa = pq[(s0 >> 1) + 2];
+        qb = pq[(s0 >> 1) + 3];
+        int d0, d1, d2, d3;
+        // four dots back to back: a dot result may be read by the VALU three instructions later at the earliest, and
+        // the compiler does not see hazards of instructions inside an asm block
+        asm("v_dot4_i32_i8 %0, %4, %6, %5\n\t"
+            "v_dot4_i32_i8 %1, %4, %7, %5\n\t"
+            "v_dot4_i32_i8 %2, %4, %8, %5\n\t"
+            "v_dot4_i32_i8 %3, %4, %9, %5"
+            : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
+            : "v"(recv4), "v"(recv_c_live), "v"(ca.x), "v"(ca.z), "v"(cb.x), "v"(cb.z));
+        if (d0 < 0) vote_one(s0, ca.y);
+        if (d1 < 0) vote_one(s0 + 1, ca.w);
+        if (d2 < 0) vote_one(s0 + 2, cb.y);
+        if (d3 < 0) vote_one(s0 + 3, cb.w);
       }
     };
-    // batches of four senders; the next batch is in flight while this one is tested and voted
-    const uint4* pq = reinterpret_cast<const uint4*>(l_pos);
-    uint4 qa = pq[0], qb = pq[1];
-    for (int s0 = 0; s0 < n; s0 += 4) {   // uniform
-      const uint4 ca = qa, cb = qb;
-      qa = pq[(s0 >> 1) + 2];
-      qb = pq[(s0 >> 1) + 3];
-      int d0, d1, d2, d3;
-      // four dots back to back: a dot result may be read by the VALU three instructions later at the earliest, and
-      // the compiler does not see hazards of instructions inside an asm block
-      asm("v_dot4_i32_i8 %0, %4, %6, %5\n\t"
-          "v_dot4_i32_i8 %1, %4, %7, %5\n\t"
-          "v_dot4_i32_i8 %2, %4, %8, %5\n\t"
-          "v_dot4_i32_i8 %3, %4, %9, %5"
-          : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
-          : "v"(recv4), "v"(recv_c_live), "v"(ca.x), "v"(ca.z), "v"(cb.x), "v"(cb.z));
-      if (d0 < 0) vote_one(s0, ca.y);
-      if (d1 < 0) vote_one(s0 + 1, ca.w);
-      if (d2 < 0) vote_one(s0 + 2, cb.y);
-      if (d3 < 0) vote_one(s0 + 3, cb.w);
-    }
-  };
 
-  // ---- the unit's receiver planes, bottom up --------------------------------------------------------------
-  // Consecutive receiver planes share 2h of their 2h+1 sender planes.  The compacted sender list of a plane
-  // (entries in vote order) is therefore written to a per-workgroup scratch ring in global memory when the plane
-  // is first met, and REPLAYED from there for the following receiver planes: only the plane rz+h is read from
-  // the volume and compacted per receiver plane (all 2h+1 for the first plane of the run).
-  // scratch entry (32 bytes): float4 {sal, n0, n1, n2} | ex + 256 ey | mask value | pad.  Ring slot of plane
-  // sz: sz mod (2h+1); cached planes: [cached_lo, cached_hi].
-  const int P = 2 * h + 1;
-  const size_t plane_stride = (size_t)p.rw * p.rh * RING_BYTES;
-  unsigned char* const ring = scratch ? scratch + (size_t)blockIdx.x * plane_stride * P : nullptr;
-  int cached_lo = 1, cached_hi = 0;     // empty
-  int npar = 0;                         // parity of the wave-total buffers
-  for (int rz = z_run0; rz < z_run1; rz++) {
-  rc = (i64)rz * plane + (i64)ry * p.nx + rx;
-  r_live = r_in && !(mask_dst && mask_dst[r_in ? rc : 0] == 0.0f);
+    // ---- the unit's receiver planes, bottom up ------------------------------------------------------------
+    int cached_lo = 1, cached_hi = 0;     // sender planes whose lists are in the ring (slot of plane sz: sz mod (2h+1))
+    for (int rz = z_run0; rz < z_run1; rz++) {
+      const int sz_hi = min(rz + h, p.nz - 1), sz_lo = max(rz - h, 0);
+      // the window holds at most 2h+1 planes, so a plane that enters it takes the slot of one that has left
+      for (int sz = sz_hi; sz >= sz_lo; sz--)   // uniform
+        if (p.relist || sz < cached_lo || sz > cached_hi) list_plane(sz);
+      cached_lo = sz_lo;
+      cached_hi = sz_hi;
+
+      const i64 rc = (i64)rz * plane + (i64)ry * p.nx + rx;
+      const bool r_live = r_in && !(mask_dst && mask_dst[r_in ? rc : 0] == 0.0f);
+      recv_c_live = r_live ? recv_c : 0x100000;
 #pragma unroll
-  for (int k = 0; k < 6; k++) T[k] = 0.0f;
-  const int sz_hi = min(rz + h, p.nz - 1), sz_lo = max(rz - h, 0);
-  const int nplanes = sz_hi - sz_lo + 1;
+      for (int k = 0; k < 6; k++) T[k] = 0.0f;
+      __syncthreads();   // ring entries and counts of this receiver plane are visible
 
-  int n_list = 0;         // entries currently in the LDS list
-  int ez_first = 0;       // region-relative z of the first plane of the current group
-  // list entry `slot`: sender at region position (ex, ey) of the plane at offset epz from the receivers' plane, table
-  // slice slot e16_plane / nsl of the group
-  auto put_entry = [&](int slot, const float4& a, int ex, int ey, int epz, int e16_plane, unsigned mv) {
-    l_ent[slot] = a;
-    const int epx = ex - h - 8, epy = ey - h - 8;
-    const int e2 = epx * epx + epy * epy + epz * epz;
-    const unsigned posw = (unsigned)(epx & 0xff) | ((unsigned)(epy & 0xff) << 8) | ((unsigned)((-(e2 >> 7)) & 0xff) << 16) |
-                          ((unsigned)(e2 & 127) << 24);
-    l_pos[slot] = make_uint2(posw, (unsigned)(16 * (ey * S + ex - e16_plane)));
-    if (MASKED_SRC) l_mv[slot] = __uint_as_float(mv);
-  };
-  auto flush = [&]() {
-    if (tid < 8) l_pos[n_list + tid] = make_uint2(NEVER_HIT, 0u);
-    __syncthreads();   // list complete
-    if (n_list > 0) sweep(n_list);
-    n_list = 0;
-    __syncthreads();   // everyone done reading before the list (or the slices) are refilled
-  };
-  for (int pl = 0; pl < nplanes; pl++) {                    // plane counter, 0 = z+h side
-    const int sz = sz_hi - pl;
-    const int ez = sz - (rz - h);                           // 0..2h
-    if (pl % p.group == 0) {
-      // previous group completely swept (n_list == 0, barrier at the end of flush):
-      // copy the table slices of this group's planes (plane s of the group: ez = ez_first - s, jz = h - ez)
-      ez_first = ez;
-      const int g_planes = min(p.group, nplanes - pl);
-      float4* sl4 = reinterpret_cast<float4*>(slices);
-      for (int i = tid; i < g_planes * nsl; i += NT) {
-        const int sidx = i / nsl, r = i - sidx * nsl;
-        const int jz = h - (ez_first - sidx);
-        sl4[i] = table[(i64)(jz + h) * nsl + r];
-      }
-    }
-    unsigned char* const ring_plane = ring ? ring + (size_t)(sz % P) * plane_stride : nullptr;
-    const int epz = ez - h;
-    const int e16_plane = (ez_first - ez) * nsl;
-
-    if (ring && sz >= cached_lo && sz <= cached_hi) {
-      // ---- replay the plane's compacted list from the scratch ring ---------------------------------------
-      const int cnt = plane_cnt[sz % P];
-      int done = 0;
-      while (done < cnt) {   // uniform
-        const int take = min(CAP - n_list, cnt - done);
-        for (int i = tid; i < take; i += NT) {
-          const unsigned char* src_e = ring_plane + (size_t)(done + i) * RING_BYTES;
-          const float4 a = *reinterpret_cast<const float4*>(src_e);
-          const uint2 m = *reinterpret_cast<const uint2*>(src_e + 16);
-          put_entry(n_list + i, a, (int)(m.x & 0xffu), (int)(m.x >> 8), epz, e16_plane, m.y);
+      for (int sz = sz_hi; sz >= sz_lo; sz--) {               // jz = rz - sz ascending
+        const int slot = sz % S;
+        const int cnt = __builtin_amdgcn_readfirstlane(plane_cnt[slot]);
+        if (cnt == 0) continue;   // uniform
+        // list and slice are free: every sweep ends with a barrier
+        {
+          const float4* src4 = table + (i64)(rz - sz + h) * nsl;
+          float4* sl4 = reinterpret_cast<float4*>(slices);
+          for (int i = tid; i < nsl; i += NT) sl4[i] = src4[i];
         }
-        n_list += take;
-        done += take;
-        if (n_list == CAP) flush();
-      }
-    } else {
-      // ---- read the plane from the volume: ordered compaction of its salient senders, band by band -------
-      int plane_fill = 0;   // entries of this plane written so far (uniform)
-      for (int bi = 0; bi < p.nbands; bi++) {
-        const int band = p.nbands - 1 - bi;                 // bands visited from the last rows down
-        const int row0 = band * p.band_rows;
-        const int rows = min(p.band_rows, p.rh - row0);
-        const int par = (npar++) & 1;
-        float cur[VPT];
-        fetch(sz, band, cur);
-        int cnt = 0;
-#pragma unroll
-        for (int v = 0; v < VPT; v++) cnt += (cur[v] != 0.0f) ? 1 : 0;
-        int incl = cnt;   // inclusive scan over the wave
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          const int o = __shfl_up(incl, d);
-          if (lane >= d) incl += o;
-        }
-        if (lane == 63) wave_tot[par][wave] = incl;
-        __syncthreads();   // (1) wave totals (and new slices) visible
-        int base = 0, len = 0;
-#pragma unroll
-        for (int w = 0; w < NT / 64; w++) {
-          const int t = wave_tot[par][w];
-          base += (w < wave) ? t : 0;
-          len += t;
-        }
-        // vote order inside a band is DESCENDING position: entry with ascending rank r gets q = len-1-r
-        const int first_q = len - 1 - (base + incl - cnt);     // q of this thread's first sender; next ones q-1, ...
-
-        const __amdgpu_buffer_rsrc_t rd0 = plane_rsrc(dir, sz);
-        const __amdgpu_buffer_rsrc_t rd1 = plane_rsrc(dir + nvox, sz);
-        const __amdgpu_buffer_rsrc_t rd2 = plane_rsrc(dir + 2 * nvox, sz);
-        int done = 0;
-        while (done < len) {   // uniform
-          const int take = min(CAP - n_list, len - done);
-          int q = first_q;
-#pragma unroll
-          for (int v = 0; v < VPT; v++) {
-            if (cur[v] != 0.0f) {
-              if (q >= done && q < done + take) {
-                const unsigned off = voff_of(v, row0, rows);
-                float4 a = make_float4(cur[v], 0.0f, 0.0f, 0.0f);
-                if (MODE != 3) { a.y = buf_load(rd0, off); a.z = buf_load(rd1, off); a.w = buf_load(rd2, off); }
-                const int ex = rc_[v] & 0xff, ey = row0 + (rc_[v] >> 8);
-                unsigned mv = 0u;
-                if (MASKED_SRC) mv = __float_as_uint(buf_load(plane_rsrc(mask_src, sz), off));
-                put_entry(n_list + (q - done), a, ex, ey, epz, e16_plane, mv);
-                if (ring_plane) {
-                  unsigned char* dst_e = ring_plane + (size_t)(plane_fill + q) * RING_BYTES;
-                  *reinterpret_cast<float4*>(dst_e) = a;
-                  *reinterpret_cast<uint2*>(dst_e + 16) = make_uint2((unsigned)ex | ((unsigned)ey << 8), mv);
-                }
-              }
-              q--;
-            }
+        const unsigned char* ring_plane = ring + (size_t)slot * plane_stride;
+        const int epz = sz - rz;
+        const int epz2 = epz * epz;
+        for (int done = 0; done < cnt; done += CAP) {          // uniform
+          const int take = min(CAP, cnt - done);
+          if (tid < take) {
+            const unsigned char* src_e = ring_plane + (size_t)(done + tid) * RING_BYTES;
+            const float4 a = *reinterpret_cast<const float4*>(src_e);
+            const uint4 m = *reinterpret_cast<const uint4*>(src_e + 16);
+            l_ent[tid] = a;
+            const int e2 = (int)m.y + epz2;
+            l_pos[tid] = make_uint2(m.x | ((unsigned)((-(e2 >> 7)) & 0xff) << 16) | ((unsigned)(e2 & 127) << 24), m.z);
+            if (MASKED_SRC) l_mv[tid] = __uint_as_float(m.w);
           }
-          n_list += take;
-          done += take;
-          if (n_list == CAP) flush();
+          if (tid < 8) l_pos[take + tid] = make_uint2(NEVER_HIT, 0u);
+          __syncthreads();   // list (and slice) complete
+          sweep(take);
+          __syncthreads();   // everyone done reading before the list or the slice is refilled
         }
-        plane_fill += len;
       }
-      if (ring) {
-        if (tid == 0) plane_cnt[sz % P] = plane_fill;
-        if (cached_lo > cached_hi) { cached_lo = sz; cached_hi = sz; }
-        else if (sz == cached_hi + 1) cached_hi = sz;
-        else if (sz == cached_lo - 1) cached_lo = sz;
-        else { cached_lo = sz; cached_hi = sz; }            // (not reached: planes arrive adjacent to the range)
-        if (cached_hi - cached_lo + 1 > P) cached_lo = cached_hi - P + 1;   // the slot of the oldest plane was reused
-      }
-    }
-    // end of group (or of all planes): sweep what is left; list and slices are free afterwards
-    if (((pl + 1) % p.group == 0) || (pl + 1 == nplanes)) flush();
-  }
 
-  if (r_live) {
-    if (MODE == 3) {
-      ten[rc] = T[0];
-    } else {
+      if (r_live) {
+        if (MODE == 3) {
+          ten[rc] = T[0];
+        } else {
 #pragma unroll
-      for (int k = 0; k < 6; k++) ten[k * nvox + rc] = T[k];
-    }
-  }
-  }   // next receiver plane of the run
-  }   // next tile
+          for (int k = 0; k < 6; k++) ten[k * nvox + rc] = T[k];
+        }
+      }
+    }   // next receiver plane of the run
+  }   // next unit
 }
 
 }  // namespace
@@ -450,7 +390,7 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
                  const float* mask_src, const float* mask_dst, i64 nx, i64 ny, i64 nz, i64 z_out0,
                  i64 z_out1, int h, const float4* dtab, int exponent, bool curves, bool weights_only, bool* handled) {
   *handled = false;
-  if (h < 1 || h > 40) return VISFD_HIP_OK;  // table slices in LDS + byte-packed coordinates limits
+  if (h < 1 || h > 40) return VISFD_HIP_OK;  // table slice in LDS + byte-packed coordinates limits
   if (nx * ny >= (1LL << 29)) return VISFD_HIP_OK;  // plane descriptors are 32-bit
   const int n = 2 * h + 1;
   hipStream_t st = ctx->stream;
@@ -459,21 +399,19 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
   p.nx = (int)nx; p.ny = (int)ny; p.nz = (int)nz;
   p.z_out0 = (int)z_out0; p.z_out1 = (int)z_out1;
   p.h = h;
-  p.rw = TILE + 2 * h; p.rh = TILE + 2 * h;
-  p.band_rows = BAND_CAP / p.rw;
-  if (p.band_rows > p.rh) p.band_rows = p.rh;
-  p.nbands = (p.rh + p.band_rows - 1) / p.band_rows;
+  p.rw = TILE + 2 * h;
+  const int R = p.rw * p.rw;
+  p.nchunk = (R + NT - 1) / NT;
+  p.rw_magic = ((1 << 20) + p.rw - 1) / p.rw;
+  for (int q = 0; q < p.nchunk * NT; q++)   // (<= 9216 positions)
+    if ((int)(((unsigned)q * (unsigned)p.rw_magic) >> 20) != q / p.rw) return fail(VISFD_HIP_EINVAL, "tv_tiled: region index division");
   const size_t slice_bytes = sizeof(float4) * (size_t)n * n;
-  // one sender plane per sweep: the sweep gains nothing from longer lists, and one slice leaves LDS for eight
-  // workgroups per CU (measured at 1024^3: 953 ms with two planes and five workgroups, 803 ms with one and eight)
-  p.group = 1;
-  if (ctx->opt.tv_group >= 1 && ctx->opt.tv_group <= MAX_GROUP && (size_t)ctx->opt.tv_group * slice_bytes <= (size_t)SLICE_BYTES_MAX)
-    p.group = ctx->opt.tv_group;
   p.tiles_x = (int)((nx + TILE - 1) / TILE);
   p.tiles_y = (int)((ny + TILE - 1) / TILE);
   p.exponent = exponent;
   p.curves = curves ? 1 : 0;
-  // units of work: a tile over a run of receiver planes (the kernel replays compacted sender planes within a run)
+  p.relist = ctx->opt.tv_no_replay ? 1 : 0;
+  // units of work: a tile over a run of receiver planes (sender-plane lists are shared within a run)
   p.zrun = 32;   // sweep at 1024^3: 16: 853 ms, 24-64: 820-833 ms, 128: 838 ms
   if (ctx->opt.tv_zrun >= 1 && ctx->opt.tv_zrun <= 4096) p.zrun = ctx->opt.tv_zrun;   // tuning aid
   if ((i64)p.zrun > z_out1 - z_out0) p.zrun = (int)(z_out1 - z_out0);
@@ -481,12 +419,14 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
   const i64 nruns = (z_out1 - z_out0 + p.zrun - 1) / p.zrun;
   const i64 nblk = (i64)p.tiles_x * p.tiles_y * nruns;
   if (nblk > 0x7fffffffLL) return fail(VISFD_HIP_EINVAL, "volume too large for one launch");
-  const size_t lds = (size_t)p.group * slice_bytes;   // dynamic part
+  if (nblk <= 0) { *handled = true; return VISFD_HIP_OK; }
+  const size_t lds = slice_bytes;   // dynamic part: one slice (one sender plane per sweep leaves LDS for eight workgroups
+                                    // per CU; measured at 1024^3: 953 ms with two planes and five workgroups, 803 ms with one)
   const size_t lds_static = sizeof(float4) * CAP + sizeof(uint2) * (CAP + 8) + sizeof(float) * (mask_src ? CAP : 1) + 512;
-  if (lds + lds_static > 150 * 1024) return VISFD_HIP_OK;   // window too wide for the LDS slices: baseline kernel
+  if (lds + lds_static > 150 * 1024) return VISFD_HIP_OK;   // window too wide for the LDS slice: baseline kernel
   const int mode = weights_only ? 3 : (curves ? 1 : (exponent == 4 ? 0 : (exponent == 2 ? 2 : 1)));
   // persistent workgroups (see the kernel): as many as the chip holds at once -- LDS allows 160 KB / (static +
-  // dynamic) per CU, registers eight waves per SIMD = 8 workgroups -- each claiming tiles from a counter
+  // dynamic) per CU, registers eight waves per SIMD = 8 workgroups -- each claiming units from a counter
   unsigned* counter = nullptr;
   VH_TRY(ws(ctx, WS_COUNTER, 16, &counter));
   VH_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned), st));
@@ -497,17 +437,19 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
   i64 ngrid = (i64)ctx->num_cus * (i64)wg_per_cu;
   if (ctx->opt.tv_max_wg > 0 && ngrid > ctx->opt.tv_max_wg) ngrid = ctx->opt.tv_max_wg;   // tests: many units per workgroup
   if (ngrid > nblk) ngrid = nblk;
-  // scratch rings: (2h+1) planes x (TILE+2h)^2 entries of 32 bytes per workgroup (2.6 GB for h = 12 on 256 CUs);
-  // beyond 16 GB (very wide windows) the kernel runs without them and compacts every plane from the volume
+  // scratch rings: (2h+1) planes x (TILE+2h)^2 entries of 32 bytes per workgroup (2.6 GB for h = 12 on 256 CUs).  Very
+  // wide windows are capped at 16 GB (fewer workgroups: their LDS slices allow only one or two per CU anyway); if the
+  // allocation fails the grid is halved, and without any ring the caller's baseline kernel takes over.
   unsigned char* scratch = nullptr;
-  {
-    const size_t per_wg = (size_t)n * p.rw * p.rh * RING_BYTES;
-    const size_t total = per_wg * (size_t)ngrid;
-    if (total <= ((size_t)16 << 30) && p.zrun > 1 && !ctx->opt.tv_no_replay) {
-      // the kernel also runs without rings (it then compacts every plane from the volume): out of memory is not an error
-      if (ws(ctx, WS_TVSCRATCH, total, &scratch) != VISFD_HIP_OK) { scratch = nullptr; set_error(""); (void)hipGetLastError(); }
-    }
+  const size_t per_wg = (size_t)n * R * RING_BYTES;
+  if ((size_t)ngrid * per_wg > ((size_t)16 << 30)) ngrid = (i64)(((size_t)16 << 30) / per_wg);
+  for (; ngrid >= 1; ngrid /= 2) {
+    if (ws(ctx, WS_TVSCRATCH, per_wg * (size_t)ngrid, &scratch) == VISFD_HIP_OK) break;
+    scratch = nullptr;
+    set_error("");
+    (void)hipGetLastError();
   }
+  if (!scratch) return VISFD_HIP_OK;
 #define VH_TV_LAUNCH(MSK, MD)                                                                        \
   do {                                                                                               \
     VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tv_tiled_kernel<MSK, MD>),             \
