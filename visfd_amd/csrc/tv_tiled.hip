@@ -5,10 +5,11 @@
 // (typically 95 % of them, feature.hpp:1704-1709).  Here the skipping is done once per workgroup instead of once per
 // receiver:
 //
-//   * workgroups are PERSISTENT: as many as the chip holds, each claiming units of work -- a 16 x 16 tile of receivers
-//     (one per thread; each wave an 8 x 8 patch) over a run of 32 consecutive receiver planes -- from a global counter
-//     until it is exhausted (a plain grid left wave slots empty on volumes whose sender density varies, see the kernel);
-//   * LISTING: the salient, unmasked senders of the (16+2h)^2 region of a sender plane -- saliency, normal, position
+//   * workgroups are PERSISTENT: as many as the chip holds, each claiming units of work -- an 8 x 32 tile of receivers
+//     (one per thread; each wave an 8 x 8 patch, the four patches stacked in y) over a run of 32 consecutive receiver
+//     planes -- from a global counter until it is exhausted (a plain grid left wave slots empty on volumes whose sender
+//     density varies, see the kernel);
+//   * LISTING: the salient, unmasked senders of the (8+2h) x (32+2h) region of a sender plane -- saliency, normal, position
 //     bytes, table offset, mask value: 32 bytes -- are compacted IN VOTE ORDER (ordered, ballot-based prefix sums:
 //     deterministic) into a per-workgroup ring of 2h+1 planes in global memory, once per unit and plane: consecutive
 //     receiver planes share 2h of their 2h+1 sender planes, so all but the first plane of a run list one new plane;
@@ -17,7 +18,9 @@
 //   * the SWEEP: every wave walks the list in order.  A sender is tested against the wave's 64 receivers --
 //     jx^2+jy^2+jz^2 <= h^2 as ONE v_dot4_i32_i8 on signed bytes (see the kernel), an exact superset of the table's
 //     spherical support -- and voted at once by the lanes it reaches, under their execution mask.  The sender's data
-//     come from uniform-address (broadcast) LDS reads: no bank conflicts, no per-lane bookkeeping;
+//     come from uniform-address (broadcast) LDS reads: no bank conflicts, no per-lane bookkeeping.  The region is as wide
+//     as one wave's reach in x and the list is in row order, so a wave sweeps only the contiguous stretch of the list
+//     whose rows it can reach on that plane (8 + 2 sqrt(h^2 - jz^2) of the 32 + 2h rows);
 //   * weights and unit displacements come from the LDS copy of the table slice (w, rhat_x, rhat_y, rhat_z as one
 //     float4, signs included).  The table index is linear in j = receiver - sender, so the byte address of a vote's
 //     table entry is  R(lane) - E(sender):  one subtraction per vote.
@@ -40,7 +43,7 @@ namespace {
 
 constexpr int NT = 256;
 constexpr int NW = NT / 64;
-constexpr int TILE = 16;
+constexpr int TX = 8, TY = 32;        // receivers of a workgroup: four 8 x 8 wave patches stacked in y
 #ifndef VH_TV_CAP
 #define VH_TV_CAP 256
 #endif
@@ -68,7 +71,7 @@ struct TiledParams {
   int nx, ny, nz;
   int z_out0, z_out1;    // receiver planes [z_out0, z_out1)
   int h;                 // window halfwidth
-  int rw;                // region width = height = TILE + 2h
+  int rw, rh;            // region width = TX + 2h, height = TY + 2h
   int rw_magic;          // q / rw == (q * rw_magic) >> 20 for every region position q (checked by the launcher)
   int nchunk;            // 64-voxel chunks of the region per wave
   int tiles_x, tiles_y;
@@ -141,6 +144,7 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
   __shared__ __attribute__((aligned(16))) uint2 l_pos[CAP + 8];
   __shared__ float l_mv[MASKED_SRC ? CAP : 1];
   __shared__ int wave_tot[2][NW];
+  __shared__ int cull[NW][2 * NW];           // per listing wave: entries above / not below the rows each wave can reach
   __shared__ unsigned claimed_tile;
   __shared__ int plane_cnt[84];              // entries per ring slot, [2h+1] (h <= 40)
   // dynamic LDS: the table slice of the current sender plane, [(2h+1)^2] float4
@@ -151,7 +155,7 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
   const int h = p.h;
   const int S = 2 * h + 1;       // table row length = planes per ring
   const int nsl = S * S;         // float4 entries per slice
-  const int R = p.rw * p.rw;     // region positions per plane
+  const int R = p.rw * p.rh;     // region positions per plane
   const i64 plane = (i64)p.nx * p.ny;
   const i64 nvox = plane * p.nz;
   const int plane_bytes = (int)(plane * 4);
@@ -174,22 +178,25 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
     const int tile_x = b % p.tiles_x;
     b /= p.tiles_x;
     const int tile_y = b % p.tiles_y;
-    // a unit of work: one 16 x 16 tile over a run of consecutive receiver planes [z_run0, z_run1)
+    // a unit of work: one 8 x 32 tile over a run of consecutive receiver planes [z_run0, z_run1)
     const int z_run0 = p.z_out0 + (int)(b / p.tiles_y) * p.zrun;
     const int z_run1 = min(z_run0 + p.zrun, p.z_out1);
-    const int x0 = tile_x * TILE, y0 = tile_y * TILE;
+    const int x0 = tile_x * TX, y0 = tile_y * TY;
 
-    // receiver of this thread: wave w owns the 8x8 patch (w&1, w>>1).  Region-relative coordinates:
-    // the sender region starts at (x0-h, y0-h, rz-h), so the receiver sits at (lx+h, ly+h, h).
-    const int lx = (wave & 1) * 8 + (lane & 7), ly = (wave >> 1) * 8 + (lane >> 3);
+    // receiver of this thread: wave w owns the rows [8w, 8w+8) of the tile.  Region-relative coordinates:
+    // the sender region starts at (x0-h, y0-h, rz-h), so the receiver sits at (lx+h, ly+h, h).  The region is exactly
+    // as wide as one wave's reach in x, and list order is row order, so the senders a wave can reach are one
+    // contiguous stretch of the list (see the replay below).
+    const int lx = lane & 7, ly = wave * 8 + (lane >> 3);
     const int rx = x0 + lx, ry = y0 + ly;
     const bool r_in = rx < p.nx && ry < p.ny;
     // Distance test  |r - e|^2 <= h^2  as ONE dot product per (receiver, sender): with coordinates
-    // relative to the tile centre (r' = (lx-8, ly-8, 0), e' = (ex-h-8, ey-h-8, ez-h)) and
+    // relative to the tile centre (r' = (lx-4, ly-16, 0), e' = (ex-h-4, ey-h-16, ez-h)) and
     // |e'|^2 = 128 q + m,
     //   |r'-e'|^2 - h^2 - 1  =  (-2r'x, -2r'y, -128, 1) . (e'x, e'y, -q, m)  +  (|r'|^2 - h^2 - 1),
-    // every factor a signed byte (|e'| <= h+8 <= 48, so q <= 54), the last term a per-lane accumulator.
-    const int rpx = lx - 8, rpy = ly - 8;
+    // every factor a signed byte (|e'x| <= h+4, |e'y| <= h+16, |e'z| <= h <= 40, so q <= 52), the last term a per-lane
+    // accumulator.
+    const int rpx = lx - TX / 2, rpy = ly - TY / 2;
     const unsigned recv4 = (unsigned)((-2 * rpx) & 0xff) | ((unsigned)((-2 * rpy) & 0xff) << 8) | (0x80u << 16) | (1u << 24);
     const int recv_c = rpx * rpx + rpy * rpy - h * h - 1;
     constexpr unsigned NEVER_HIT = 0x009c0000u;   // operand whose dot product is positive for every receiver (-128 * -100)
@@ -266,7 +273,7 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
             if (MODE != 3) { a.y = buf_load(rd0, off); a.z = buf_load(rd1, off); a.w = buf_load(rd2, off); }
             unsigned mv = 0u;
             if (MASKED_SRC) mv = __float_as_uint(buf_load(rm, off));
-            const int epx = ex - h - 8, epy = ey - h - 8;
+            const int epx = ex - h - TX / 2, epy = ey - h - TY / 2;
             unsigned char* dst_e = ring_plane + (size_t)idx * RING_BYTES;
             *reinterpret_cast<float4*>(dst_e) = a;
             *reinterpret_cast<uint4*>(dst_e + 16) =
@@ -282,30 +289,24 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
     float T[6];
     int recv_c_live = 0x100000;   // receivers that take no votes never hit: their accumulator operand is large and positive
 
-    // ---- the SWEEP over list entries [0, n), in vote order --------------------------------------------------
-    auto sweep = [&](int n) {
+    // ---- the SWEEP over list entries [i0, i1), in vote order -------------------------------------------------
+    auto sweep = [&](int i0, int i1) {
       // the table entry is requested together with the sender's own data: its address needs only E, which came with
-      // the batch
-      auto vote_one = [&](int s, unsigned e16) {
+      // the batch; ent = LDS address of the batch's first entry (a vector register: DS addresses cannot be scalar)
+      auto vote_one = [&](unsigned ent, int k, int s, unsigned e16) {
         const f4v tw = *lds_ptr<f4v>(r16s - e16);
         float fv = tw.x;
         if (MASKED_SRC) fv = fv * l_mv[s];    // fv = w * mask value first (feature.hpp:2262-2275), then sal * fv
         if (MODE == 3) {
           acc(T[0], fv);                      // "denominator += filter_val" (feature.hpp:2376-2377)
         } else {
-          const f4v d = *lds_ptr<f4v>(ent_base + ((unsigned)s << 4));
+          const f4v d = *lds_ptr<f4v>(ent + 16u * (unsigned)k);
           float bse, m0, m1, m2;
           vote_dir<MODE>(d.x, fv, tw.y, tw.z, tw.w, d.y, d.z, d.w, p.exponent, p.curves, bse, m0, m1, m2);
           vote_acc(T, bse, m0, m1, m2);
         }
       };
-      // batches of four senders; the next batch is in flight while this one is tested and voted
-      const uint4* pq = reinterpret_cast<const uint4*>(l_pos);
-      uint4 qa = pq[0], qb = pq[1];
-      for (int s0 = 0; s0 < n; s0 += 4) {   // uniform
-        const uint4 ca = qa, cb = qb;
-        qa = pq[(s0 >> 1) + 2];
-        qb = pq[(s0 >> 1) + 3];
+      auto batch = [&](const uint4& ca, const uint4& cb, unsigned ent, int s0) {
         int d0, d1, d2, d3;
         // four dots back to back: a dot result may be read by the VALU three instructions later at the earliest, and
         // the compiler does not see hazards of instructions inside an asm block
@@ -315,10 +316,29 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
             "v_dot4_i32_i8 %3, %4, %9, %5"
             : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
             : "v"(recv4), "v"(recv_c_live), "v"(ca.x), "v"(ca.z), "v"(cb.x), "v"(cb.z));
-        if (d0 < 0) vote_one(s0, ca.y);
-        if (d1 < 0) vote_one(s0 + 1, ca.w);
-        if (d2 < 0) vote_one(s0 + 2, cb.y);
-        if (d3 < 0) vote_one(s0 + 3, cb.w);
+        if (d0 < 0) vote_one(ent, 0, s0, ca.y);
+        if (d1 < 0) vote_one(ent, 1, s0 + 1, ca.w);
+        if (d2 < 0) vote_one(ent, 2, s0 + 2, cb.y);
+        if (d3 < 0) vote_one(ent, 3, s0 + 3, cb.w);
+      };
+      // batches of four senders, two per trip: the next batch is in flight while this one is tested and voted, and the
+      // two register sets swap roles without copies
+      int s0 = i0 & ~1;                      // l_pos is read two entries at a time
+      const uint4* pq = reinterpret_cast<const uint4*>(l_pos) + (s0 >> 1);
+      unsigned ent = ent_base + 16u * (unsigned)s0;
+      asm volatile("" : "+v"(ent));
+      uint4 a0 = pq[0], a1 = pq[1];
+      while (s0 < i1) {   // uniform
+        const uint4 b0 = pq[2], b1 = pq[3];
+        batch(a0, a1, ent, s0);
+        if (s0 + 4 >= i1) break;
+        a0 = pq[4];
+        a1 = pq[5];
+        batch(b0, b1, ent + 64u, s0 + 4);
+        pq += 4;
+        ent += 128u;
+        asm volatile("" : "+v"(ent));
+        s0 += 8;
       }
     };
 
@@ -352,8 +372,13 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
         const unsigned char* ring_plane = ring + (size_t)slot * plane_stride;
         const int epz = sz - rz;
         const int epz2 = epz * epz;
+        // rows a wave can reach on this plane: |r'y - e'y| <= rho = floor(sqrt(h^2 - epz^2)), r'y in [8w-16, 8w-9]
+        int rho = (int)__builtin_sqrtf((float)(h * h - epz2));
+        while (rho * rho > h * h - epz2) rho--;
+        while ((rho + 1) * (rho + 1) <= h * h - epz2) rho++;
         for (int done = 0; done < cnt; done += CAP) {          // uniform
           const int take = min(CAP, cnt - done);
+          int epy = -128;                                      // threads without an entry: below every range
           if (tid < take) {
             const unsigned char* src_e = ring_plane + (size_t)(done + tid) * RING_BYTES;
             const float4 a = *reinterpret_cast<const float4*>(src_e);
@@ -362,10 +387,24 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
             const int e2 = (int)m.y + epz2;
             l_pos[tid] = make_uint2(m.x | ((unsigned)((-(e2 >> 7)) & 0xff) << 16) | ((unsigned)(e2 & 127) << 24), m.z);
             if (MASKED_SRC) l_mv[tid] = __uint_as_float(m.w);
+            epy = (int)(signed char)(m.x >> 8);
           }
           if (tid < 8) l_pos[take + tid] = make_uint2(NEVER_HIT, 0u);
+          // entries are in descending row order: wave w needs those from the first one at or below row 8w-9+rho to
+          // the last one at or above row 8w-16-rho; every wave counts, among its 64 entries, both kinds for all waves
+#pragma unroll
+          for (int w = 0; w < NW; w++) {
+            const int above = __builtin_popcountll(__builtin_amdgcn_ballot_w64(epy > 8 * w - (TY / 2 - 7) + rho));
+            const int upto = __builtin_popcountll(__builtin_amdgcn_ballot_w64(epy >= 8 * w - TY / 2 - rho));
+            if (lane == 0) { cull[wave][2 * w] = above; cull[wave][2 * w + 1] = upto; }
+          }
           __syncthreads();   // list (and slice) complete
-          sweep(take);
+          int i0 = 0, i1 = 0;
+#pragma unroll
+          for (int w = 0; w < NW; w++) { i0 += cull[w][2 * wave]; i1 += cull[w][2 * wave + 1]; }
+          i0 = __builtin_amdgcn_readfirstlane(i0);
+          i1 = __builtin_amdgcn_readfirstlane(i1);
+          sweep(i0, i1);
           __syncthreads();   // everyone done reading before the list or the slice is refilled
         }
       }
@@ -399,15 +438,16 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
   p.nx = (int)nx; p.ny = (int)ny; p.nz = (int)nz;
   p.z_out0 = (int)z_out0; p.z_out1 = (int)z_out1;
   p.h = h;
-  p.rw = TILE + 2 * h;
-  const int R = p.rw * p.rw;
+  p.rw = TX + 2 * h;
+  p.rh = TY + 2 * h;
+  const int R = p.rw * p.rh;
   p.nchunk = (R + NT - 1) / NT;
   p.rw_magic = ((1 << 20) + p.rw - 1) / p.rw;
   for (int q = 0; q < p.nchunk * NT; q++)   // (<= 9216 positions)
     if ((int)(((unsigned)q * (unsigned)p.rw_magic) >> 20) != q / p.rw) return fail(VISFD_HIP_EINVAL, "tv_tiled: region index division");
   const size_t slice_bytes = sizeof(float4) * (size_t)n * n;
-  p.tiles_x = (int)((nx + TILE - 1) / TILE);
-  p.tiles_y = (int)((ny + TILE - 1) / TILE);
+  p.tiles_x = (int)((nx + TX - 1) / TX);
+  p.tiles_y = (int)((ny + TY - 1) / TY);
   p.exponent = exponent;
   p.curves = curves ? 1 : 0;
   p.relist = ctx->opt.tv_no_replay ? 1 : 0;
@@ -437,7 +477,7 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
   i64 ngrid = (i64)ctx->num_cus * (i64)wg_per_cu;
   if (ctx->opt.tv_max_wg > 0 && ngrid > ctx->opt.tv_max_wg) ngrid = ctx->opt.tv_max_wg;   // tests: many units per workgroup
   if (ngrid > nblk) ngrid = nblk;
-  // scratch rings: (2h+1) planes x (TILE+2h)^2 entries of 32 bytes per workgroup (2.6 GB for h = 12 on 256 CUs).  Very
+  // scratch rings: (2h+1) planes x (8+2h)(32+2h) entries of 32 bytes per workgroup (2.9 GB for h = 12 on 256 CUs).  Very
   // wide windows are capped at 16 GB (fewer workgroups: their LDS slices allow only one or two per CU anyway); if the
   // allocation fails the grid is halved, and without any ring the caller's baseline kernel takes over.
   unsigned char* scratch = nullptr;
