@@ -11,6 +11,21 @@ python3 bench.py > $out/bench.json 2> $out/bench.err
 tail -c 600 $out/bench.json; echo
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 bench.py --steps 2 --warmup 1 --no-cpu > $out/bench_under_rocprof.json 2> $out/prof.err
 cp $out/prof/*/*kernel_stats.csv $out/kernel_stats.csv
+# the Gaussian launches of that run by grid size (1024^3 and 2048^3 launches share one kernel name in the statistics)
+python3 - $out/prof > $out/gauss_launches.txt <<'PY'
+import csv, glob, sys
+rows = list(csv.DictReader(open(glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0])))
+groups = {}
+for r in rows:
+    if "gauss_fused_kernel<5" not in r["Kernel_Name"]:
+        continue
+    key = (int(r["Grid_Size_X"]), int(r["Grid_Size_Y"]), int(r["Grid_Size_Z"]))
+    groups.setdefault(key, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+print("# gauss_fused_kernel<5,...> launches of the rocprofv3 --kernel-trace run of bench.py, grouped by grid size (ms)")
+for k, v in sorted(groups.items()):
+    v.sort()
+    print("grid %s: %d launches, mean %.4f  median %.4f  min %.4f  max %.4f" % (k, len(v), sum(v) / len(v), v[len(v) // 2], v[0], v[-1]))
+PY
 rm -rf $out/prof
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/g_$c -- python3 tools/pmc_traffic.py $n > $out/g_$c.log 2>&1

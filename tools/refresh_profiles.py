@@ -27,7 +27,8 @@ with open(os.path.join(P, "%s_bench_1024_summary.txt" % tag), "w") as f:
         f.write("%-100s %6d %12.3f %10.4f %7s\n" % (r["Name"][:100], int(r["Calls"]), int(r["TotalDurationNs"]) / 1e6,
                                                      float(r["AverageNs"]) / 1e6, r["Percentage"]))
 for a, b in (("bench.json", "%s_bench_1024.json"), ("bench_under_rocprof.json", "%s_bench_1024_under_rocprof.json"),
-             ("gauss_traffic.json", "%s_gauss_traffic.json"), ("tv_traffic.json", "%s_tv_traffic.json")):
+             ("gauss_traffic.json", "%s_gauss_traffic.json"), ("tv_traffic.json", "%s_tv_traffic.json"),
+             ("gauss_launches.txt", "%s_bench_1024_gauss_launches.txt"), ("pytest_gpu.log", "%s_pytest_gpu.txt")):
     if os.path.exists(os.path.join(src_dir, a)):
         shutil.copy(os.path.join(src_dir, a), os.path.join(P, b % tag))
 print(open(os.path.join(P, "%s_bench_1024_summary.txt" % tag)).read()[:4000])
