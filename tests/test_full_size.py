@@ -1,7 +1,7 @@
 """BASELINE configs 3 and 4 at FULL size (1024^3, the bench's own synthetic volume and parameters), checked against the
 CPU restatement through locality: every stage of the path has a finite reach, so the result inside a crop equals the
 oracle's result on the crop plus a halo.  The crops sit at corners and faces of the volume, in its interior, across
-the seams of the voting kernel's units of work (tiles of 16 x 16 voxels, runs of 32 receiver planes) and on the
+the seams of the voting kernel's units of work (tiles of 8 x 32 voxels, runs of 32 receiver planes) and on the
 synthetic membranes, where sender lists are long.  At this size every persistent workgroup of the voting kernel claims
 more than a hundred units, which no small test reaches.
 
