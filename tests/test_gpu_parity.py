@@ -328,11 +328,12 @@ def test_blob_scan_overflow_path(ctx, oracle, monkeypatch):
     sig = oracle.diameters_to_sigmas(volgen.BLOB_DIAMS)
     r = ratio(oracle)
     want = oracle.blob_dog(src, sig, None, None, 0.02, r, np.inf, -np.inf, False)
-    with ctx.options(blob_test_cap=8):
-        got = ctx.blob_dog(src, sig, None, None, 0.02, r, np.inf, -np.inf, False)
     assert len(want[0]) > 8 or len(want[1]) > 8
-    for g, w, asc in ((got[0], want[0], True), (got[1], want[1], False)):
-        assert_bits_equal(volgen.sort_blobs(g, asc), volgen.sort_blobs(w, asc), "blob list through the overflow path")
+    for cap in (8, 24, 64):     # every scale overflows / only the scales with the longest lists do
+        with ctx.options(blob_test_cap=cap):
+            got = ctx.blob_dog(src, sig, None, None, 0.02, r, np.inf, -np.inf, False)
+        for g, w, asc in ((got[0], want[0], True), (got[1], want[1], False)):
+            assert_bits_equal(volgen.sort_blobs(g, asc), volgen.sort_blobs(w, asc), "blob list through the overflow path, cap %d" % cap)
 
 
 @pytest.mark.parametrize("tag", ["nomask", "mask"])

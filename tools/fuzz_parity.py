@@ -82,9 +82,15 @@ def main():
                 d = np.ascontiguousarray(d, np.float32)
                 sigma_tv = float(rng.uniform(0.8, 9.5))
                 ex = int(rng.choice([2, 4]))
-                ok = bits_equal(ctx.tv_dense_stick(sal, d, sigma_tv, ex, 2.0 ** 0.5, mask, mask),
-                                O.tv_dense_stick(sal, d, sigma_tv, ex, 2.0 ** 0.5, mask, mask))
-                desc = "tv shape=%s sigma_tv=%g exponent=%d mask=%s" % (shape, sigma_tv, ex, mask is not None)
+                opts = {}
+                if rng.random() < 0.6:     # few persistent workgroups, short runs: every workgroup claims many units
+                    opts = {"tv_max_wg": int(rng.integers(1, 5)), "tv_zrun": int(rng.integers(1, 9))}
+                    if rng.random() < 0.3:
+                        opts["tv_no_replay"] = 1
+                with ctx.options(**opts):
+                    got = ctx.tv_dense_stick(sal, d, sigma_tv, ex, 2.0 ** 0.5, mask, mask)
+                ok = bits_equal(got, O.tv_dense_stick(sal, d, sigma_tv, ex, 2.0 ** 0.5, mask, mask))
+                desc = "tv shape=%s sigma_tv=%g exponent=%d mask=%s opts=%s" % (shape, sigma_tv, ex, mask is not None, opts)
             else:
                 b = tuple(int(v) for v in rng.integers(1, 5, 3))
                 ds = tuple(max(1, shape[i] // b[i]) for i in range(3))

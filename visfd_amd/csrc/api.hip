@@ -160,13 +160,16 @@ int blob_dog_dev(visfd_hip_ctx* ctx, const float* src, const float* mask, i64 nx
   hipEvent_t ev[2] = {nullptr, nullptr};
   for (int k = 0; k < 2; k++) VH_HIP(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
   int rc_loop = VISFD_HIP_OK;
-  bool redo = false;
+  // lists per middle scale (output order is scale order, feature.hpp:236-358); scales whose buffers overflowed in the
+  // pipelined scan are repeated on their own afterwards
+  std::vector<std::vector<visfd_hip_blob>> smin((size_t)std::max(n_sigma, 1)), smax((size_t)std::max(n_sigma, 1));
+  std::vector<int> redo;
   int pending = -1;   // middle scale whose scan is queued but not collected yet (buffer set: pending & 1)
   auto collect = [&](int scale) -> int {
     bool overflow = false;
-    VH_TRY(blob_scan_collect(ctx, scale & 1, ev[scale & 1], ctx->aux_stream, nx, ny, n, scale, blob_sigma[scale], &mins,
-                             &maxs, &overflow));
-    if (overflow) redo = true;
+    VH_TRY(blob_scan_collect(ctx, scale & 1, ev[scale & 1], ctx->aux_stream, nx, ny, n, scale, blob_sigma[scale],
+                             &smin[(size_t)scale], &smax[(size_t)scale], &overflow));
+    if (overflow) redo.push_back(scale);
     return VISFD_HIP_OK;
   };
   for (int ir = 0; ir < n_sigma && rc_loop == VISFD_HIP_OK; ir++) {
@@ -182,17 +185,21 @@ int blob_dog_dev(visfd_hip_ctx* ctx, const float* src, const float* mask, i64 nx
   if (rc_loop == VISFD_HIP_OK && pending >= 0) rc_loop = collect(pending);
   for (int k = 0; k < 2; k++) (void)hipEventDestroy(ev[k]);
   VH_TRY(rc_loop);
-  if (redo) {
-    // a candidate or survivor buffer overflowed (dense extrema): repeat scale by scale with buffers that grow
-    mins.clear(); maxs.clear();
-    for (int ir = 0; ir < n_sigma; ir++) {
+  // a candidate or survivor buffer overflowed (dense extrema): those scales again, one at a time, with buffers that grow
+  // (the three LoG volumes of the scale are filtered again; the other scales keep their lists)
+  for (int sc : redo) {
+    for (int k = 0; k < 3; k++) {
+      const int ir = sc - 1 + k;
       const float sg[3] = {blob_sigma[ir] * asp[0], blob_sigma[ir] * asp[1], blob_sigma[ir] * asp[2]};
-      VH_TRY(log_dev(ctx, src, vol[ir % 3], tmp, mask, nx, ny, nz, sg, delta, ratio, nullptr, nullptr));
-      if (ir < 2) continue;
-      VH_TRY(dev_blob_scan(ctx, vol[(ir - 2) % 3], vol[(ir - 1) % 3], vol[ir % 3], mask, nx, ny, nz, ir - 1,
-                           blob_sigma[ir - 1], scan_min, scan_max, true, true, &mins, &maxs));
+      VH_TRY(log_dev(ctx, src, vol[k], tmp, mask, nx, ny, nz, sg, delta, ratio, nullptr, nullptr));
     }
+    smin[(size_t)sc].clear();
+    smax[(size_t)sc].clear();
+    VH_TRY(dev_blob_scan(ctx, vol[0], vol[1], vol[2], mask, nx, ny, nz, sc, blob_sigma[sc], scan_min, scan_max, true, true,
+                         &smin[(size_t)sc], &smax[(size_t)sc]));
   }
+  for (auto& v : smin) mins.insert(mins.end(), v.begin(), v.end());
+  for (auto& v : smax) maxs.insert(maxs.end(), v.begin(), v.end());
   // Ratio mode with max_thr = -inf: the reference's scan compares score > (-inf) * (its running best, initially -1) = +inf in
   // every thread, so it never records a maximum (feature.hpp:286-289) -- deterministically none.
   if (use_ratios && max_thr == -inf) maxs.clear();

@@ -316,10 +316,11 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
             "v_dot4_i32_i8 %3, %4, %9, %5"
             : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
             : "v"(recv4), "v"(recv_c_live), "v"(ca.x), "v"(ca.z), "v"(cb.x), "v"(cb.z));
-        if (d0 < 0) vote_one(ent, 0, s0, ca.y);
-        if (d1 < 0) vote_one(ent, 1, s0 + 1, ca.w);
-        if (d2 < 0) vote_one(ent, 2, s0 + 2, cb.y);
-        if (d3 < 0) vote_one(ent, 3, s0 + 3, cb.w);
+        // most tested senders vote (the list is already cut to the rows the wave can reach): votes on the fall-through path
+        if (__builtin_expect(d0 < 0, 1)) vote_one(ent, 0, s0, ca.y);
+        if (__builtin_expect(d1 < 0, 1)) vote_one(ent, 1, s0 + 1, ca.w);
+        if (__builtin_expect(d2 < 0, 1)) vote_one(ent, 2, s0 + 2, cb.y);
+        if (__builtin_expect(d3 < 0, 1)) vote_one(ent, 3, s0 + 3, cb.w);
       };
       // batches of four senders, two per trip: the next batch is in flight while this one is tested and voted, and the
       // two register sets swap roles without copies
