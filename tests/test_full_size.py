@@ -53,13 +53,15 @@ def _crop(t, lo, hi):
     return t[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]].contiguous().cpu().numpy()
 
 
-def test_membrane_1024_cubed_crops_equal_oracle(gpu, volume, oracle):
-    """BASELINE config 4: `-membrane minima 3 -tv 5 -tv-angle-exponent 4` on 1024^3 (sigma 1.732, top 5 %, sigma_tv 8.66,
-    25^3 vote window), every stage fed by the previous device stage as in bench.py."""
+def _check_membrane(gpu, oracle, src, crops, E, dense=0.12, ridge_crops=4):
+    """The steps of pipeline.membrane_detect on `src` (every stage fed by the previous device stage, as in bench.py),
+    keeping the thresholded saliency the votes are cast from; then crops against the oracle on crop + halo."""
     import bench
     from visfd_amd import api
     torch, dev, ctx = gpu
-    src = volume
+    shape = tuple(src.shape)
+    dims = np.array(shape)
+    nvox = int(np.prod(dims))
     P = bench.MEMBRANE
     sigma = P["sigma"]
     ratio = api.ratio_from_threshold(0.03)
@@ -67,22 +69,68 @@ def test_membrane_1024_cubed_crops_equal_oracle(gpu, volume, oracle):
     sigma_tv = float(np.float32(P["tv_sigma_ratio"]) * np.float32(sigma))
     h = int(math.floor(np.float32(sigma_tv) * np.float32(math.sqrt(2.0))))
     assert h == 12
-    # the steps of pipeline.membrane_detect, keeping the thresholded saliency (what the votes are cast from)
     sal = torch.empty_like(src)
     smoothed = torch.empty_like(src)
-    dirs = torch.zeros((3, N, N, N), device=dev)
-    ten = torch.empty((6, N, N, N), device=dev)
+    dirs = torch.zeros((3,) + shape, device=dev)
+    ten = torch.empty((6,) + shape, device=dev)
     ctx.ridge_scores_dev(src, sal, smoothed, sigma, ratio, order)
     thr = ctx.threshold_fraction_dev(sal, P["best_fraction"])
     ctx.ridge_directions_dev(smoothed, sal, dirs, sigma, order)
     ctx.synchronize()
+    del smoothed
     sal_thr = sal.clone()
     ctx.tv_dense_stick_dev(sal, dirs, ten, sigma_tv, P["tv_exponent"], math.sqrt(2.0))
     ctx.tensor_saliency_dev(ten, sal, order)
     ctx.synchronize()
     nsal = int((sal_thr != 0).sum().item())
-    assert abs(nsal / N ** 3 - P["best_fraction"]) < 1e-3 and thr > 0
+    assert abs(nsal / nvox - P["best_fraction"]) < 1e-3 and thr > 0
 
+    seen_dense = False
+    for (z0, y0, x0) in crops:
+        c0 = np.array([z0, y0, x0])
+        lo = np.maximum(c0 - h, 0)
+        hi = np.minimum(c0 + E + h, dims)
+        s_sub = _crop(sal_thr, lo, hi)
+        d_sub = np.ascontiguousarray(np.stack([_crop(dirs[k], lo, hi) for k in range(3)], axis=-1))
+        want = oracle.tv_dense_stick(s_sub, d_sub, sigma_tv, P["tv_exponent"], 2.0 ** 0.5)
+        o = c0 - lo
+        want_c = want[o[0]:o[0] + E, o[1]:o[1] + E, o[2]:o[2] + E]
+        got_c = np.ascontiguousarray(np.stack([_crop(ten[k], c0, c0 + E) for k in range(6)], axis=-1))
+        assert np.abs(want_c).max() > 0
+        assert_bits_equal(got_c, want_c, "vote tensor in the crop at %s" % ((z0, y0, x0),))
+        seen_dense = seen_dense or (s_sub != 0).mean() > dense
+        # post-vote score of the crop (eigen-derived: 1e-5 of the field's scale)
+        s2 = np.zeros(want_c.shape[:3], np.float32)
+        oracle.tensor_saliency(np.ascontiguousarray(want_c), po.ORDER_DECREASING, s2)
+        assert_close_rel(_crop(sal, c0, c0 + E), s2, 1e-5, "post-vote score in the crop at %s" % ((z0, y0, x0),))
+    assert seen_dense, "no crop sits on a membrane (sender density well above the 5 % average)"
+
+    # the ridge stage that fed the votes, at full size: saliency before thresholding within 1e-5 of the oracle's on a
+    # crop + halo (Gaussian window + finite differences), and the threshold cut consistent with it
+    hg = int(math.floor(np.float32(sigma) * np.float32(ratio))) + 1
+    for (z0, y0, x0) in crops[:ridge_crops]:
+        c0 = np.array([z0, y0, x0])
+        lo = np.maximum(c0 - hg, 0)
+        hi = np.minimum(c0 + E + hg, dims)
+        sub = _crop(src, lo, hi)
+        _, hess = oracle.calc_hessian(sub, np.float32(sigma), ratio)
+        s_o, _ = oracle.hessian_saliency(hess, po.ORDER_DECREASING)
+        o = c0 - lo
+        # faces of the crop that are interior to the big volume see a different boundary normaliser: compare away from them
+        inner = [slice(o[k] + (hg if lo[k] > 0 else 0), o[k] + E - (hg if hi[k] < dims[k] else 0)) for k in range(3)]
+        innerg = [slice(c0[k] + (hg if lo[k] > 0 else 0), c0[k] + E - (hg if hi[k] < dims[k] else 0)) for k in range(3)]
+        a = sal_thr[innerg[0], innerg[1], innerg[2]].cpu().numpy()
+        b = s_o[inner[0], inner[1], inner[2]]
+        kept = a != 0
+        scale = float(np.abs(b).max())
+        assert np.all(np.abs(a[kept] - b[kept]) <= 1e-5 * scale), "saliency of kept voxels at %s" % ((z0, y0, x0),)
+        # voxels the device zeroed lie below the threshold, up to the tolerance band around it
+        assert np.all(b[~kept] < thr + 1e-5 * scale), "thresholded voxels at %s" % ((z0, y0, x0),)
+
+
+def test_membrane_1024_cubed_crops_equal_oracle(gpu, volume, oracle):
+    """BASELINE config 4: `-membrane minima 3 -tv 5 -tv-angle-exponent 4` on 1024^3 (sigma 1.732, top 5 %, sigma_tv 8.66,
+    25^3 vote window), every stage fed by the previous device stage as in bench.py."""
     # membranes of the synthetic volume (bench.synth_volume): the tilted plane 0.15 x - 0.1 y + z = 0.35 N and the shell
     # of radius 0.3 N around (0.5, 0.4, 0.5) N
     zp = lambda y, x: int(round(0.35 * N - 0.15 * x + 0.1 * y))
@@ -96,47 +144,33 @@ def test_membrane_1024_cubed_crops_equal_oracle(gpu, volume, oracle):
         (zp(200, 300) - E // 2, 200, 300),           # on the tilted membrane
         (int(0.5 * N + 0.3 * N) - E // 2, int(0.4 * N), int(0.5 * N)),   # on the shell (its top)
     ]
-    seen_dense = False
-    for (z0, y0, x0) in crops:
-        c0 = np.array([z0, y0, x0])
-        lo = np.maximum(c0 - h, 0)
-        hi = np.minimum(c0 + E + h, N)
-        s_sub = _crop(sal_thr, lo, hi)
-        d_sub = np.ascontiguousarray(np.stack([_crop(dirs[k], lo, hi) for k in range(3)], axis=-1))
-        want = oracle.tv_dense_stick(s_sub, d_sub, sigma_tv, P["tv_exponent"], 2.0 ** 0.5)
-        o = c0 - lo
-        want_c = want[o[0]:o[0] + E, o[1]:o[1] + E, o[2]:o[2] + E]
-        got_c = np.ascontiguousarray(np.stack([_crop(ten[k], c0, c0 + E) for k in range(6)], axis=-1))
-        assert np.abs(want_c).max() > 0
-        assert_bits_equal(got_c, want_c, "vote tensor in the crop at %s" % ((z0, y0, x0),))
-        seen_dense = seen_dense or (s_sub != 0).mean() > 0.12
-        # post-vote score of the crop (eigen-derived: 1e-5 of the field's scale)
-        s2 = np.zeros(want_c.shape[:3], np.float32)
-        oracle.tensor_saliency(np.ascontiguousarray(want_c), po.ORDER_DECREASING, s2)
-        assert_close_rel(_crop(sal, c0, c0 + E), s2, 1e-5, "post-vote score in the crop at %s" % ((z0, y0, x0),))
-    assert seen_dense, "no crop sits on a membrane (sender density several times the 5 % average)"
+    _check_membrane(gpu, oracle, volume, crops, E)
 
-    # the ridge stage that fed the votes, at full size: saliency before thresholding within 1e-5 of the oracle's on a
-    # crop + halo (Gaussian window + finite differences), and the threshold cut consistent with it
-    hg = int(math.floor(np.float32(sigma) * np.float32(ratio))) + 1
-    for (z0, y0, x0) in crops[:4]:
-        c0 = np.array([z0, y0, x0])
-        lo = np.maximum(c0 - hg, 0)
-        hi = np.minimum(c0 + E + hg, N)
-        sub = _crop(src, lo, hi)
-        _, hess = oracle.calc_hessian(sub, np.float32(sigma), ratio)
-        s_o, _ = oracle.hessian_saliency(hess, po.ORDER_DECREASING)
-        o = c0 - lo
-        # faces of the crop that are interior to the big volume see a different boundary normaliser: compare away from them
-        inner = [slice(o[k] + (hg if lo[k] > 0 else 0), o[k] + E - (hg if hi[k] < N else 0)) for k in range(3)]
-        innerg = [slice(c0[k] + (hg if lo[k] > 0 else 0), c0[k] + E - (hg if hi[k] < N else 0)) for k in range(3)]
-        a = sal_thr[innerg[0], innerg[1], innerg[2]].cpu().numpy()
-        b = s_o[inner[0], inner[1], inner[2]]
-        kept = a != 0
-        scale = float(np.abs(b).max())
-        assert np.all(np.abs(a[kept] - b[kept]) <= 1e-5 * scale), "saliency of kept voxels at %s" % ((z0, y0, x0),)
-        # voxels the device zeroed lie below the threshold, up to the tolerance band around it
-        assert np.all(b[~kept] < thr + 1e-5 * scale), "thresholded voxels at %s" % ((z0, y0, x0),)
+
+def test_config5_plane_block_crops_equal_oracle(gpu, oracle):
+    """BASELINE config 5's per-GPU regime: 2048 x 2048 planes (4 times the tiles of the 1024^3 case per plane, 16 MB
+    planes) -- a block of 160 planes of the 2048 x 2048 x 4096 volume, generated from their global z like a slab of the
+    8-GPU run (bench.synth_volume with z_offset), through the same stages; crops at corners, faces, across unit seams
+    and on the tilted membrane (0.15 x - 0.1 y + z = 0.35 * 4096) against the oracle."""
+    import bench
+    torch, dev, ctx = gpu
+    ctx.trim()     # the 1024^3 tests' workspace is not needed any more
+    torch.cuda.empty_cache()
+    nzb, n2, z_off, nzg = 160, 2048, 1370, 4096
+    src = bench.synth_volume(torch, ctx, (nzb, n2, n2), dev, seed=12345, z_offset=z_off, nz_global=nzg)
+    torch.cuda.synchronize()
+    E = 28
+    zp = lambda y, x: int(round(0.35 * nzg - 0.15 * x + 0.1 * y)) - z_off     # local plane of the tilted membrane
+    assert 20 < zp(1000, 600) < nzb - 40
+    crops = [
+        (0, 0, 0),
+        (nzb - E, n2 - E, n2 - E),
+        (64 - E // 2, 32 * 40 - E // 2, 8 * 201 - E // 2),        # across run seams (z = 64) and tile seams in y and x
+        (96 - 5, n2 - E, 1024 - E // 2),                          # run seam at z = 96, y face, the middle of a row
+        (zp(1000, 600) - E // 2, 1000, 600),                      # on the tilted membrane
+        (nzb - E, 3, n2 - E),
+    ]
+    _check_membrane(gpu, oracle, src, crops, E, dense=0.09, ridge_crops=3)
 
 
 def test_blob_1024_cubed_crops_equal_oracle(gpu, volume, oracle):
