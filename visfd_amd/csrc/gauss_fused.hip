@@ -75,6 +75,15 @@ struct FusedCfg {
   // (two lanes per pair task): half the instructions for the same outputs
   static constexpr int YREM = YTASKS % 64;
   static constexpr bool YLAST_SINGLE = (YV == 2) && YREM > 0 && YREM <= 32;
+  // ROW BLOCKING of the Y pass (YBLOCK): a lane filters BOTH rows of its wave for one column pair from ONE window of
+  // 2H+2 source rows -- 2H+2 LDS reads for two output rows instead of 2(2H+1): the LDS return path (128 B per clock and
+  // CU) is as busy as the VALU in this kernel.  The column pairs beyond a multiple of 64 are filtered
+  // on single columns, one (column, row) per lane, as before.  Used when that remainder fits one round.
+  static constexpr int NPAIR = HX / 2;
+  static constexpr int YB_FULL = NPAIR / 64;       // blocked rounds
+  static constexpr int YB_REM = NPAIR % 64;        // column pairs left for the single-column round
+  static constexpr bool YBLOCK = (YV == 2) && (RPW == 2) && YB_FULL >= 1 && YB_REM * RPW * 2 <= 64;
+  static constexpr int YB_ROUNDS = YB_FULL + (YB_REM > 0 ? 1 : 0);
   static constexpr int XV = XV_;                   // outputs per lane in the X pass (2 or 4)
   static constexpr int XTASKS = (TX / XV) * RPW;   // per wave
   static constexpr int XROUNDS = (XTASKS + 63) / 64;
@@ -200,13 +209,24 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
   }
   const int lds_base = 4 * tid;   // BYTE offset of column c in sZ: lds_base + 4 * NT * c
   const int lane = tid & 63, wave = tid >> 6;
-  int y_off[C::YROUNDS];    // LDS BYTE offset of (row y, column pair xp); -1: idle lane
+  constexpr int NYR = C::YBLOCK ? C::YB_ROUNDS : C::YROUNDS;
+  int y_off[NYR];    // LDS BYTE offset of (row y, column pair xp); -1: idle lane
+  if constexpr (C::YBLOCK) {
 #pragma unroll
-  for (int r = 0; r < C::YROUNDS; r++) {
-    const bool single = C::YLAST_SINGLE && r == C::YROUNDS - 1;
-    const int task = single ? (r * 64 + (lane >> 1)) : (lane + r * 64);
-    const int yy = task / (C::HX / C::YV), xp = task - yy * (C::HX / C::YV);
-    y_off[r] = (task < C::YTASKS) ? 4 * ((wave * C::RPW + yy) * C::SX + C::YV * xp + (single ? (lane & 1) : 0)) : -1;
+    for (int r = 0; r < C::YB_FULL; r++) y_off[r] = 4 * ((wave * C::RPW) * C::SX + 2 * (lane + 64 * r));   // both rows
+    if (C::YB_REM > 0) {   // (column, row) per lane: lane = 2 * (row * YB_REM + pair) + column
+      const int task = lane >> 1;
+      const int yy = task / C::YB_REM, xp = 64 * C::YB_FULL + (task - yy * C::YB_REM);
+      y_off[NYR - 1] = (task < C::YB_REM * C::RPW) ? 4 * ((wave * C::RPW + yy) * C::SX + 2 * xp + (lane & 1)) : -1;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < C::YROUNDS; r++) {
+      const bool single = C::YLAST_SINGLE && r == C::YROUNDS - 1;
+      const int task = single ? (r * 64 + (lane >> 1)) : (lane + r * 64);
+      const int yy = task / (C::HX / C::YV), xp = task - yy * (C::HX / C::YV);
+      y_off[r] = (task < C::YTASKS) ? 4 * ((wave * C::RPW + yy) * C::SX + C::YV * xp + (single ? (lane & 1) : 0)) : -1;
+    }
   }
   int x_off[C::XROUNDS];
   unsigned o_off[C::XROUNDS];  // byte offset of the output quad inside a plane (OOB outside)
@@ -290,10 +310,30 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
   auto yx_passes = [&](int z, const float* sZ) {
         // Y pass: two adjacent x per lane; source rows y+2H (j=-H) down to y (j=+H)
 #pragma unroll
-        for (int r = 0; r < C::YROUNDS; r++) {
-          if (y_off[r] >= 0) {
+        for (int r = 0; r < NYR; r++) {
+          if (C::YBLOCK && r < C::YB_FULL) {
+            // both rows of the wave for one column pair: window rows y+1+2H (v[0]) down to y (v[W]); the upper row's sum
+            // runs over v[0..W-1], the lower row's over v[1..W], each with j ascending as the reference
             const float* base = reinterpret_cast<const float*>(reinterpret_cast<const char*>(sZ) + y_off[r]);
-            if (C::YV == 2 && !(C::YLAST_SINGLE && r == C::YROUNDS - 1)) {
+            float2 v[W + 1];
+#pragma unroll
+            for (int jj = 0; jj <= W; jj++) v[jj] = lds_read_f2(base + (2 * H + 1 - jj) * C::SX);
+            float a00 = 0.0f, a01 = 0.0f, a10 = 0.0f, a11 = 0.0f;
+#pragma unroll
+            for (int jj = 0; jj < W; jj++) {
+              const float t = tap_y(jj);
+              const float p10 = t * v[jj].x, p11 = t * v[jj].y;
+              const float p00 = t * v[jj + 1].x, p01 = t * v[jj + 1].y;
+              a10 = jj == 0 ? p10 : a10 + p10;
+              a11 = jj == 0 ? p11 : a11 + p11;
+              a00 = jj == 0 ? p00 : a00 + p00;
+              a01 = jj == 0 ? p01 : a01 + p01;
+            }
+            *reinterpret_cast<float2*>(reinterpret_cast<char*>(sY) + y_off[r]) = make_float2(a00, a01);
+            *reinterpret_cast<float2*>(reinterpret_cast<char*>(sY) + y_off[r] + 4 * C::SX) = make_float2(a10, a11);
+          } else if (y_off[r] >= 0) {
+            const float* base = reinterpret_cast<const float*>(reinterpret_cast<const char*>(sZ) + y_off[r]);
+            if (!C::YBLOCK && C::YV == 2 && !(C::YLAST_SINGLE && r == C::YROUNDS - 1)) {
               float a0 = 0.0f, a1 = 0.0f;
               float2 v[W];   // the whole window is requested before the first use: one LDS round trip per round
 #pragma unroll
@@ -336,11 +376,17 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
         for (int r = 0; r < C::XROUNDS; r++) {
           float v[C::XV * C::XWINV];
           float dxy[C::XV], rcp_int[C::XV];   // requested together with the window (only this thread touches these LDS words)
-          if (NORMALIZE) {
-#pragma unroll
-            for (int k = 0; k < C::XV; k++) {
-              dxy[k] = sK[((2 * r) * NT + tid) * C::XV + k];
-              rcp_int[k] = sK[((2 * r + 1) * NT + tid) * C::XV + k];
+          if (NORMALIZE) {   // one vector read each (XV consecutive floats per thread, 16-byte aligned for XV = 4)
+            if constexpr (C::XV == 4) {
+              const float4 q0 = *reinterpret_cast<const float4*>(&sK[((2 * r) * NT + tid) * 4]);
+              const float4 q1 = *reinterpret_cast<const float4*>(&sK[((2 * r + 1) * NT + tid) * 4]);
+              dxy[0] = q0.x; dxy[1] = q0.y; dxy[2] = q0.z; dxy[3] = q0.w;
+              rcp_int[0] = q1.x; rcp_int[1] = q1.y; rcp_int[2] = q1.z; rcp_int[3] = q1.w;
+            } else {
+              const float2 q0 = *reinterpret_cast<const float2*>(&sK[((2 * r) * NT + tid) * 2]);
+              const float2 q1 = *reinterpret_cast<const float2*>(&sK[((2 * r + 1) * NT + tid) * 2]);
+              dxy[0] = q0.x; dxy[1] = q0.y;
+              rcp_int[0] = q1.x; rcp_int[1] = q1.y;
             }
           }
           if (C::XV == 4) {
