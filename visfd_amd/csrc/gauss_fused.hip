@@ -39,6 +39,13 @@
 #error "compile with -DVH_FUSED_H=<halfwidth>"
 #endif
 
+#ifndef VH_FUSED_ZFILL
+#define VH_FUSED_ZFILL 1
+#endif
+#ifndef VH_FUSED_STAGGER
+#define VH_FUSED_STAGGER 0
+#endif
+
 namespace vh {
 
 namespace {
@@ -114,6 +121,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 // 8 cycles for 1 KB, ds_read_b64 2 cycles for 512 B) -- and the Y pass is bound by exactly these reads
 // (profiles/r02_gauss_experiments.txt).  Volatile accesses are not merged.
 #define VH_LDS __attribute__((address_space(3)))
+__device__ __forceinline__ float lds_read_f1(const float* p) {
+  return *(const volatile VH_LDS float*)(uintptr_t)(const VH_LDS void*)p;
+}
 __device__ __forceinline__ float2 lds_read_f2(const float* p) {
 #if defined(VH_FUSED_EXP) && VH_FUSED_EXP == 4   // experiment 4: no LDS reads in the Y pass
   float x = 1.0f, y = 2.0f;
@@ -292,9 +302,10 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
   // (checked on the host, bit for bit), so t[j]*f[k] and t[-j]*f[k] are the same IEEE product and only
   // H+1 multiplies are needed per input instead of 2H+1.  Slot of output i: (ktop + H - i) mod W
   // = (u + H - j) mod W at step number congruent to u.
-  auto z_scatter = [&](int u) {
+  auto z_scatter_cols = [&](int u, int c_lo, int c_hi) {   // (columns [c_lo, c_hi); all arguments constants after inlining)
 #pragma unroll
     for (int c = 0; c < C::NC; c++) {
+      if (c < c_lo || c >= c_hi) continue;
       float pr[H + 1];
 #pragma unroll
       for (int m = 0; m <= H; m++) pr[m] = tap_z(m) * xin[c];
@@ -306,8 +317,14 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
       }
     }
   };
+  auto z_scatter = [&](int u) { z_scatter_cols(u, 0, C::NC); };
+  // FILL: the Z pass of the NEXT plane is independent of the Y and X passes of this one, and every Y or X round starts
+  // with an LDS round trip that four waves per SIMD do not cover.  With VH_FUSED_ZFILL the ring update is cut into three
+  // column groups that run right after the reads of the first Y round, the last Y round and the first X round have
+  // been requested.
+  constexpr int ZF0 = C::NC / 3, ZF1 = (2 * C::NC) / 3;
   // Y and X passes of output plane z from the Z-filtered (or, without a Z pass, the source) tile sZ
-  auto yx_passes = [&](int z, const float* sZ) {
+  auto yx_passes = [&](int z, const float* sZ, auto&& zfill) {
         // Y pass: two adjacent x per lane; source rows y+2H (j=-H) down to y (j=+H)
 #pragma unroll
         for (int r = 0; r < NYR; r++) {
@@ -318,6 +335,10 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
             float2 v[W + 1];
 #pragma unroll
             for (int jj = 0; jj <= W; jj++) v[jj] = lds_read_f2(base + (2 * H + 1 - jj) * C::SX);
+            if (r == 0) {
+              zfill(0);
+              if (C::YB_REM == 0) zfill(1);
+            }
             float a00 = 0.0f, a01 = 0.0f, a10 = 0.0f, a11 = 0.0f;
 #pragma unroll
             for (int jj = 0; jj < W; jj++) {
@@ -331,9 +352,24 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
             }
             *reinterpret_cast<float2*>(reinterpret_cast<char*>(sY) + y_off[r]) = make_float2(a00, a01);
             *reinterpret_cast<float2*>(reinterpret_cast<char*>(sY) + y_off[r] + 4 * C::SX) = make_float2(a10, a11);
+          } else if (C::YBLOCK) {
+            // the column pairs beyond the blocked rounds, one (column, row) per lane; every lane reads (idle lanes their
+            // own first column) so that the fill work can stand between the reads and their use
+            const float* base = reinterpret_cast<const float*>(reinterpret_cast<const char*>(sZ) + (y_off[r] >= 0 ? y_off[r] : 0));
+            float a0 = 0.0f;
+            float v[W];
+#pragma unroll
+            for (int jj = 0; jj < W; jj++) v[jj] = lds_read_f1(base + (2 * H - jj) * C::SX);
+            zfill(1);
+#pragma unroll
+            for (int jj = 0; jj < W; jj++) {
+              const float p0 = tap_y(jj) * v[jj];
+              a0 = jj == 0 ? p0 : a0 + p0;
+            }
+            if (y_off[r] >= 0) *reinterpret_cast<float*>(reinterpret_cast<char*>(sY) + y_off[r]) = a0;
           } else if (y_off[r] >= 0) {
             const float* base = reinterpret_cast<const float*>(reinterpret_cast<const char*>(sZ) + y_off[r]);
-            if (!C::YBLOCK && C::YV == 2 && !(C::YLAST_SINGLE && r == C::YROUNDS - 1)) {
+            if (C::YV == 2 && !(C::YLAST_SINGLE && r == C::YROUNDS - 1)) {
               float a0 = 0.0f, a1 = 0.0f;
               float2 v[W];   // the whole window is requested before the first use: one LDS round trip per round
 #pragma unroll
@@ -404,6 +440,7 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
               v[2 * k] = q.x; v[2 * k + 1] = q.y;
             }
           }
+          if (r == 0) zfill(2);
           float a[C::XV];
 #pragma unroll
           for (int k = 0; k < C::XV; k++) a[k] = 0.0f;
@@ -541,7 +578,7 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
         *reinterpret_cast<float*>(reinterpret_cast<char*>(sZ) + lds_base + 4 * NT * c) = xin[c];
       request_plane(z - 1, n + 1 < nout);
       __syncthreads();
-      yx_passes(z, sZ);
+      yx_passes(z, sZ, [](int) {});
     }
     return;
   }
@@ -555,14 +592,18 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
   // Z pass of the step that completes output plane number n (z = ze-1-n; ring phase u = (n + W-1) % W, a constant at
   // every call site), its tile into LDS buffer n & 1, and the request for the next input plane, whose latency the
   // rest of the interval covers
-  auto z_step = [&](auto U, int n) {
+  auto z_store = [&](auto U, int n) {   // the completed sums of plane n into its LDS buffer; request of the next input plane
     constexpr int u = decltype(U)::value;
     float* sZ = sZ2[n & 1];
-    z_scatter(u);
 #pragma unroll
     for (int c = 0; c < C::NC; c++)
       *reinterpret_cast<float*>(reinterpret_cast<char*>(sZ) + lds_base + 4 * NT * c) = ring[c][u];
     request_plane(ze - 1 - n - H - 1, n + 1 < nout);
+  };
+  auto z_step = [&](auto U, int n) {
+    constexpr int u = decltype(U)::value;
+    z_scatter(u);
+    z_store(U, n);
   };
   z_step(std::integral_constant<int, W - 1>{}, 0);
   // Main loop, one workgroup barrier per plane.  Between two barriers every wave runs the Y and X passes of plane n
@@ -587,15 +628,28 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
         VH_STAMP(3);
         // (the Z pass, which updates the register ring, stands once in the code; the Y/X passes stand before and
         // after it and each wave runs one of the two copies)
-        if (!z_first) {   // uniform per wave
-          yx_passes(ze - 1 - n, sZ2[n & 1]);
-          VH_STAMP(6);
-        }
-        if (n + 1 < nout) z_step(V, n + 1);
-        VH_STAMP(1);
-        if (z_first) {
-          yx_passes(ze - 1 - n, sZ2[n & 1]);
-          VH_STAMP(6);
+        if (VH_FUSED_ZFILL && C::YBLOCK && H <= 3 && !VH_FUSED_STAGGER) {
+          // the ring update of plane n+1 runs inside the Y/X passes of plane n, in three pieces behind their LDS requests.
+          // Only for the small windows: the pieces need the next input plane EARLY in the interval, and at H >= 4 (one
+          // 1024-thread workgroup per CU, 2.2 us per plane) that exposes the HBM latency the old order hides -- H = 2, 3:
+          // -6...-9 %, H = 4: +-0, H = 5: +2.5 % (profiles/r02_gauss_experiments.txt)
+          const bool more = n + 1 < nout;   // uniform
+          yx_passes(ze - 1 - n, sZ2[n & 1], [&](int k) {
+            if (more) z_scatter_cols(v, k == 0 ? 0 : (k == 1 ? ZF0 : ZF1), k == 0 ? ZF0 : (k == 1 ? ZF1 : C::NC));
+          });
+          if (more) z_store(V, n + 1);
+          VH_STAMP(1);
+        } else {
+          if (!z_first) {   // uniform per wave
+            yx_passes(ze - 1 - n, sZ2[n & 1], [](int) {});
+            VH_STAMP(6);
+          }
+          if (n + 1 < nout) z_step(V, n + 1);
+          VH_STAMP(1);
+          if (z_first) {
+            yx_passes(ze - 1 - n, sZ2[n & 1], [](int) {});
+            VH_STAMP(6);
+          }
         }
       }
     });
