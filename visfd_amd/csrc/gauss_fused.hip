@@ -82,14 +82,16 @@ struct FusedCfg {
   // (two lanes per pair task): half the instructions for the same outputs
   static constexpr int YREM = YTASKS % 64;
   static constexpr bool YLAST_SINGLE = (YV == 2) && YREM > 0 && YREM <= 32;
-  // ROW BLOCKING of the Y pass (YBLOCK): a lane filters BOTH rows of its wave for one column pair from ONE window of
-  // 2H+2 source rows -- 2H+2 LDS reads for two output rows instead of 2(2H+1): the LDS return path (128 B per clock and
-  // CU) is as busy as the VALU in this kernel.  The column pairs beyond a multiple of 64 are filtered
-  // on single columns, one (column, row) per lane, as before.  Used when that remainder fits one round.
-  static constexpr int NPAIR = HX / 2;
-  static constexpr int YB_FULL = NPAIR / 64;       // blocked rounds
-  static constexpr int YB_REM = NPAIR % 64;        // column pairs left for the single-column round
-  static constexpr bool YBLOCK = (YV == 2) && (RPW == 2) && YB_FULL >= 1 && YB_REM * RPW * 2 <= 64;
+  // ROW BLOCKING of the Y pass (YBLOCK): a lane filters BOTH rows of its wave for one unit of YV columns from ONE window
+  // of 2H+2 source rows -- 2H+2 LDS reads for two output rows instead of 2(2H+1), and one LDS round trip instead of two:
+  // the round trips in front of the Y and X arithmetic are what four waves per SIMD do not cover.  The
+  // units beyond a multiple of 64 are filtered on single columns, one (column, row) per lane, as before.  Used when
+  // that remainder fits one round.
+  static constexpr int NUNIT = HX / YV;
+  static constexpr int YB_FULL = NUNIT / 64;       // blocked rounds
+  static constexpr int YB_REM = NUNIT % 64;        // units left for the single-column round
+  static constexpr int YB_RCOLS = YB_REM * YV;     // their columns
+  static constexpr bool YBLOCK = (RPW == 2) && YB_FULL >= 1 && YB_RCOLS * RPW <= 64;
   static constexpr int YB_ROUNDS = YB_FULL + (YB_REM > 0 ? 1 : 0);
   static constexpr int XV = XV_;                   // outputs per lane in the X pass (2 or 4)
   static constexpr int XTASKS = (TX / XV) * RPW;   // per wave
@@ -223,11 +225,10 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
   int y_off[NYR];    // LDS BYTE offset of (row y, column pair xp); -1: idle lane
   if constexpr (C::YBLOCK) {
 #pragma unroll
-    for (int r = 0; r < C::YB_FULL; r++) y_off[r] = 4 * ((wave * C::RPW) * C::SX + 2 * (lane + 64 * r));   // both rows
-    if (C::YB_REM > 0) {   // (column, row) per lane: lane = 2 * (row * YB_REM + pair) + column
-      const int task = lane >> 1;
-      const int yy = task / C::YB_REM, xp = 64 * C::YB_FULL + (task - yy * C::YB_REM);
-      y_off[NYR - 1] = (task < C::YB_REM * C::RPW) ? 4 * ((wave * C::RPW + yy) * C::SX + 2 * xp + (lane & 1)) : -1;
+    for (int r = 0; r < C::YB_FULL; r++) y_off[r] = 4 * ((wave * C::RPW) * C::SX + C::YV * (lane + 64 * r));   // both rows
+    if (C::YB_REM > 0) {   // (column, row) per lane: lane = row * YB_RCOLS + column
+      const int yy = lane / C::YB_RCOLS, xc = 64 * C::YB_FULL * C::YV + (lane - yy * C::YB_RCOLS);
+      y_off[NYR - 1] = (lane < C::YB_RCOLS * C::RPW) ? 4 * ((wave * C::RPW + yy) * C::SX + xc) : -1;
     }
   } else {
 #pragma unroll
@@ -332,26 +333,47 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
             // both rows of the wave for one column pair: window rows y+1+2H (v[0]) down to y (v[W]); the upper row's sum
             // runs over v[0..W-1], the lower row's over v[1..W], each with j ascending as the reference
             const float* base = reinterpret_cast<const float*>(reinterpret_cast<const char*>(sZ) + y_off[r]);
-            float2 v[W + 1];
+            if constexpr (C::YV == 2) {
+              float2 v[W + 1];
 #pragma unroll
-            for (int jj = 0; jj <= W; jj++) v[jj] = lds_read_f2(base + (2 * H + 1 - jj) * C::SX);
-            if (r == 0) {
-              zfill(0);
-              if (C::YB_REM == 0) zfill(1);
-            }
-            float a00 = 0.0f, a01 = 0.0f, a10 = 0.0f, a11 = 0.0f;
+              for (int jj = 0; jj <= W; jj++) v[jj] = lds_read_f2(base + (2 * H + 1 - jj) * C::SX);
+              if (r == 0) {
+                zfill(0);
+                if (C::YB_REM == 0) zfill(1);
+              }
+              float a00 = 0.0f, a01 = 0.0f, a10 = 0.0f, a11 = 0.0f;
 #pragma unroll
-            for (int jj = 0; jj < W; jj++) {
-              const float t = tap_y(jj);
-              const float p10 = t * v[jj].x, p11 = t * v[jj].y;
-              const float p00 = t * v[jj + 1].x, p01 = t * v[jj + 1].y;
-              a10 = jj == 0 ? p10 : a10 + p10;
-              a11 = jj == 0 ? p11 : a11 + p11;
-              a00 = jj == 0 ? p00 : a00 + p00;
-              a01 = jj == 0 ? p01 : a01 + p01;
+              for (int jj = 0; jj < W; jj++) {
+                const float t = tap_y(jj);
+                const float p10 = t * v[jj].x, p11 = t * v[jj].y;
+                const float p00 = t * v[jj + 1].x, p01 = t * v[jj + 1].y;
+                a10 = jj == 0 ? p10 : a10 + p10;
+                a11 = jj == 0 ? p11 : a11 + p11;
+                a00 = jj == 0 ? p00 : a00 + p00;
+                a01 = jj == 0 ? p01 : a01 + p01;
+              }
+              *reinterpret_cast<float2*>(reinterpret_cast<char*>(sY) + y_off[r]) = make_float2(a00, a01);
+              *reinterpret_cast<float2*>(reinterpret_cast<char*>(sY) + y_off[r] + 4 * C::SX) = make_float2(a10, a11);
+            } else {
+              float v[W + 1];
+#pragma unroll
+              for (int jj = 0; jj <= W; jj++) v[jj] = lds_read_f1(base + (2 * H + 1 - jj) * C::SX);
+              if (r == 0) {
+                zfill(0);
+                if (C::YB_REM == 0) zfill(1);
+              }
+              float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+              for (int jj = 0; jj < W; jj++) {
+                const float t = tap_y(jj);
+                const float p1 = t * v[jj];
+                const float p0 = t * v[jj + 1];
+                a1 = jj == 0 ? p1 : a1 + p1;
+                a0 = jj == 0 ? p0 : a0 + p0;
+              }
+              *reinterpret_cast<float*>(reinterpret_cast<char*>(sY) + y_off[r]) = a0;
+              *reinterpret_cast<float*>(reinterpret_cast<char*>(sY) + y_off[r] + 4 * C::SX) = a1;
             }
-            *reinterpret_cast<float2*>(reinterpret_cast<char*>(sY) + y_off[r]) = make_float2(a00, a01);
-            *reinterpret_cast<float2*>(reinterpret_cast<char*>(sY) + y_off[r] + 4 * C::SX) = make_float2(a10, a11);
           } else if (C::YBLOCK) {
             // the column pairs beyond the blocked rounds, one (column, row) per lane; every lane reads (idle lanes their
             // own first column) so that the fill work can stand between the reads and their use
