@@ -338,6 +338,10 @@ def main():
                        "achieved": round(tv_tflops, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tv_tflops / 157.3, 4),
                        "traffic": tv_traffic, "ms_per_launch": round(tv_ms, 2), "votes_per_launch": votes,
                        "flop_per_vote": 45, "salient_senders": n_salient, "nonzero_taps": n_taps,
+                       # the same work against what the VALU can issue without FMA: 32 multiplies/adds per vote, 70 T scalar
+                       # lane-operations/s measured on this chip (profiles/r02_microbench_valu.txt)
+                       "useful_lane_ops_per_s": round(32.0 * votes / (tv_ms * 1e-3) / 1e12, 2), "valu_issue_peak_lane_ops_per_s": 70.0,
+                       "valu_frac_useful": round(32.0 * votes / (tv_ms * 1e-3) / 70e12, 4),
                        "algorithmic_bytes": 40 * nv, "hbm_achieved_gbs": round(40.0 * nv / (tv_ms * 1e-3) / 1e9, 1),
                        "hbm_frac": round(40.0 * nv / (tv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                        "traffic_unit": "bytes per launch, measured OFFLINE (%s), not in this run" % tv_traffic_file,
