@@ -41,14 +41,15 @@ namespace vh {
 
 namespace {
 
-constexpr int NT = 256;
+constexpr int NT = 512;
 constexpr int NW = NT / 64;
-constexpr int TX = 8, TY = 32;        // receivers of a workgroup: four 8 x 8 wave patches stacked in y
+constexpr int TX = 8, TY = 32;        // receivers of a workgroup: 8 x 32 on each of TWO consecutive planes; a wave owns four
+                                      // rows of both planes (lanes 0-31: plane z, lanes 32-63: plane z+1)
 #ifndef VH_TV_CAP
 #define VH_TV_CAP 256
 #endif
 constexpr int CAP = VH_TV_CAP;       // list entries held in LDS per sweep (one per thread)
-static_assert(CAP == NT, "the replay loads one entry per thread");
+static_assert(CAP <= NT, "the replay loads one entry per thread");
 constexpr int RING_BYTES = 32;       // bytes per entry of the scratch rings
 constexpr unsigned OOB = 0x7ffffff0u;  // byte offset beyond any plane descriptor: reads give 0
 
@@ -144,10 +145,10 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
   __shared__ __attribute__((aligned(16))) uint2 l_pos[CAP + 8];
   __shared__ float l_mv[MASKED_SRC ? CAP : 1];
   __shared__ int wave_tot[2][NW];
-  __shared__ int cull[NW][2 * NW];           // per listing wave: entries above / not below the rows each wave can reach
+  __shared__ int cull[CAP / 64][2 * NW];     // per wave holding entries: entries above / not below the rows each wave can reach
   __shared__ unsigned claimed_tile;
-  __shared__ int plane_cnt[84];              // entries per ring slot, [2h+1] (h <= 40)
-  // dynamic LDS: the table slice of the current sender plane, [(2h+1)^2] float4
+  __shared__ int plane_cnt[84];              // entries per ring slot, [2h+2] (h <= 40)
+  // dynamic LDS: two table slices (jz and jz + 1 of the current sender plane), [2][(2h+1)^2] float4
   extern __shared__ __attribute__((aligned(16))) unsigned char slices[];
 
   const int tid = threadIdx.x;
@@ -160,7 +161,8 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
   const i64 nvox = plane * p.nz;
   const int plane_bytes = (int)(plane * 4);
   const size_t plane_stride = (size_t)R * RING_BYTES;
-  unsigned char* const ring = scratch + (size_t)blockIdx.x * plane_stride * S;
+  const int P = S + 1;           // sender planes a pair of receiver planes reaches = slots of the ring
+  unsigned char* const ring = scratch + (size_t)blockIdx.x * plane_stride * P;
   int npar = 0;                  // parity of the wave-total buffers
 
   // ---- persistent workgroups: units are claimed from a global counter ---------------------------------------
@@ -187,7 +189,8 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
     // the sender region starts at (x0-h, y0-h, rz-h), so the receiver sits at (lx+h, ly+h, h).  The region is exactly
     // as wide as one wave's reach in x, and list order is row order, so the senders a wave can reach are one
     // contiguous stretch of the list (see the replay below).
-    const int lx = lane & 7, ly = wave * 8 + (lane >> 3);
+    const int half = lane >> 5;                       // 0: receiver plane rz, 1: plane rz + 1
+    const int lx = lane & 7, ly = wave * 4 + ((lane & 31) >> 3);
     const int rx = x0 + lx, ry = y0 + ly;
     const bool r_in = rx < p.nx && ry < p.ny;
     // Distance test  |r - e|^2 <= h^2  as ONE dot product per (receiver, sender): with coordinates
@@ -201,7 +204,8 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
     const int recv_c = rpx * rpx + rpy * rpy - h * h - 1;
     constexpr unsigned NEVER_HIT = 0x009c0000u;   // operand whose dot product is positive for every receiver (-128 * -100)
     // (jy+h)*S + (jx+h) with jx = lx+h-ex, jy = ly+h-ey  =  [(ly+2h)*S + lx+2h] - [ey*S + ex]
-    const unsigned r16s = lds_addr(slices) + (unsigned)(16 * ((ly + 2 * h) * S + lx + 2 * h));
+    const unsigned r16_0 = lds_addr(slices) + (unsigned)(16 * ((ly + 2 * h) * S + lx + 2 * h));   // in LDS slice slot 0
+    unsigned r16s = r16_0;                                                                        // in this lane's slot
     const unsigned ent_base = lds_addr(l_ent);
 
     // ---- LISTING: sender plane sz of this tile's region into its ring slot, in vote order -------------------
@@ -248,7 +252,7 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
         total += t;
       }
       running = __builtin_amdgcn_readfirstlane(running);
-      const int slot = sz % S;
+      const int slot = sz % P;
       unsigned char* const ring_plane = ring + (size_t)slot * plane_stride;
       if (cnt > 0) {
         const __amdgpu_buffer_rsrc_t rd0 =
@@ -343,40 +347,62 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
       }
     };
 
-    // ---- the unit's receiver planes, bottom up ------------------------------------------------------------
-    int cached_lo = 1, cached_hi = 0;     // sender planes whose lists are in the ring (slot of plane sz: sz mod (2h+1))
-    for (int rz = z_run0; rz < z_run1; rz++) {
-      const int sz_hi = min(rz + h, p.nz - 1), sz_lo = max(rz - h, 0);
-      // the window holds at most 2h+1 planes, so a plane that enters it takes the slot of one that has left
+    // ---- the unit's receiver planes, bottom up, TWO AT A TIME ----------------------------------------------
+    // A sweep of sender plane sz serves the receivers of planes rz (jz = rz - sz) and rz + 1 (jz + 1) together: a wave's
+    // 64 receivers are 8 x 4 x 2 instead of 8 x 8 x 1, which a sender's ball covers better (fewer, fuller vote steps), and
+    // every list is brought into LDS once per two receiver planes.  The table slices of jz and jz + 1 sit in two LDS slots
+    // chosen by the parity of jz, so a step of the sender plane needs ONE new slice.
+    int cached_lo = 1, cached_hi = 0;     // sender planes whose lists are in the ring (slot of plane sz: sz mod (2h+2))
+    int slot_a = 1 << 20, slot_b = 1 << 20;   // which table slice LDS slot 0 / 1 holds (uniform)
+    float4* const sl4 = reinterpret_cast<float4*>(slices);
+    for (int rz = z_run0; rz < z_run1; rz += 2) {
+      const int sz_hi = min(rz + 1 + h, p.nz - 1), sz_lo = max(rz - h, 0);
+      // the window holds at most 2h+2 planes, so a plane that enters it takes the slot of one that has left
       for (int sz = sz_hi; sz >= sz_lo; sz--)   // uniform
         if (p.relist || sz < cached_lo || sz > cached_hi) list_plane(sz);
       cached_lo = sz_lo;
       cached_hi = sz_hi;
 
-      const i64 rc = (i64)rz * plane + (i64)ry * p.nx + rx;
-      const bool r_live = r_in && !(mask_dst && mask_dst[r_in ? rc : 0] == 0.0f);
-      recv_c_live = r_live ? recv_c : 0x100000;
+      const int rzl = rz + half;                               // this lane's receiver plane
+      const bool z_in = rzl < z_run1;                          // (a run of odd length ends with half a pair)
+      const i64 rc = (i64)rzl * plane + (i64)ry * p.nx + rx;
+      const bool r_live = r_in && z_in && !(mask_dst && mask_dst[(r_in && z_in) ? rc : 0] == 0.0f);
 #pragma unroll
       for (int k = 0; k < 6; k++) T[k] = 0.0f;
-      __syncthreads();   // ring entries and counts of this receiver plane are visible
+      __syncthreads();   // ring entries and counts of this pair of receiver planes are visible
 
       for (int sz = sz_hi; sz >= sz_lo; sz--) {               // jz = rz - sz ascending
-        const int slot = sz % S;
+        const int slot = sz % P;
         const int cnt = __builtin_amdgcn_readfirstlane(plane_cnt[slot]);
         if (cnt == 0) continue;   // uniform
-        // list and slice are free: every sweep ends with a barrier
-        {
-          const float4* src4 = table + (i64)(rz - sz + h) * nsl;
-          float4* sl4 = reinterpret_cast<float4*>(slices);
-          for (int i = tid; i < nsl; i += NT) sl4[i] = src4[i];
-        }
+        const int jz0 = rz - sz, jz1 = jz0 + 1;               // for the lower / upper receiver plane; one of them may be
+        const bool v0 = jz0 >= -h && jz0 <= h, v1 = jz1 >= -h && jz1 <= h;   // outside the window (never hit then)
         const unsigned char* ring_plane = ring + (size_t)slot * plane_stride;
-        const int epz = sz - rz;
+        // list and slices are free: every sweep ends with a barrier.  Slot of slice jz: (jz + h + 1) & 1.
+        {
+          const int s0 = (jz0 + h + 1) & 1, s1 = s0 ^ 1;
+          if (v0 && (s0 ? slot_b : slot_a) != jz0) {
+            const float4* src4 = table + (i64)(jz0 + h) * nsl;
+            for (int i = tid; i < nsl; i += NT) sl4[s0 * nsl + i] = src4[i];
+            (s0 ? slot_b : slot_a) = jz0;
+          }
+          if (v1 && (s1 ? slot_b : slot_a) != jz1) {
+            const float4* src4 = table + (i64)(jz1 + h) * nsl;
+            for (int i = tid; i < nsl; i += NT) sl4[s1 * nsl + i] = src4[i];
+            (s1 ? slot_b : slot_a) = jz1;
+          }
+          r16s = r16_0 + (unsigned)(16 * nsl) * (unsigned)(half ? s1 : s0);
+        }
+        const int epz = sz - rz;                               // sender plane relative to the LOWER receiver plane
         const int epz2 = epz * epz;
-        // rows a wave can reach on this plane: |r'y - e'y| <= rho = floor(sqrt(h^2 - epz^2)), r'y in [8w-16, 8w-9]
-        int rho = (int)__builtin_sqrtf((float)(h * h - epz2));
-        while (rho * rho > h * h - epz2) rho--;
-        while ((rho + 1) * (rho + 1) <= h * h - epz2) rho++;
+        // the upper plane's receivers see the sender one plane further down: |r - e|^2 grows by 1 - 2 epz
+        recv_c_live = r_live ? recv_c + (half ? 1 - 2 * epz : 0) : 0x100000;
+        // rows a wave can reach on this plane: |r'y - e'y| <= rho = floor(sqrt(h^2 - jz^2)) for the nearer of its two
+        // receiver planes, r'y in [4w-16, 4w-13]
+        const int jn = min(v0 ? jz0 * jz0 : (1 << 20), v1 ? jz1 * jz1 : (1 << 20));
+        int rho = (int)__builtin_sqrtf((float)(h * h - jn));
+        while (rho * rho > h * h - jn) rho--;
+        while ((rho + 1) * (rho + 1) <= h * h - jn) rho++;
         for (int done = 0; done < cnt; done += CAP) {          // uniform
           const int take = min(CAP, cnt - done);
           int epy = -128;                                      // threads without an entry: below every range
@@ -391,22 +417,28 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
             epy = (int)(signed char)(m.x >> 8);
           }
           if (tid < 8) l_pos[take + tid] = make_uint2(NEVER_HIT, 0u);
-          // entries are in descending row order: wave w needs those from the first one at or below row 8w-9+rho to
-          // the last one at or above row 8w-16-rho; every wave counts, among its 64 entries, both kinds for all waves
+          // entries are in descending row order: wave w needs those from the first one at or below row 4w-13+rho to
+          // the last one at or above row 4w-16-rho; the waves that hold entries count both kinds for all waves
+          if (wave < CAP / 64) {
 #pragma unroll
-          for (int w = 0; w < NW; w++) {
-            const int above = __builtin_popcountll(__builtin_amdgcn_ballot_w64(epy > 8 * w - (TY / 2 - 7) + rho));
-            const int upto = __builtin_popcountll(__builtin_amdgcn_ballot_w64(epy >= 8 * w - TY / 2 - rho));
-            if (lane == 0) { cull[wave][2 * w] = above; cull[wave][2 * w + 1] = upto; }
+            for (int w = 0; w < NW; w++) {
+              const int above = __builtin_popcountll(__builtin_amdgcn_ballot_w64(epy > 4 * w - (TY / 2 - 3) + rho));
+              const int upto = __builtin_popcountll(__builtin_amdgcn_ballot_w64(epy >= 4 * w - TY / 2 - rho));
+              if (lane == 0) { cull[wave][2 * w] = above; cull[wave][2 * w + 1] = upto; }
+            }
           }
-          __syncthreads();   // list (and slice) complete
+          __syncthreads();   // list (and slices) complete
           int i0 = 0, i1 = 0;
 #pragma unroll
-          for (int w = 0; w < NW; w++) { i0 += cull[w][2 * wave]; i1 += cull[w][2 * wave + 1]; }
+          for (int w = 0; w < CAP / 64; w++) { i0 += cull[w][2 * wave]; i1 += cull[w][2 * wave + 1]; }
           i0 = __builtin_amdgcn_readfirstlane(i0);
           i1 = __builtin_amdgcn_readfirstlane(i1);
+#if defined(VH_TV_EXP) && VH_TV_EXP == 2   // ablation (wrong results): everything but the sweeps
+          if (i0 > (1 << 20)) sweep(i0, i1);
+#else
           sweep(i0, i1);
-          __syncthreads();   // everyone done reading before the list or the slice is refilled
+#endif
+          __syncthreads();   // everyone done reading before the list or the slices are refilled
         }
       }
 
@@ -418,7 +450,7 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
           for (int k = 0; k < 6; k++) ten[k * nvox + rc] = T[k];
         }
       }
-    }   // next receiver plane of the run
+    }   // next pair of receiver planes of the run
   }   // next unit
 }
 
@@ -461,18 +493,17 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
   const i64 nblk = (i64)p.tiles_x * p.tiles_y * nruns;
   if (nblk > 0x7fffffffLL) return fail(VISFD_HIP_EINVAL, "volume too large for one launch");
   if (nblk <= 0) { *handled = true; return VISFD_HIP_OK; }
-  const size_t lds = slice_bytes;   // dynamic part: one slice (one sender plane per sweep leaves LDS for eight workgroups
-                                    // per CU; measured at 1024^3: 953 ms with two planes and five workgroups, 803 ms with one)
-  const size_t lds_static = sizeof(float4) * CAP + sizeof(uint2) * (CAP + 8) + sizeof(float) * (mask_src ? CAP : 1) + 512;
+  const size_t lds = 2 * slice_bytes;   // dynamic part: the slices of jz and jz + 1
+  const size_t lds_static = sizeof(float4) * CAP + sizeof(uint2) * (CAP + 8) + sizeof(float) * (mask_src ? CAP : 1) + 1024;
   if (lds + lds_static > 150 * 1024) return VISFD_HIP_OK;   // window too wide for the LDS slice: baseline kernel
   const int mode = weights_only ? 3 : (curves ? 1 : (exponent == 4 ? 0 : (exponent == 2 ? 2 : 1)));
   // persistent workgroups (see the kernel): as many as the chip holds at once -- LDS allows 160 KB / (static +
-  // dynamic) per CU, registers eight waves per SIMD = 8 workgroups -- each claiming units from a counter
+  // dynamic) per CU, registers eight waves per SIMD = 4 workgroups of 8 waves -- each claiming units from a counter
   unsigned* counter = nullptr;
   VH_TRY(ws(ctx, WS_COUNTER, 16, &counter));
   VH_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned), st));
   size_t wg_per_cu = (160 * 1024) / (lds + lds_static);
-  const size_t max_wg = mode == 1 ? 2 : 8;
+  const size_t max_wg = mode == 1 ? 1 : 4;   // eight waves each
   if (wg_per_cu > max_wg) wg_per_cu = max_wg;
   if (wg_per_cu < 1) wg_per_cu = 1;
   i64 ngrid = (i64)ctx->num_cus * (i64)wg_per_cu;
@@ -482,7 +513,7 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
   // wide windows are capped at 16 GB (fewer workgroups: their LDS slices allow only one or two per CU anyway); if the
   // allocation fails the grid is halved, and without any ring the caller's baseline kernel takes over.
   unsigned char* scratch = nullptr;
-  const size_t per_wg = (size_t)n * R * RING_BYTES;
+  const size_t per_wg = (size_t)(n + 1) * R * RING_BYTES;
   if ((size_t)ngrid * per_wg > ((size_t)16 << 30)) ngrid = (i64)(((size_t)16 << 30) / per_wg);
   for (; ngrid >= 1; ngrid /= 2) {
     if (ws(ctx, WS_TVSCRATCH, per_wg * (size_t)ngrid, &scratch) == VISFD_HIP_OK) break;
