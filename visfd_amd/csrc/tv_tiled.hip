@@ -6,21 +6,23 @@
 // receiver:
 //
 //   * workgroups are PERSISTENT: as many as the chip holds, each claiming units of work -- an 8 x 32 tile of receivers
-//     (one per thread; each wave an 8 x 8 patch, the four patches stacked in y) over a run of 32 consecutive receiver
-//     planes -- from a global counter until it is exhausted (a plain grid left wave slots empty on volumes whose sender
-//     density varies, see the kernel);
+//     over a run of 32 consecutive receiver planes -- from a global counter until it is exhausted (a plain grid left wave
+//     slots empty on volumes whose sender density varies, see the kernel).  Receiver planes are taken TWO AT A TIME: one
+//     receiver per thread, a wave = 8 x 4 x 2 receivers (lanes 0-31 on plane z, lanes 32-63 on plane z+1), eight waves;
 //   * LISTING: the salient, unmasked senders of the (8+2h) x (32+2h) region of a sender plane -- saliency, normal, position
 //     bytes, table offset, mask value: 32 bytes -- are compacted IN VOTE ORDER (ordered, ballot-based prefix sums:
-//     deterministic) into a per-workgroup ring of 2h+1 planes in global memory, once per unit and plane: consecutive
-//     receiver planes share 2h of their 2h+1 sender planes, so all but the first plane of a run list one new plane;
-//   * for a receiver plane z, sender planes are visited from z+h down to z-h (= jz ascending): the plane's list is
-//     read back from the ring (L2) into LDS together with the (2h+1)^2 slice of the vote table for that jz;
+//     deterministic) into a per-workgroup ring of 2h+2 planes in global memory, once per unit and plane: consecutive
+//     pairs of receiver planes share 2h of their 2h+2 sender planes, so all but the first pair of a run list two new planes;
+//   * for the receiver planes z and z+1, sender planes are visited from z+1+h down to z-h (= jz ascending for both): the
+//     plane's list is read back from the ring (L2) into LDS; the (2h+1)^2 slices of the vote table for jz and jz+1 sit in
+//     two LDS slots chosen by the parity of jz, so a step of the sender plane copies one new slice;
 //   * the SWEEP: every wave walks the list in order.  A sender is tested against the wave's 64 receivers --
 //     jx^2+jy^2+jz^2 <= h^2 as ONE v_dot4_i32_i8 on signed bytes (see the kernel), an exact superset of the table's
 //     spherical support -- and voted at once by the lanes it reaches, under their execution mask.  The sender's data
 //     come from uniform-address (broadcast) LDS reads: no bank conflicts, no per-lane bookkeeping.  The region is as wide
 //     as one wave's reach in x and the list is in row order, so a wave sweeps only the contiguous stretch of the list
-//     whose rows it can reach on that plane (8 + 2 sqrt(h^2 - jz^2) of the 32 + 2h rows);
+//     whose rows it can reach on that plane (4 + 2 sqrt(h^2 - jz^2) of the 32 + 2h rows).  The upper receiver plane's
+//     distance test is the lower one's plus a per-plane constant in the accumulator operand;
 //   * weights and unit displacements come from the LDS copy of the table slice (w, rhat_x, rhat_y, rhat_z as one
 //     float4, signs included).  The table index is linear in j = receiver - sender, so the byte address of a vote's
 //     table entry is  R(lane) - E(sender):  one subtraction per vote.
