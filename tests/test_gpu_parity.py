@@ -417,6 +417,21 @@ def test_tensor_voting_wide_windows(ctx, oracle, sigma_tv, shape, monkeypatch):
             assert_bits_equal(ten, ref_m, "masked tensor sigma_tv=%g %s" % (sigma_tv, opts))
 
 
+@pytest.mark.parametrize("sigma_tv,h", [(19.2, 27), (24.1, 34)])
+def test_tensor_voting_very_wide_windows(ctx, oracle, sigma_tv, h):
+    """Windows far wider than BASELINE's: h = 27 still runs the tiled kernel (two table slices of 48 KB each, one
+    workgroup per CU), h = 34 no longer fits its slices into LDS and goes to the baseline kernel."""
+    import math
+    assert int(math.floor(np.float32(sigma_tv) * np.float32(math.sqrt(2.0)))) == h
+    shape = (9, 37, 30)
+    sal, dirs = _sparse_field(shape, seed=h)
+    ref = oracle.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5)
+    assert np.abs(ref).max() > 0
+    for opts in ({}, {"tv_max_wg": 2, "tv_zrun": 3}):
+        with ctx.options(**opts):
+            assert_bits_equal(ctx.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5), ref, "tensor h=%d %s" % (h, opts))
+
+
 def test_tensor_voting_dense_saliency(ctx, oracle):
     """Every voxel salient: the per-band list overflows one 64-entry chunk many times over."""
     shape = (7, 24, 28)
