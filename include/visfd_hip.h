@@ -59,18 +59,25 @@ void* visfd_hip_get_stream(visfd_hip_ctx* ctx);
 /* release the cached workspace (it otherwise persists between calls) */
 int visfd_hip_trim(visfd_hip_ctx* ctx);
 const char* visfd_hip_last_error(void);
-int visfd_hip_abi_version(void);   /* 5: entry points only get added between versions */
+int visfd_hip_abi_version(void);   /* 6: entry points only get added between versions */
 /* Tuning and test switches of a context (integers; unknown names are VISFD_HIP_EINVAL).  A new context starts from the
  * environment (VISFD_HIP_<NAME>, read once in visfd_hip_create); nothing reads the environment afterwards.
  *   gauss_3pass      1: the separable filter always takes its three single-axis passes
  *   gauss_wg_per_cu  workgroups per CU the single-sweep filter cuts the volume into (default 2)
  *   tv_dense         1: tensor voting by the baseline kernel
+ *   tv_fma           1: TOLERANCE MODE of tensor voting (surfaces, angular exponent 2 or 4): the vote chain with fused
+ *                    multiply-adds.  Tensors are then within 1e-5 of the field's scale of the reference's instead of
+ *                    bit-identical to them (BASELINE north_star: 1e-5 relative for float voxel values); default 0 = exact
+ *   gauss_fma        1: TOLERANCE MODE of the plain separable Gaussian (ApplyGauss / ApplySeparable, symmetric taps,
+ *                    no mask): fused multiply-adds and a reciprocal normaliser, same 1e-5 bar.  DoG / LoG / BlobDog feed
+ *                    index comparisons and ignore it (always the reference's bits); default 0 = exact
  *   tv_zrun          receiver planes per unit of work (default 32)
  *   tv_no_replay     1: every sender plane is listed again for every receiver plane (no reuse within a run)
  *   tv_max_wg        cap on the number of persistent workgroups (tests: forces many units of work per workgroup)
  *   blob_test_cap    tests: capacity the pipelined blob scan pretends to have (exercises its overflow path)
  *   gauss_cfg, debug development aids */
 int visfd_hip_set_option(visfd_hip_ctx* ctx, const char* name, int64_t value);
+int visfd_hip_get_option(visfd_hip_ctx* ctx, const char* name, int64_t* value_out);
 /* bytes of device workspace currently held by the context */
 int64_t visfd_hip_workspace_bytes(visfd_hip_ctx* ctx);
 

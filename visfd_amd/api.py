@@ -48,6 +48,7 @@ _SIGS = {
     "visfd_hip_abi_version": (C.c_int, []),
     "visfd_hip_workspace_bytes": (_i64, [_vp]),
     "visfd_hip_set_option": (C.c_int, [_vp, C.c_char_p, _i64]),
+    "visfd_hip_get_option": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_int64)]),
     "visfd_hip_gauss_taps": (C.c_int, [C.c_float, C.c_int, _fp]),
     "visfd_hip_ratio_from_threshold": (C.c_float, [C.c_float]),
     "visfd_hip_local_fluctuations": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _fp, C.c_float, C.c_float, C.c_int]),
@@ -439,19 +440,26 @@ class Context:
         """Tuning / test switch of this context (include/visfd_hip.h: visfd_hip_set_option)."""
         self._chk(self._L.visfd_hip_set_option(self._h, name.encode(), int(value)))
 
+    def get_option(self, name):
+        v = C.c_int64()
+        self._chk(self._L.visfd_hip_get_option(self._h, name.encode(), C.byref(v)))
+        return int(v.value)
+
     def options(self, **kw):
-        """Context manager: set options for the duration of a with-block, then restore the given defaults (0)."""
+        """Context manager: set options for the duration of a with-block, then restore the values they had before it
+        (whatever their origin: the environment, an earlier set_option, an enclosing scope)."""
         ctx = self
 
         class _Scope:
             def __enter__(self_):
+                self_.saved = {k: ctx.get_option(k) for k in kw}
                 for k, v in kw.items():
                     ctx.set_option(k, v)
                 return ctx
 
             def __exit__(self_, *a):
-                for k in kw:
-                    ctx.set_option(k, 2 if k == "gauss_wg_per_cu" else 0)
+                for k, v in self_.saved.items():
+                    ctx.set_option(k, v)
                 return False
         return _Scope()
 

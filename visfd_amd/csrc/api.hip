@@ -69,7 +69,7 @@ int halfwidths_from_ratio(const float sigma[3], float ratio, int hw[3]) {
 
 int gauss_dev(visfd_hip_ctx* ctx, const float* src, float* dst, const float* mask, i64 nx, i64 ny, i64 nz,
               const float sigma[3], const int hw[3], bool normalize, SlabInfo slab, float* A_out,
-              const float* minuend = nullptr, float log_scale = 1.0f, bool* epilogue_done = nullptr) {
+              const float* minuend = nullptr, float log_scale = 1.0f, bool* epilogue_done = nullptr, bool fma = false) {
   VH_REQUIRE(ctx && src && dst && sigma && hw, "null argument");
   std::vector<float> t[3];
   for (int d = 0; d < 3; d++) {
@@ -79,7 +79,7 @@ int gauss_dev(visfd_hip_ctx* ctx, const float* src, float* dst, const float* mas
     host_gauss_taps(sigma[d], hw[d], t[d].data());
   }
   return dev_separable3d(ctx, src, dst, mask, nx, ny, nz, t[0].data(), hw[0], t[1].data(), hw[1],
-                         t[2].data(), hw[2], normalize, slab, A_out, minuend, log_scale, epilogue_done);
+                         t[2].data(), hw[2], normalize, slab, A_out, minuend, log_scale, epilogue_done, fma);
 }
 
 // ApplyDog with a caller-provided temp volume (filter3d.hpp:1338-1402); with do_scale it is the body of
@@ -256,7 +256,8 @@ struct OptionDesc { const char* name; int visfd_hip_options::*i; int64_t visfd_h
 const OptionDesc kOptions[] = {
     {"gauss_3pass", &visfd_hip_options::gauss_3pass, nullptr},   {"gauss_cfg", &visfd_hip_options::gauss_cfg, nullptr},
     {"gauss_wg_per_cu", &visfd_hip_options::gauss_wg_per_cu, nullptr}, {"tv_dense", &visfd_hip_options::tv_dense, nullptr},
-    {"tv_zrun", &visfd_hip_options::tv_zrun, nullptr},
+    {"tv_zrun", &visfd_hip_options::tv_zrun, nullptr}, {"tv_fma", &visfd_hip_options::tv_fma, nullptr},
+    {"gauss_fma", &visfd_hip_options::gauss_fma, nullptr},
     {"tv_no_replay", &visfd_hip_options::tv_no_replay, nullptr}, {"tv_max_wg", &visfd_hip_options::tv_max_wg, nullptr},
     {"blob_test_cap", nullptr, &visfd_hip_options::blob_test_cap}, {"debug", &visfd_hip_options::debug, nullptr},
 };
@@ -264,6 +265,14 @@ bool set_option(visfd_hip_options* o, const char* name, int64_t value) {
   for (const OptionDesc& d : kOptions) {
     if (std::strcmp(d.name, name) != 0) continue;
     if (d.i) o->*(d.i) = (int)value; else o->*(d.l) = value;
+    return true;
+  }
+  return false;
+}
+bool get_option(const visfd_hip_options* o, const char* name, int64_t* value) {
+  for (const OptionDesc& d : kOptions) {
+    if (std::strcmp(d.name, name) != 0) continue;
+    *value = d.i ? (int64_t)(o->*(d.i)) : o->*(d.l);
     return true;
   }
   return false;
@@ -277,7 +286,7 @@ void options_from_environment(visfd_hip_options* o) {
 }
 }  // namespace
 
-int visfd_hip_abi_version(void) { return 5; }   // 5: + visfd_hip_set_option, CompactMultiChannelImage3D/TVDenseStick normalisation in the shim; 2: + blob post-processing, binning, LabelConnected and its host helpers; 3: + host DiagonalizeFlatSym3 / ConvertFlatSym2Evects3; 4: + LocalFluctuations, two-step ridge (scores / directions)
+int visfd_hip_abi_version(void) { return 6; }   // 6: + visfd_hip_get_option, tolerance modes (tv_fma, gauss_fma); 5: + visfd_hip_set_option, CompactMultiChannelImage3D/TVDenseStick normalisation in the shim; 2: + blob post-processing, binning, LabelConnected and its host helpers; 3: + host DiagonalizeFlatSym3 / ConvertFlatSym2Evects3; 4: + LocalFluctuations, two-step ridge (scores / directions)
 const char* visfd_hip_last_error(void) { return g_last_error.c_str(); }
 
 int visfd_hip_create(int device, void* stream, visfd_hip_ctx** out) {
@@ -312,6 +321,12 @@ int visfd_hip_create(int device, void* stream, visfd_hip_ctx** out) {
 int visfd_hip_set_option(visfd_hip_ctx* ctx, const char* name, int64_t value) {
   VH_REQUIRE(ctx && name, "null argument");
   if (!set_option(&ctx->opt, name, value)) return fail(VISFD_HIP_EINVAL, std::string("unknown option: ") + name);
+  return VISFD_HIP_OK;
+}
+
+int visfd_hip_get_option(visfd_hip_ctx* ctx, const char* name, int64_t* value) {
+  VH_REQUIRE(ctx && name && value, "null argument");
+  if (!get_option(&ctx->opt, name, value)) return fail(VISFD_HIP_EINVAL, std::string("unknown option: ") + name);
   return VISFD_HIP_OK;
 }
 
@@ -374,7 +389,7 @@ int visfd_hip_separable3d_dev(visfd_hip_ctx* ctx, const float* src, float* dst, 
   VH_HIP(hipSetDevice(ctx->device));
   const SlabInfo whole = {0, nz};
   return dev_separable3d(ctx, src, dst, mask, nx, ny, nz, tx, hx, ty, hy, tz, hz, normalize != 0, whole,
-                         A_out);
+                         A_out, nullptr, 1.0f, nullptr, ctx->opt.gauss_fma != 0);
 }
 
 int visfd_hip_separable3d(visfd_hip_ctx* ctx, const float* src, float* dst, const float* mask,
@@ -400,7 +415,8 @@ int visfd_hip_apply_gauss_dev(visfd_hip_ctx* ctx, const float* src, float* dst, 
   VH_REQUIRE(ctx, "null context");
   VH_HIP(hipSetDevice(ctx->device));
   const SlabInfo whole = {0, nz};
-  return gauss_dev(ctx, src, dst, mask, nx, ny, nz, sigma, hw, normalize != 0, whole, A_out);
+  return gauss_dev(ctx, src, dst, mask, nx, ny, nz, sigma, hw, normalize != 0, whole, A_out, nullptr, 1.0f, nullptr,
+                   ctx->opt.gauss_fma != 0);
 }
 
 int visfd_hip_apply_gauss_slab_dev(visfd_hip_ctx* ctx, const float* src, float* dst, int64_t nx,
@@ -410,7 +426,8 @@ int visfd_hip_apply_gauss_slab_dev(visfd_hip_ctx* ctx, const float* src, float* 
   VH_REQUIRE(z_lo >= 0 && z_lo + nz_local <= nz_global, "slab outside the volume");
   VH_HIP(hipSetDevice(ctx->device));
   const SlabInfo slab = {z_lo, nz_global};
-  return gauss_dev(ctx, src, dst, nullptr, nx, ny, nz_local, sigma, hw, normalize != 0, slab, A_out);
+  return gauss_dev(ctx, src, dst, nullptr, nx, ny, nz_local, sigma, hw, normalize != 0, slab, A_out, nullptr, 1.0f, nullptr,
+                   ctx->opt.gauss_fma != 0);
 }
 
 int visfd_hip_apply_gauss(visfd_hip_ctx* ctx, const float* src, float* dst, const float* mask,

@@ -62,6 +62,9 @@ struct visfd_hip_options {
   int gauss_cfg = 0;        // development builds: alternative tilings of the single-sweep filter
   int gauss_wg_per_cu = 2;  // workgroups per CU the single-sweep filter cuts the volume into
   int tv_dense = 0;         // 1: tensor voting by the baseline kernel (csrc/tv.hip)
+  int tv_fma = 0;           // 1: TOLERANCE MODE of tensor voting: fused multiply-adds, results within 1e-5 of the field's scale
+                            //    instead of bit-identical (surfaces, exponent 2 or 4; everything else stays exact)
+  int gauss_fma = 0;        // 1: TOLERANCE MODE of the single-sweep Gaussian (plain ApplyGauss only; DoG/LoG stay exact)
   int tv_zrun = 0;          // receiver planes per unit of work (0: default)
   int tv_no_replay = 0;     // 1: list every sender plane again for every receiver plane (nothing reused from the rings)
   int tv_max_wg = 0;        // cap on the persistent grid (0: fill the chip); tests use it to make workgroups claim many units
@@ -125,7 +128,9 @@ int dev_separable3d(visfd_hip_ctx* ctx, const float* src, float* dst, const floa
                     const float* tz, int hz, bool normalize, SlabInfo slab, float* A_out,
                     // optional DoG/LoG epilogue: dst = (minuend - G(src)) * log_scale, fused into the
                     // single-sweep kernel when it applies (*epilogue_done tells whether it was)
-                    const float* minuend = nullptr, float log_scale = 1.0f, bool* epilogue_done = nullptr);
+                    const float* minuend = nullptr, float log_scale = 1.0f, bool* epilogue_done = nullptr,
+                    // tolerance mode (option gauss_fma) for callers whose output is a float field; never with a minuend
+                    bool fma = false);
 // dst = (a - b) * scale  with two roundings (filter3d.hpp:1387-1390,1495-1498); scale==1: no multiply
 int dev_sub_scale(visfd_hip_ctx* ctx, float* a_inout, const float* b, i64 n, float scale, bool do_scale);
 // LocalFluctuations element-wise steps (filter3d.hpp:1776-1790 and :1819-1846)

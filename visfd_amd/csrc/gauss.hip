@@ -353,7 +353,7 @@ int launch_row(visfd_hip_ctx* ctx, const float* in, float* out, const float* den
   int launch_gauss_fused_h##HH(visfd_hip_ctx* ctx, const float* src, float* dst, i64 nx, i64 ny,   \
                                i64 nz, const Taps& tx, const Taps& ty, const Taps& tz,            \
                                const float* Dx, const float* Dy, const float* Dz, i64 dz_offset,  \
-                               bool normalize, int cfg, const float* minuend, float log_scale);
+                               bool normalize, int cfg, const float* minuend, float log_scale, bool fma);
 VH_DECL_FUSED(1) VH_DECL_FUSED(2) VH_DECL_FUSED(3) VH_DECL_FUSED(4) VH_DECL_FUSED(5)
 VH_DECL_FUSED(6) VH_DECL_FUSED(7) VH_DECL_FUSED(8)
 #undef VH_DECL_FUSED
@@ -372,7 +372,7 @@ VH_DECL_FUSED_YX(6) VH_DECL_FUSED_YX(7) VH_DECL_FUSED_YX(8)
 static int dev_gauss_fused(visfd_hip_ctx* ctx, const float* src, float* dst, i64 nx, i64 ny, i64 nz,
                            const Taps& tx, const Taps& ty, const Taps& tz, const float* Dx,
                            const float* Dy, const float* Dz, i64 dz_offset, bool normalize,
-                           const float* minuend, float log_scale, bool* handled) {
+                           const float* minuend, float log_scale, bool fma, bool* handled) {
   *handled = false;
   const int H = tx.h;
   if (ty.h != H || tz.h != H || H < 1 || H > 8) return VISFD_HIP_OK;
@@ -389,7 +389,7 @@ static int dev_gauss_fused(visfd_hip_ctx* ctx, const float* src, float* dst, i64
   const int cfg = ctx->opt.gauss_cfg;
   *handled = true;
   switch (H) {
-#define VH_CASE(HH) case HH: return launch_gauss_fused_h##HH(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, cfg, minuend, log_scale);
+#define VH_CASE(HH) case HH: return launch_gauss_fused_h##HH(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, cfg, minuend, log_scale, fma);
     VH_CASE(1) VH_CASE(2) VH_CASE(3) VH_CASE(4) VH_CASE(5) VH_CASE(6) VH_CASE(7) VH_CASE(8)
 #undef VH_CASE
   }
@@ -424,7 +424,7 @@ static int dev_gauss_fused_yx(visfd_hip_ctx* ctx, const float* src, float* dst, 
 int dev_separable3d(visfd_hip_ctx* ctx, const float* src, float* dst, const float* mask, i64 nx,
                     i64 ny, i64 nz, const float* tx, int hx, const float* ty, int hy,
                     const float* tz, int hz, bool normalize, SlabInfo slab, float* A_out,
-                    const float* minuend, float log_scale, bool* epilogue_done) {
+                    const float* minuend, float log_scale, bool* epilogue_done, bool fma) {
   if (epilogue_done) *epilogue_done = false;
   VH_TRY(check_dims(nx, ny, nz));
   Taps Tx, Ty, Tz;
@@ -452,7 +452,7 @@ int dev_separable3d(visfd_hip_ctx* ctx, const float* src, float* dst, const floa
   if (!mask) {
     bool handled = false;
     VH_TRY(dev_gauss_fused(ctx, src, dst, nx, ny, nz, Tx, Ty, Tz, Dx, Dy, Dz, slab.z_lo, normalize,
-                           minuend, log_scale, &handled));
+                           minuend, log_scale, fma && !minuend, &handled));
     if (handled) {
       if (epilogue_done) *epilogue_done = (minuend != nullptr);
       return VISFD_HIP_OK;

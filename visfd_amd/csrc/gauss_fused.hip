@@ -144,8 +144,12 @@ __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rs, unsigned by
 // ZPASS == false: the Y and X passes only (the masked filter runs its Z pass, which applies the mask, as a separate
 // kernel); DENOM: the result is a filtered mask denominator and the output is numer / result where result > 0, numer
 // elsewhere (filter3d.hpp:986-996).
+// FMA: the TOLERANCE MODE (context option gauss_fma): every tap is one fused multiply-add and the normaliser a
+// multiplication by the per-lane reciprocal -- about half the vector instructions of the exact form.  Results are within
+// a few ulp of the reference's (tests: 1e-5 of the field's scale) instead of bit-identical, so only callers whose output
+// is a float field get it (ApplyGauss); the Gaussians of DoG/LoG feed index comparisons and never do.
 template <int H, int TX, int TY, int NT, int XV_, int YV_, bool NORMALIZE, bool ISO, bool RAGGED, bool ZPASS = true,
-          bool DENOM = false>
+          bool DENOM = false, bool FMA = false>
 __global__ void __launch_bounds__(NT)
 gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH<H> tz, TapsH<H> ty_,
                    TapsH<H> tx_, const float* __restrict__ Dx, const float* __restrict__ Dy,
@@ -307,6 +311,15 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
 #pragma unroll
     for (int c = 0; c < C::NC; c++) {
       if (c < c_lo || c >= c_hi) continue;
+      if constexpr (FMA) {
+#pragma unroll
+        for (int j = -H; j <= H; j++) {
+          const int s = (u + H - j) % W;
+          if (j == -H) ring[c][s] = tap_z(H) * xin[c];
+          else ring[c][s] = __builtin_fmaf(tap_z(j < 0 ? -j : j), xin[c], ring[c][s]);
+        }
+        continue;
+      }
       float pr[H + 1];
 #pragma unroll
       for (int m = 0; m <= H; m++) pr[m] = tap_z(m) * xin[c];
@@ -324,6 +337,12 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
   // column groups that run right after the reads of the first Y round, the last Y round and the first X round have
   // been requested.
   constexpr int ZF0 = C::NC / 3, ZF1 = (2 * C::NC) / 3;
+  // one term of a Y or X sum: acc + t * v (the reference's two roundings), or fused in the tolerance mode
+  auto madd = [](float acc, float t, float v, bool first) -> float {
+    if (first) return t * v;
+    if constexpr (FMA) return __builtin_fmaf(t, v, acc);
+    else return acc + t * v;
+  };
   // Y and X passes of output plane z from the Z-filtered (or, without a Z pass, the source) tile sZ
   auto yx_passes = [&](int z, const float* sZ, auto&& zfill) {
         // Y pass: two adjacent x per lane; source rows y+2H (j=-H) down to y (j=+H)
@@ -345,12 +364,10 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
 #pragma unroll
               for (int jj = 0; jj < W; jj++) {
                 const float t = tap_y(jj);
-                const float p10 = t * v[jj].x, p11 = t * v[jj].y;
-                const float p00 = t * v[jj + 1].x, p01 = t * v[jj + 1].y;
-                a10 = jj == 0 ? p10 : a10 + p10;
-                a11 = jj == 0 ? p11 : a11 + p11;
-                a00 = jj == 0 ? p00 : a00 + p00;
-                a01 = jj == 0 ? p01 : a01 + p01;
+                a10 = madd(a10, t, v[jj].x, jj == 0);
+                a11 = madd(a11, t, v[jj].y, jj == 0);
+                a00 = madd(a00, t, v[jj + 1].x, jj == 0);
+                a01 = madd(a01, t, v[jj + 1].y, jj == 0);
               }
               *reinterpret_cast<float2*>(reinterpret_cast<char*>(sY) + y_off[r]) = make_float2(a00, a01);
               *reinterpret_cast<float2*>(reinterpret_cast<char*>(sY) + y_off[r] + 4 * C::SX) = make_float2(a10, a11);
@@ -366,10 +383,8 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
 #pragma unroll
               for (int jj = 0; jj < W; jj++) {
                 const float t = tap_y(jj);
-                const float p1 = t * v[jj];
-                const float p0 = t * v[jj + 1];
-                a1 = jj == 0 ? p1 : a1 + p1;
-                a0 = jj == 0 ? p0 : a0 + p0;
+                a1 = madd(a1, t, v[jj], jj == 0);
+                a0 = madd(a0, t, v[jj + 1], jj == 0);
               }
               *reinterpret_cast<float*>(reinterpret_cast<char*>(sY) + y_off[r]) = a0;
               *reinterpret_cast<float*>(reinterpret_cast<char*>(sY) + y_off[r] + 4 * C::SX) = a1;
@@ -384,10 +399,7 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
             for (int jj = 0; jj < W; jj++) v[jj] = lds_read_f1(base + (2 * H - jj) * C::SX);
             zfill(1);
 #pragma unroll
-            for (int jj = 0; jj < W; jj++) {
-              const float p0 = tap_y(jj) * v[jj];
-              a0 = jj == 0 ? p0 : a0 + p0;
-            }
+            for (int jj = 0; jj < W; jj++) a0 = madd(a0, tap_y(jj), v[jj], jj == 0);
             if (y_off[r] >= 0) *reinterpret_cast<float*>(reinterpret_cast<char*>(sY) + y_off[r]) = a0;
           } else if (y_off[r] >= 0) {
             const float* base = reinterpret_cast<const float*>(reinterpret_cast<const char*>(sZ) + y_off[r]);
@@ -399,10 +411,8 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
 #pragma unroll
               for (int jj = 0; jj < W; jj++) {
                 const float t = tap_y(jj);
-                const float p0 = t * v[jj].x;
-                const float p1 = t * v[jj].y;
-                a0 = jj == 0 ? p0 : a0 + p0;
-                a1 = jj == 0 ? p1 : a1 + p1;
+                a0 = madd(a0, t, v[jj].x, jj == 0);
+                a1 = madd(a1, t, v[jj].y, jj == 0);
               }
               *reinterpret_cast<float2*>(reinterpret_cast<char*>(sY) + y_off[r]) = make_float2(a0, a1);
             } else {
@@ -411,10 +421,7 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
 #pragma unroll
               for (int jj = 0; jj < W; jj++) v[jj] = base[(2 * H - jj) * C::SX];   // (ds_read2_b32 pairs cost what two ds_read_b32 do)
 #pragma unroll
-              for (int jj = 0; jj < W; jj++) {
-                const float p0 = tap_y(jj) * v[jj];
-                a0 = jj == 0 ? p0 : a0 + p0;
-              }
+              for (int jj = 0; jj < W; jj++) a0 = madd(a0, tap_y(jj), v[jj], jj == 0);
               *reinterpret_cast<float*>(reinterpret_cast<char*>(sY) + y_off[r]) = a0;
             }
           }
@@ -470,10 +477,7 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
           for (int jj = 0; jj < W; jj++) {
             const float t = tap_x(jj);
 #pragma unroll
-            for (int k = 0; k < C::XV; k++) {
-              const float pr = t * v[2 * H - jj + k];
-              a[k] = jj == 0 ? pr : a[k] + pr;
-            }
+            for (int k = 0; k < C::XV; k++) a[k] = madd(a[k], t, v[2 * H - jj + k], jj == 0);
           }
           // Signed zeros.  The reference starts every sum from +0.0 ("acc = 0; acc += term", filter1d.hpp:96-101); the
           // three passes above start from the first product instead, which saves one add per output and pass.  The two
@@ -481,9 +485,20 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
           // sign contributes the same (zero) products to the next pass, so no non-zero value downstream can change, and a
           // final result can only be -0.0 where the reference has +0.0; adding +0.0 once, here, restores exactly that
           // (x + 0.0 == x for every other x).
+          if (!FMA) {
 #pragma unroll
-          for (int k = 0; k < C::XV; k++) a[k] = a[k] + 0.0f;
-          if (NORMALIZE) {
+            for (int k = 0; k < C::XV; k++) a[k] = a[k] + 0.0f;
+          }
+          if (NORMALIZE && FMA) {
+            // tolerance mode: interior planes multiply by the per-lane reciprocal of (Dx*Dy)*Dz, the others divide
+            if (dz_is_int) {
+#pragma unroll
+              for (int k = 0; k < C::XV; k++) a[k] = a[k] * rcp_int[k];
+            } else {
+#pragma unroll
+              for (int k = 0; k < C::XV; k++) a[k] = a[k] / (dxy[k] * dz);
+            }
+          } else if (NORMALIZE) {
             // dest /= (Dx*Dy)*Dz (filter3d.hpp:1016-1018), one correctly rounded division.  On planes with the
             // interior Dz the divisor is a per-lane constant whose correctly rounded reciprocal y is known, and
             // the quotient follows from two Newton corrections with exact FMA residuals (Markstein): q1 = q0 +
@@ -688,7 +703,7 @@ template <int H, int TX, int TY, int NT, int XV = 4, int YV = 2>
 int launch_cfg(visfd_hip_ctx* ctx, const float* src, float* dst, i64 nx, i64 ny, i64 nz,
                const Taps& tx, const Taps& ty, const Taps& tz, const float* Dx, const float* Dy,
                const float* Dz, i64 dz_offset, bool normalize, const float* minuend, float log_scale,
-               bool zpass = true, const float* numer = nullptr) {
+               bool zpass = true, const float* numer = nullptr, bool fma = false) {
   TapsH<H> a, b, c;
   bool iso = true;
   for (int k = 0; k < 2 * H + 1; k++) {
@@ -715,13 +730,14 @@ int launch_cfg(visfd_hip_ctx* ctx, const float* src, float* dst, i64 nx, i64 ny,
   const i64 nblk = tiles * nchunks;
   if (nblk > 0x7fffffffLL) return fail(VISFD_HIP_EINVAL, "volume too large for one launch");
   dim3 grid((unsigned)nblk), block(NT);
-#define VH_GO(NORM, ISOV, RAG, ZP, DEN)                                                          \
-  gauss_fused_kernel<H, TX, TY, NT, XV, YV, NORM, ISOV, RAG, ZP, DEN><<<grid, block, 0, ctx->stream>>>(  \
+#define VH_GO(NORM, ISOV, RAG, ZP, DEN, ...)                                                     \
+  gauss_fused_kernel<H, TX, TY, NT, XV, YV, NORM, ISOV, RAG, ZP, DEN, ##__VA_ARGS__><<<grid, block, 0, ctx->stream>>>(  \
       src, dst, a, b, c, Dx, Dy, Dz, dz_offset, (int)nx, (int)ny, (int)nz, (int)zchunk, tiles_x, tiles_y,  \
       minuend, log_scale, dz_int, numer)
   // anisotropic taps share the ragged-row instantiation (both are the uncommon cases)
   const bool ragged = (nx % XV) != 0;
   if (!zpass) { if (numer) VH_GO(false, false, true, false, true); else VH_GO(false, false, true, false, false); }
+  else if (normalize && iso && !ragged && fma && !minuend) VH_GO(true, true, false, true, false, true);   // tolerance mode
   else if (normalize) { if (iso && !ragged) VH_GO(true, true, false, true, false); else VH_GO(true, false, true, true, false); }
   else                { if (iso && !ragged) VH_GO(false, true, false, true, false); else VH_GO(false, false, true, true, false); }
 #undef VH_GO
@@ -750,7 +766,7 @@ int VH_CAT(launch_gauss_fused_h, VH_FUSED_H)(visfd_hip_ctx* ctx, const float* sr
                                             i64 ny, i64 nz, const Taps& tx, const Taps& ty,
                                             const Taps& tz, const float* Dx, const float* Dy,
                                             const float* Dz, i64 dz_offset, bool normalize, int cfg,
-                                            const float* minuend, float log_scale) {
+                                            const float* minuend, float log_scale, bool fma) {
   constexpr int H = VH_FUSED_H;
 #ifdef VH_FUSED_EXTRA_CFGS   // development: alternative tilings selectable at run time
   if (cfg == 7) return launch_cfg<H, 64, 32, 1024, 2, 2>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
@@ -766,11 +782,11 @@ int VH_CAT(launch_gauss_fused_h, VH_FUSED_H)(visfd_hip_ctx* ctx, const float* sr
   // (columns per thread x (2H+1)) no longer fits 128 VGPRs; with the 64-wide tile the X pass needs two
   // outputs per lane to fill its wave, and single-column Y tasks pack the rounds better
   if constexpr (H <= 3)
-    return launch_cfg<H, 128, 16, 512, 4, 2>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
+    return launch_cfg<H, 128, 16, 512, 4, 2>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale, true, nullptr, fma);
   else if constexpr (H <= 5)
-    return launch_cfg<H, 128, 32, 1024, 4, 2>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
+    return launch_cfg<H, 128, 32, 1024, 4, 2>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale, true, nullptr, fma);
   else
-    return launch_cfg<H, 64, 32, 1024, 2, 1>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
+    return launch_cfg<H, 64, 32, 1024, 2, 1>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale, true, nullptr, fma);
 }
 
 // The Y and X passes alone (no Z pass, no box normaliser), optionally with the masked-normalisation epilogue

@@ -136,12 +136,17 @@ static int tv_table_device(visfd_hip_ctx* ctx, float sigma_tv, float cutoff, int
   VH_HIP(hipStreamSynchronize(ctx->stream));
   std::vector<float> w(m), rh(3 * m);
   host_tv_tables(sigma_tv, h, w.data(), rh.data());
-  std::vector<float4> tab(m);
-  for (size_t k = 0; k < m; k++) tab[k] = make_float4(w[k], rh[3 * k], rh[3 * k + 1], rh[3 * k + 2]);
+  // two tables: [0, m) the reference's {w, rhat}; [m, 2m) the tolerance mode's {w, sqrt(2) rhat} (tv_tiled.hip: vote_dir_fma)
+  std::vector<float4> tab(2 * m);
+  const float rt2 = 1.41421356237309504880f;
+  for (size_t k = 0; k < m; k++) {
+    tab[k] = make_float4(w[k], rh[3 * k], rh[3 * k + 1], rh[3 * k + 2]);
+    tab[m + k] = make_float4(w[k], rt2 * rh[3 * k], rt2 * rh[3 * k + 1], rt2 * rh[3 * k + 2]);
+  }
   float4* dtab = nullptr;
   ctx->tv_table_dev = nullptr;
-  VH_TRY(ws(ctx, WS_TVTAB, m, &dtab));
-  VH_HIP(hipMemcpyAsync(dtab, tab.data(), sizeof(float4) * m, hipMemcpyHostToDevice, ctx->stream));
+  VH_TRY(ws(ctx, WS_TVTAB, 2 * m, &dtab));
+  VH_HIP(hipMemcpyAsync(dtab, tab.data(), sizeof(float4) * 2 * m, hipMemcpyHostToDevice, ctx->stream));
   VH_HIP(hipStreamSynchronize(ctx->stream));
   ctx->tv_table_dev = reinterpret_cast<float*>(dtab);
   ctx->tv_table_h = h;
