@@ -43,10 +43,14 @@ namespace vh {
 
 namespace {
 
-constexpr int NT = 512;
+#ifndef VH_TV_NT
+#define VH_TV_NT 512
+#endif
+constexpr int NT = VH_TV_NT;
 constexpr int NW = NT / 64;
-constexpr int TX = 8, TY = 32;        // receivers of a workgroup: 8 x 32 on each of TWO consecutive planes; a wave owns four
+constexpr int TX = 8, TY = 4 * NW;    // receivers of a workgroup: 8 x 32 on each of TWO consecutive planes; a wave owns four
                                       // rows of both planes (lanes 0-31: plane z, lanes 32-63: plane z+1)
+static_assert(TY <= 64, "row coordinates relative to the tile centre are packed as signed bytes");
 #ifndef VH_TV_CAP
 #define VH_TV_CAP 256
 #endif
@@ -532,7 +536,7 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
   if (nblk > 0x7fffffffLL) return fail(VISFD_HIP_EINVAL, "volume too large for one launch");
   if (nblk <= 0) { *handled = true; return VISFD_HIP_OK; }
   const size_t lds = 2 * slice_bytes;   // dynamic part: the slices of jz and jz + 1
-  const size_t lds_static = sizeof(float4) * CAP + sizeof(uint2) * (CAP + 8) + sizeof(float) * (mask_src ? CAP : 1) + 1024;
+  const size_t lds_static = sizeof(float4) * CAP + sizeof(uint2) * (CAP + 8) + sizeof(float) * (mask_src ? CAP : 1) + 2048;
   if (lds + lds_static > 150 * 1024) return VISFD_HIP_OK;   // window too wide for the LDS slice: baseline kernel
   const int mode = weights_only ? 3 : (curves ? 1 : (exponent == 4 ? 0 : (exponent == 2 ? 2 : 1)));
   // persistent workgroups (see the kernel): as many as the chip holds at once -- LDS allows 160 KB / (static +
@@ -541,7 +545,7 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
   VH_TRY(ws(ctx, WS_COUNTER, 16, &counter));
   VH_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned), st));
   size_t wg_per_cu = (160 * 1024) / (lds + lds_static);
-  const size_t max_wg = mode == 1 ? 1 : 4;   // eight waves each
+  const size_t max_wg = mode == 1 ? 1 : 2048 / NT;   // eight waves per SIMD in all
   if (wg_per_cu > max_wg) wg_per_cu = max_wg;
   if (wg_per_cu < 1) wg_per_cu = 1;
   i64 ngrid = (i64)ctx->num_cus * (i64)wg_per_cu;
