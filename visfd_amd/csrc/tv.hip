@@ -123,6 +123,11 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
                  const float* mask_src, const float* mask_dst, i64 nx, i64 ny, i64 nz, i64 z_out0,
                  i64 z_out1, int h, const float4* dtab, int exponent, bool curves, bool weights_only, bool* handled);
 
+// declared in tv_pair.hip
+int dev_tv_pair(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* ten, const float* mask_src,
+                const float* mask_dst, i64 nx, i64 ny, i64 nz, i64 z_out0, i64 z_out1, int h, const float4* dtab_fma,
+                int exponent, bool* handled);
+
 // The vote table of (sigma_tv, cutoff) on the device: float4 {w, rhat_x, rhat_y, rhat_z} per offset j in z, y, x order
 // (filter3d.hpp:563-578, feature.hpp:2470-2478).  Built on the host once and kept in the context: a launch with the same
 // parameters queues no copy and never waits for the stream.
@@ -170,6 +175,12 @@ int dev_tv_dense_stick(visfd_hip_ctx* ctx, const float* sal, const float* dir, f
   VH_TRY(tv_table_device(ctx, sigma_tv, cutoff, h, &dtab));
 
   bool handled = false;
+  // tolerance mode (option tv_fma = 1): mirror-paired sender planes (tv_pair.hip); tv_fma = 2 keeps the exact kernel's
+  // structure with fused multiply-adds (development comparisons); windows neither takes fall through to the exact kernels
+  if (!ctx->opt.tv_dense && ctx->opt.tv_fma == 1 && !curves)
+    VH_TRY(dev_tv_pair(ctx, sal, dir, ten, mask_src, mask_dst, nx, ny, nz, z_out0, z_out1, h,
+                       dtab + (size_t)(2 * h + 1) * (2 * h + 1) * (2 * h + 1), exponent, &handled));
+  if (handled) return VISFD_HIP_OK;
   if (!ctx->opt.tv_dense)
     VH_TRY(dev_tv_tiled(ctx, sal, dir, ten, mask_src, mask_dst, nx, ny, nz, z_out0, z_out1, h, dtab, exponent, curves,
                         false, &handled));
