@@ -112,7 +112,7 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
   __shared__ __attribute__((aligned(16))) float4 l_ent[2 * LSTRIDE];
   __shared__ __attribute__((aligned(16))) uint2 l_pos[2 * LSTRIDE];
   __shared__ float l_mv[MASKED_SRC ? 2 * LSTRIDE : 1];
-  __shared__ int wave_tot[2][NW];
+  __shared__ int wave_tot[2][2][NW];
   __shared__ int cull[NW][2 * NW];           // per wave holding entries (0-3: list A, 4-7: list B): entries above / not below each wave's rows
   __shared__ unsigned claimed_tile;
   __shared__ int plane_cnt[84];              // entries per ring slot, [2h+2] (h <= 40)
@@ -165,7 +165,112 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
     const unsigned r16_0 = lds_addr(slices) + (unsigned)(16 * ((ly + 2 * h) * S + lx + 2 * h));   // table entry of j = 0.. in slot 0
     const unsigned ent_base = lds_addr(l_ent);
 
-    // ---- LISTING (as tv_tiled.hip, 20-byte entries): sender plane sz of this tile's region into its ring slot -----------
+    // position word of a list entry = the sender's operand of the distance test: signed bytes (e'x, e'y, -q, m) with
+    // e'x^2 + e'y^2 = 128 q + m.  It does not depend on the receiver planes: e'z^2 is added to the receivers' accumulator
+    // operand instead, so the word is built once, when the sender is listed.
+    auto pos_word = [&](int epx, int epy) -> unsigned {
+      const int e2 = epx * epx + epy * epy;
+      return (unsigned)(epx & 0xff) | ((unsigned)(epy & 0xff) << 8) | ((unsigned)((-(e2 >> 7)) & 0xff) << 16) | ((unsigned)(e2 & 127) << 24);
+    };
+
+    // ---- LISTING, two planes at a time (window regions of <= 4 chunks per wave: h <= 12).  Every load of a phase is in
+    // flight at once -- the saliencies of both planes (kept in registers across the barrier: one read per voxel), then the
+    // normals of a plane's salient voxels -- and both planes share one barrier: the listing of the two sender planes that
+    // enter the window with every pair of receiver planes costs two memory round trips instead of sixteen.
+    // A plane index < 0 means "no plane" (zero-length descriptors: nothing is salient).
+    auto list_two = [&](int sz0, int sz1) {
+      constexpr int NCH = 4;
+      const int q0 = wave * p.nchunk * 64 + lane;
+      unsigned off[NCH];
+#pragma unroll
+      for (int j = 0; j < NCH; j++) {
+        const int q = q0 + 64 * j;
+        const int ey = (int)(((unsigned)q * (unsigned)p.rw_magic) >> 20);
+        const int ex = q - ey * p.rw;
+        const int sx = x0 - h + ex, sy = y0 - h + ey;
+        const bool ok = j < p.nchunk && q < R && sx >= 0 && sx < p.nx && sy >= 0 && sy < p.ny;
+        off[j] = ok ? (unsigned)(sy * p.nx + sx) * 4u : OOB;
+      }
+      float sv[2][NCH];
+      int cnt[2] = {0, 0};
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const int sz = k ? sz1 : sz0;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(sal + (i64)(sz < 0 ? 0 : sz) * plane), 0,
+                                                                            sz < 0 ? 0 : plane_bytes, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NCH; j++) sv[k][j] = buf_load(rs, off[j]);
+        if (MASKED_SRC) {
+          const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)(mask_src + (i64)(sz < 0 ? 0 : sz) * plane), 0,
+                                                                              sz < 0 ? 0 : plane_bytes, 0x00020000);
+#pragma unroll
+          for (int j = 0; j < NCH; j++)
+            if (buf_load(rm, off[j]) == 0.0f) sv[k][j] = 0.0f;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int j = 0; j < NCH; j++) cnt[k] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(sv[k][j] != 0.0f));
+      const int par = (npar++) & 1;
+      if (lane == 0) { wave_tot[par][0][wave] = cnt[0]; wave_tot[par][1][wave] = cnt[1]; }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const int sz = k ? sz1 : sz0;
+        if (sz < 0) continue;   // uniform
+        int running = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+          const int t = wave_tot[par][k][w];
+          running += (w > wave) ? t : 0;
+          total += t;
+        }
+        running = __builtin_amdgcn_readfirstlane(running);
+        const int slot = sz % P;
+        unsigned char* const ring_plane = ring + (size_t)slot * plane_stride;
+        if (tid == 0) plane_cnt[slot] = total;
+        if (cnt[k] == 0) continue;   // uniform
+        const __amdgpu_buffer_rsrc_t rd0 =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(dir + (i64)sz * plane), 0, plane_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rd1 =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(dir + nvox + (i64)sz * plane), 0, plane_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rd2 =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(dir + 2 * nvox + (i64)sz * plane), 0, plane_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((MASKED_SRC ? mask_src : sal) + (i64)sz * plane), 0, plane_bytes, 0x00020000);
+        float n0[NCH], n1[NCH], n2[NCH], mvv[NCH];
+#pragma unroll
+        for (int j = 0; j < NCH; j++) {   // the normals of the salient voxels only, all chunks requested before the first use
+          n0[j] = n1[j] = n2[j] = mvv[j] = 0.0f;
+          if (sv[k][j] != 0.0f) {
+            n0[j] = buf_load(rd0, off[j]);
+            n1[j] = buf_load(rd1, off[j]);
+            n2[j] = buf_load(rd2, off[j]);
+            if (MASKED_SRC) mvv[j] = buf_load(rm, off[j]);
+          }
+        }
+#pragma unroll
+        for (int j = NCH - 1; j >= 0; j--) {   // descending region position = row order, which the culling needs
+          const bool f = sv[k][j] != 0.0f;
+          const unsigned long long bal = __builtin_amdgcn_ballot_w64(f);
+          const int tb = __builtin_popcountll(bal);
+          const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+          if (f) {
+            const int idx = running + (tb - below - 1);
+            const int q = q0 + 64 * j;
+            const int ey = (int)(((unsigned)q * (unsigned)p.rw_magic) >> 20);
+            const int ex = q - ey * p.rw;
+            reinterpret_cast<float4*>(ring_plane)[idx] = make_float4(sv[k][j] * (MODE == 0 ? 0.25f : 0.5f), n0[j], n1[j], n2[j]);
+            reinterpret_cast<unsigned*>(ring_plane + (size_t)R * 16)[idx] = pos_word(ex - h - TX / 2, ey - h - TY / 2);
+            if (MASKED_SRC) reinterpret_cast<float*>(ring_plane + (size_t)R * 20)[idx] = mvv[j];
+          }
+          running += tb;
+        }
+      }
+    };
+
+    // ---- LISTING, one plane, any window (as tv_tiled.hip): sender plane sz of this tile's region into its ring slot ------
     auto list_plane = [&](int sz) {
       const __amdgpu_buffer_rsrc_t rs =
           __builtin_amdgcn_make_buffer_rsrc((void*)(sal + (i64)sz * plane), 0, plane_bytes, 0x00020000);
@@ -194,12 +299,12 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
         cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(s != 0.0f));
       }
       const int par = (npar++) & 1;
-      if (lane == 0) wave_tot[par][wave] = cnt;
+      if (lane == 0) wave_tot[par][0][wave] = cnt;
       __syncthreads();
       int running = 0, total = 0;
 #pragma unroll
       for (int w = 0; w < NW; w++) {
-        const int t = wave_tot[par][w];
+        const int t = wave_tot[par][0][w];
         running += (w > wave) ? t : 0;
         total += t;
       }
@@ -228,8 +333,7 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
             const float4 a = make_float4(s * (MODE == 0 ? 0.25f : 0.5f), buf_load(rd0, off), buf_load(rd1, off), buf_load(rd2, off));
             const int epx = ex - h - TX / 2, epy = ey - h - TY / 2;
             reinterpret_cast<float4*>(ring_plane)[idx] = a;
-            reinterpret_cast<unsigned*>(ring_plane + (size_t)R * 16)[idx] =
-                (unsigned)(epx & 0xff) | ((unsigned)(epy & 0xff) << 8) | ((unsigned)(epx * epx + epy * epy) << 16);
+            reinterpret_cast<unsigned*>(ring_plane + (size_t)R * 16)[idx] = pos_word(epx, epy);
             if (MASKED_SRC) reinterpret_cast<float*>(ring_plane + (size_t)R * 20)[idx] = buf_load(rm, off);
           }
           running += tb;
@@ -289,8 +393,25 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
       // sender planes that reach the live receivers of this pair (an odd run ends with half a pair: nothing above
       // rz + h is needed -- or, in a slab run, complete -- then)
       const int sz_hi = min(min(rz + 1, z_run1 - 1) + h, p.nz - 1), sz_lo = max(rz - h, 0);
-      for (int sz = sz_hi; sz >= sz_lo; sz--)   // uniform
-        if (p.relist || sz < cached_lo || sz > cached_hi) list_plane(sz);
+#ifndef VH_PAIR_LIST2
+#define VH_PAIR_LIST2 1
+#endif
+#ifndef VH_PAIR_FILL_FIRST
+#define VH_PAIR_FILL_FIRST 0
+#endif
+      if (VH_PAIR_LIST2 && p.nchunk <= 4) {
+        int pend = -1;
+        for (int sz = sz_hi; sz >= sz_lo; sz--) {   // uniform
+          if (!(p.relist || sz < cached_lo || sz > cached_hi)) continue;
+          if (pend < 0) { pend = sz; continue; }
+          list_two(pend, sz);
+          pend = -1;
+        }
+        if (pend >= 0) list_two(pend, -1);
+      } else {
+        for (int sz = sz_hi; sz >= sz_lo; sz--)   // uniform
+          if (p.relist || sz < cached_lo || sz > cached_hi) list_plane(sz);
+      }
       cached_lo = sz_lo;
       cached_hi = sz_hi;
 
@@ -314,14 +435,12 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
         if (cntA + cntB == 0) continue;   // uniform
         // slices S_(d-1) and S_d (S_(h+1) does not exist: its lanes never hit); list and slices are free: every sweep ends
         // with a barrier
+        int need[2];
 #pragma unroll
         for (int k = 0; k < 2; k++) {
           const int j = d - 1 + k;
-          if (j <= h && slot_has[j & 1] != j) {
-            const float4* src4 = table + (i64)(j + h) * nsl;
-            for (int i = tid; i < nsl; i += NT) sl4[(j & 1) * nsl + i] = src4[i];
-            slot_has[j & 1] = j;
-          }
+          need[k] = (j <= h && slot_has[j & 1] != j) ? j : -1;
+          if (need[k] >= 0) slot_has[j & 1] = j;
         }
         // rows a wave can reach: the nearer of its two receiver planes is |jz| = d-1 away from either sender plane
         const int jn = (d - 1) * (d - 1);
@@ -331,25 +450,47 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
         const bool isB = wave >= NW / 2;                       // (uniform) this thread brings entries of list B
         const int my_sz = isB ? szB : szA;
         const int my_cnt = isB ? cntB : cntA;
-        const int epz = my_sz - rz;                            // sender plane relative to the LOWER receiver plane
-        const int epz2 = epz * epz;
         const unsigned char* ring_plane = ring + (size_t)(((my_sz % P) + P) % P) * plane_stride;
         const int ltid = tid & (CAPH - 1);
         const int lbase = isB ? LSTRIDE : 0;
         for (int done = 0; done < cntA || done < cntB; done += CAPH) {   // uniform
           const int take = min(CAPH, max(my_cnt - done, 0));
           int epy = -128;                                      // threads without an entry: below every range
+          // requests first -- this thread's ring entry, then its share of the missing slice (one per step as a rule) -- so
+          // that the fill of a step is ONE memory round trip
+          float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          unsigned m = 0u;
+          float mvv = 0.0f;
           if (ltid < take) {
             const int idx = done + ltid;
-            const float4 a = reinterpret_cast<const float4*>(ring_plane)[idx];
-            const unsigned m = reinterpret_cast<const unsigned*>(ring_plane + (size_t)R * 16)[idx];
+            a = reinterpret_cast<const float4*>(ring_plane)[idx];
+            m = reinterpret_cast<const unsigned*>(ring_plane + (size_t)R * 16)[idx];
+            if (MASKED_SRC) mvv = reinterpret_cast<const float*>(ring_plane + (size_t)R * 20)[idx];
+          }
+          if (done == 0) {
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+              if (need[k] < 0) continue;   // uniform
+              const int j = need[k];
+              const float4* src4 = table + (i64)(j + h) * nsl;
+              float4* dst4 = sl4 + (j & 1) * nsl;
+              if (VH_PAIR_FILL_FIRST && nsl <= 2 * NT) {
+                const float4 v0 = tid < nsl ? src4[tid] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                const float4 v1 = tid + NT < nsl ? src4[tid + NT] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (tid < nsl) dst4[tid] = v0;
+                if (tid + NT < nsl) dst4[tid + NT] = v1;
+              } else {
+                for (int i = tid; i < nsl; i += NT) dst4[i] = src4[i];
+              }
+            }
+          }
+          if (ltid < take) {
             l_ent[lbase + ltid] = a;
             const int epx = (int)(signed char)(m & 0xff);
             epy = (int)(signed char)((m >> 8) & 0xff);
-            const int e2 = (int)(m >> 16) + epz2;
             const unsigned e16 = (unsigned)(16 * ((epy + h + TY / 2) * S + (epx + h + TX / 2)));
-            l_pos[lbase + ltid] = make_uint2((m & 0xffffu) | ((unsigned)((-(e2 >> 7)) & 0xff) << 16) | ((unsigned)(e2 & 127) << 24), e16);
-            if (MASKED_SRC) l_mv[lbase + ltid] = reinterpret_cast<const float*>(ring_plane + (size_t)R * 20)[idx];
+            l_pos[lbase + ltid] = make_uint2(m, e16);
+            if (MASKED_SRC) l_mv[lbase + ltid] = mvv;
           }
           if (ltid < 8) l_pos[lbase + take + ltid] = make_uint2(NEVER_HIT, 0u);
           // entries are in descending row order: wave w needs those from the first one at or below row 4w-13+rho to the
@@ -377,14 +518,14 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
             const int jl = d, ju = d - 1;
             const bool ok = r_live && (half ? ju <= h : jl <= h);
             const unsigned r16 = r16_0 + (unsigned)(16 * nsl) * (unsigned)((half ? ju : jl) & 1);
-            sweep(std::true_type{}, 0, iA0, iA1, r16, ok ? recv_c + (half ? 1 - 2 * d : 0) : 0x100000);
+            sweep(std::true_type{}, 0, iA0, iA1, r16, ok ? recv_c + d * d + (half ? 1 - 2 * d : 0) : 0x100000);
           }
           // plane B (below): jz = d-1 for the lower plane (S_(d-1)), d for the upper one (S_d)
           if (iB1 > iB0) {
             const int jl = d - 1, ju = d;
             const bool ok = r_live && (half ? ju <= h : jl <= h);
             const unsigned r16 = r16_0 + (unsigned)(16 * nsl) * (unsigned)((half ? ju : jl) & 1);
-            sweep(std::false_type{}, LSTRIDE, iB0, iB1, r16, ok ? recv_c + (half ? 1 - 2 * (1 - d) : 0) : 0x100000);
+            sweep(std::false_type{}, LSTRIDE, iB0, iB1, r16, ok ? recv_c + (1 - d) * (1 - d) + (half ? 1 - 2 * (1 - d) : 0) : 0x100000);
           }
           VH_STAMP(3);
           __syncthreads();   // everyone done reading before the lists or the slices are refilled
