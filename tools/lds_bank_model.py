@@ -1,0 +1,34 @@
+"""LDS bank model of the vote-table reads of the tensor-voting kernels (development aid; MI355X_MICROARCH.md, LDS table):
+ds_read_b128 serves a wave in four groups of 16 lanes, banks = (byte address / 4) mod 64, a group takes as many LDS cycles
+as its busiest bank has distinct addresses.  Prints the cycles per half wave (32 receivers of one plane) for table rows of
+`stride` float4 entries, lanes dealt to the 8 x 4 patch in row order ("row") or as two 4-column blocks ("block",
+csrc/tv_pair.hip)."""
+groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+
+
+def cycles(addr_of_lane):
+    tot = 0
+    for g in groups:
+        banks = {}
+        for l in g:
+            a = addr_of_lane(l)
+            for k in range(4):
+                banks.setdefault(((a // 4) + k) % 64, set()).add(a + 4 * k)
+        tot += max(len(v) for v in banks.values())
+    return tot
+
+
+def row_map(l):
+    return l >> 3, l & 7
+
+
+def block_map(l):
+    row = 0 if l < 8 else 1 if l < 16 else 2 if l < 24 else 3
+    return row, (l & 3) + (4 if (0xc33c >> (l >> 1)) & 1 else 0)
+
+
+assert sorted(block_map(l) for l in range(32)) == [(r, x) for r in range(4) for x in range(8)]
+for stride in (25, 26, 27, 28, 29, 31, 33, 36, 40):
+    for name, f in (("row", row_map), ("block", block_map)):
+        cs = [cycles(lambda l: base + 16 * (f(l)[0] * stride + f(l)[1])) for base in range(0, 4096, 16)]
+        print("stride %2d  %-5s  cycles per half-wave read: min %d  max %d" % (stride, name, min(cs), max(cs)))

@@ -110,6 +110,13 @@ struct Taps {
   int h;
 };
 
+// row stride (in float4 entries) of the tolerance-mode vote table: 2h+1 rounded up to 4 modulo 8 (tv_pair.hip: LDS banks)
+inline int tv_padded_row(int h) {
+  int sp = 2 * h + 1;
+  while ((sp & 7) != 4) sp++;
+  return sp;
+}
+
 // host-side arithmetic (taps.cpp)
 void host_gauss_taps(float sigma, int h, float* t);
 void host_conv_ones(i64 n, const float* t, int h, float* out);  // filter applied to a line of ones

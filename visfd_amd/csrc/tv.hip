@@ -141,17 +141,19 @@ static int tv_table_device(visfd_hip_ctx* ctx, float sigma_tv, float cutoff, int
   VH_HIP(hipStreamSynchronize(ctx->stream));
   std::vector<float> w(m), rh(3 * m);
   host_tv_tables(sigma_tv, h, w.data(), rh.data());
-  // two tables: [0, m) the reference's {w, rhat}; [m, 2m) the tolerance mode's {w, sqrt(2) rhat} (tv_tiled.hip: vote_dir_fma)
-  std::vector<float4> tab(2 * m);
+  // two tables: [0, m) the reference's {w, rhat}; behind it the tolerance mode's {w, sqrt(2) rhat} (tv_pair.hip: vote_fma)
+  // with rows padded to tv_padded_row(h) entries (the pad entries are never read)
+  const size_t sp = (size_t)tv_padded_row(h), m2 = n * n * sp;
+  std::vector<float4> tab(m + m2, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
   const float rt2 = 1.41421356237309504880f;
   for (size_t k = 0; k < m; k++) {
     tab[k] = make_float4(w[k], rh[3 * k], rh[3 * k + 1], rh[3 * k + 2]);
-    tab[m + k] = make_float4(w[k], rt2 * rh[3 * k], rt2 * rh[3 * k + 1], rt2 * rh[3 * k + 2]);
+    tab[m + (k / n) * sp + (k % n)] = make_float4(w[k], rt2 * rh[3 * k], rt2 * rh[3 * k + 1], rt2 * rh[3 * k + 2]);
   }
   float4* dtab = nullptr;
   ctx->tv_table_dev = nullptr;
-  VH_TRY(ws(ctx, WS_TVTAB, 2 * m, &dtab));
-  VH_HIP(hipMemcpyAsync(dtab, tab.data(), sizeof(float4) * 2 * m, hipMemcpyHostToDevice, ctx->stream));
+  VH_TRY(ws(ctx, WS_TVTAB, m + m2, &dtab));
+  VH_HIP(hipMemcpyAsync(dtab, tab.data(), sizeof(float4) * (m + m2), hipMemcpyHostToDevice, ctx->stream));
   VH_HIP(hipStreamSynchronize(ctx->stream));
   ctx->tv_table_dev = reinterpret_cast<float*>(dtab);
   ctx->tv_table_h = h;
@@ -175,9 +177,9 @@ int dev_tv_dense_stick(visfd_hip_ctx* ctx, const float* sal, const float* dir, f
   VH_TRY(tv_table_device(ctx, sigma_tv, cutoff, h, &dtab));
 
   bool handled = false;
-  // tolerance mode (option tv_fma = 1): mirror-paired sender planes (tv_pair.hip); tv_fma = 2 keeps the exact kernel's
-  // structure with fused multiply-adds (development comparisons); windows neither takes fall through to the exact kernels
-  if (!ctx->opt.tv_dense && ctx->opt.tv_fma == 1 && !curves)
+  // tolerance mode (option tv_fma): fused multiply-adds and mirror-paired sender planes (tv_pair.hip); windows and vote
+  // forms it does not take fall through to the exact kernels
+  if (!ctx->opt.tv_dense && ctx->opt.tv_fma && !curves)
     VH_TRY(dev_tv_pair(ctx, sal, dir, ten, mask_src, mask_dst, nx, ny, nz, z_out0, z_out1, h,
                        dtab + (size_t)(2 * h + 1) * (2 * h + 1) * (2 * h + 1), exponent, &handled));
   if (handled) return VISFD_HIP_OK;

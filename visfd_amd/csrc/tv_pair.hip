@@ -32,10 +32,14 @@ namespace vh {
 
 namespace {
 
-constexpr int NT = 512;
+#ifndef VH_PAIR_NT
+#define VH_PAIR_NT 512
+#endif
+constexpr int NT = VH_PAIR_NT;
 constexpr int NW = NT / 64;
-constexpr int TX = 8, TY = 32;
-constexpr int CAPH = 256;              // list entries per sender plane held in LDS per sweep: one per thread of a half workgroup
+constexpr int TX = 8, TY = 4 * NW;
+constexpr int CAPH = NT / 2;           // list entries per sender plane held in LDS per sweep: one per thread of a half workgroup
+constexpr int NCH_MAX = NT >= 512 ? 4 : 5;   // chunks of the region per wave the two-plane lister handles
 constexpr int LSTRIDE = CAPH + 8;      // entries of list B start here (8 never-hit entries of slack behind each list)
 constexpr unsigned OOB = 0x7ffffff0u;  // byte offset beyond any plane descriptor: reads give 0
 
@@ -70,6 +74,7 @@ struct PairParams {
   int tiles_x, tiles_y;
   int zrun;              // receiver planes per unit of work
   int relist;            // 1: list every sender plane again for every receiver pair (option tv_no_replay; tests)
+  int sp;                // row stride of a table slice in float4 entries (>= 2h+1)
 };
 
 __device__ __forceinline__ void fmacc(float& t, float a, float b) {
@@ -122,7 +127,13 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
   const int lane = tid & 63, wave = tid >> 6;
   const int h = p.h;
   const int S = 2 * h + 1;
-  const int nsl = S * S;
+  // LDS rows of a table slice are SP float4 apart, SP = S rounded up to 4 mod 8, and the lanes of a half wave are dealt to
+  // its 8 x 4 receivers so that each of ds_read_b128's two 16-lane groups ({0-3, 12-15, 20-27} and the rest) is one
+  // 4-column block of all four rows: with row offsets of 64 or 192 bytes modulo the 256 bytes of the 64 banks the four
+  // 64-byte segments of a group fall on different banks -- 2 LDS cycles per half wave, where rows of 2h+1 entries with lanes
+  // in row order take 4 (tools/lds_bank_model.py).  The table in global memory has the same padded rows (tv.hip).
+  const int SP = p.sp;
+  const int nsl = S * SP;
   const int R = p.rw * p.rh;
   const i64 plane = (i64)p.nx * p.ny;
   const i64 nvox = plane * p.nz;
@@ -154,7 +165,12 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
     const int x0 = tile_x * TX, y0 = tile_y * TY;
 
     const int half = lane >> 5;                       // 0: receiver plane rz, 1: plane rz + 1
-    const int lx = lane & 7, ly = wave * 4 + ((lane & 31) >> 3);
+    // lane -> receiver inside the wave's 8 x 4 patch (see SP above): lanes 0-3, 12-15, 20-23, 24-27 are columns 0-3 of rows
+    // 0, 1, 2, 3; lanes 4-7, 8-11, 16-19, 28-31 columns 4-7 of rows 0, 1, 2, 3
+    const int l5 = lane & 31;
+    const int lrow = (l5 < 8) ? 0 : (l5 < 16) ? 1 : (l5 < 24) ? 2 : 3;
+    const int lcol = (l5 & 3) + (((0xc33cu >> (l5 >> 1)) & 1u) ? 4 : 0);   // lane pairs 2-5, 8-9, 14-15 (lanes 4-11, 16-19, 28-31): the right block
+    const int lx = lcol, ly = wave * 4 + lrow;
     const int rx = x0 + lx, ry = y0 + ly;
     const bool r_in = rx < p.nx && ry < p.ny;
     // distance test as one dot product (tv_tiled.hip):  |r'-e'|^2 - h^2 - 1 = (-2r'x, -2r'y, -128, 1).(e'x, e'y, -q, m) + (|r'|^2 - h^2 - 1)
@@ -162,7 +178,7 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
     const unsigned recv4 = (unsigned)((-2 * rpx) & 0xff) | ((unsigned)((-2 * rpy) & 0xff) << 8) | (0x80u << 16) | (1u << 24);
     const int recv_c = rpx * rpx + rpy * rpy - h * h - 1;
     constexpr unsigned NEVER_HIT = 0x009c0000u;
-    const unsigned r16_0 = lds_addr(slices) + (unsigned)(16 * ((ly + 2 * h) * S + lx + 2 * h));   // table entry of j = 0.. in slot 0
+    const unsigned r16_0 = lds_addr(slices) + (unsigned)(16 * ((ly + 2 * h) * SP + lx + 2 * h));   // table entry of j = 0.. in slot 0
     const unsigned ent_base = lds_addr(l_ent);
 
     // position word of a list entry = the sender's operand of the distance test: signed bytes (e'x, e'y, -q, m) with
@@ -179,7 +195,7 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
     // enter the window with every pair of receiver planes costs two memory round trips instead of sixteen.
     // A plane index < 0 means "no plane" (zero-length descriptors: nothing is salient).
     auto list_two = [&](int sz0, int sz1) {
-      constexpr int NCH = 4;
+      constexpr int NCH = NCH_MAX;
       const int q0 = wave * p.nchunk * 64 + lane;
       unsigned off[NCH];
 #pragma unroll
@@ -363,10 +379,34 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
             "v_dot4_i32_i8 %3, %4, %9, %5"
             : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
             : "v"(recv4), "v"(rcl), "v"(ca.x), "v"(ca.z), "v"(cb.x), "v"(cb.z));
+#ifndef VH_PAIR_PREFETCH
+#define VH_PAIR_PREFETCH 0
+#endif
+#if VH_PAIR_PREFETCH
+        // the LDS reads of a vote are requested one vote ahead, for ALL lanes (a lane the sender does not reach reads some
+        // word of LDS -- or zero beyond the allocation -- and never uses it): the round trip of a vote's two reads hides
+        // under the arithmetic of the vote before it
+        auto rd_t = [&](unsigned e16) -> f4v { return *lds_ptr<f4v>(r16 - e16); };
+        auto rd_e = [&](int k) -> f4v { return *lds_ptr<f4v>(ent + 16u * (unsigned)k); };
+        auto vote_v = [&](const f4v& tw, const f4v& d, int s) {
+          float fv = tw.x;
+          if (MASKED_SRC) fv = fv * l_mv[s];
+          vote_fma<MODE, ZNEG>(T, d.x, fv, tw.y, tw.z, tw.w, d.y, d.z, d.w);
+        };
+        f4v t0 = rd_t(ca.y), e0 = rd_e(0);
+        f4v t1 = rd_t(ca.w), e1 = rd_e(1);
+        if (__builtin_expect(d0 < 0, 1)) vote_v(t0, e0, s0);
+        t0 = rd_t(cb.y); e0 = rd_e(2);
+        if (__builtin_expect(d1 < 0, 1)) vote_v(t1, e1, s0 + 1);
+        t1 = rd_t(cb.w); e1 = rd_e(3);
+        if (__builtin_expect(d2 < 0, 1)) vote_v(t0, e0, s0 + 2);
+        if (__builtin_expect(d3 < 0, 1)) vote_v(t1, e1, s0 + 3);
+#else
         if (__builtin_expect(d0 < 0, 1)) vote_one(ent, 0, s0, ca.y);
         if (__builtin_expect(d1 < 0, 1)) vote_one(ent, 1, s0 + 1, ca.w);
         if (__builtin_expect(d2 < 0, 1)) vote_one(ent, 2, s0 + 2, cb.y);
         if (__builtin_expect(d3 < 0, 1)) vote_one(ent, 3, s0 + 3, cb.w);
+#endif
       };
       int s0 = base + (i0 & ~1);
       const int send = base + i1;
@@ -399,7 +439,7 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
 #ifndef VH_PAIR_FILL_FIRST
 #define VH_PAIR_FILL_FIRST 0
 #endif
-      if (VH_PAIR_LIST2 && p.nchunk <= 4) {
+      if (VH_PAIR_LIST2 && p.nchunk <= NCH_MAX) {
         int pend = -1;
         for (int sz = sz_hi; sz >= sz_lo; sz--) {   // uniform
           if (!(p.relist || sz < cached_lo || sz > cached_hi)) continue;
@@ -488,7 +528,7 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
             l_ent[lbase + ltid] = a;
             const int epx = (int)(signed char)(m & 0xff);
             epy = (int)(signed char)((m >> 8) & 0xff);
-            const unsigned e16 = (unsigned)(16 * ((epy + h + TY / 2) * S + (epx + h + TX / 2)));
+            const unsigned e16 = (unsigned)(16 * ((epy + h + TY / 2) * SP + (epx + h + TX / 2)));
             l_pos[lbase + ltid] = make_uint2(m, e16);
             if (MASKED_SRC) l_mv[lbase + ltid] = mvv;
           }
@@ -574,10 +614,11 @@ int dev_tv_pair(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* t
     if ((int)(((unsigned)q * (unsigned)p.rw_magic) >> 20) != q / p.rw) return fail(VISFD_HIP_EINVAL, "tv_pair: region index division");
   // e'x^2 + e'y^2 travels in 16 bits of the position word
   if ((h + TX / 2) * (h + TX / 2) + (h + TY / 2) * (h + TY / 2) >= (1 << 16)) return VISFD_HIP_OK;
-  const size_t slice_bytes = sizeof(float4) * (size_t)n * n;
+  const size_t slice_bytes = sizeof(float4) * (size_t)n * tv_padded_row(h);
   p.tiles_x = (int)((nx + TX - 1) / TX);
   p.tiles_y = (int)((ny + TY - 1) / TY);
   p.relist = ctx->opt.tv_no_replay ? 1 : 0;
+  p.sp = tv_padded_row(h);
   p.zrun = 32;
   if (ctx->opt.tv_zrun >= 1 && ctx->opt.tv_zrun <= 4096) p.zrun = ctx->opt.tv_zrun;
   if ((i64)p.zrun > z_out1 - z_out0) p.zrun = (int)(z_out1 - z_out0);
@@ -593,7 +634,7 @@ int dev_tv_pair(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* t
   VH_TRY(ws(ctx, WS_COUNTER, 16, &counter));
   VH_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned), st));
   size_t wg_per_cu = (160 * 1024) / (lds + lds_static);
-  if (wg_per_cu > 4) wg_per_cu = 4;
+  if (wg_per_cu > 2048 / NT) wg_per_cu = 2048 / NT;
   if (wg_per_cu < 1) wg_per_cu = 1;
   i64 ngrid = (i64)ctx->num_cus * (i64)wg_per_cu;
   if (ctx->opt.tv_max_wg > 0 && ngrid > ctx->opt.tv_max_wg) ngrid = ctx->opt.tv_max_wg;

@@ -117,37 +117,6 @@ __device__ __forceinline__ void vote_dir(float sal, float fv, float r0, float r1
   bse = (sal * fv) * dec;
 }
 
-// TOLERANCE MODE (context option tv_fma; surfaces with exponent 2 or 4): the same vote with fused multiply-adds -- 19
-// instructions instead of 32 -- for callers that want the north-star's 1e-5 float tolerance rather than the reference's
-// bits.  The table of this mode holds R = sqrt(2) * rhat, so that  t = R.n = sqrt(2) u,  t R - n = 2 u rhat - n = m  and
-// 2 - t^2 = 2 (1 - u^2)  need no doubling; the factor 1/2 (exponent 2) or 1/4 (exponent 4) that the decay then lacks is
-// an exact power of two and is applied to the sender's saliency once, when the sender is listed.
-template <int MODE>
-__device__ __forceinline__ void vote_dir_fma(float sal, float fv, float R0, float R1, float R2, float n0, float n1,
-                                             float n2, float& bse, float& m0, float& m1, float& m2) {
-  const float t = __builtin_fmaf(R2, n2, __builtin_fmaf(R1, n1, R0 * n0));
-  const float q = __builtin_fmaf(-t, t, 2.0f);
-  m0 = __builtin_fmaf(t, R0, -n0);
-  m1 = __builtin_fmaf(t, R1, -n1);
-  m2 = __builtin_fmaf(t, R2, -n2);
-  const float sw = sal * fv;
-  bse = (MODE == 0) ? (sw * q) * q : sw * q;
-}
-
-__device__ __forceinline__ void fmacc(float& t, float a, float b) {
-  asm("v_fmac_f32 %0, %1, %2" : "+v"(t) : "v"(a), "v"(b));
-}
-
-__device__ __forceinline__ void vote_acc_fma(float T[6], float bse, float m0, float m1, float m2) {
-  const float b0 = bse * m0, b1 = bse * m1, b2 = bse * m2;
-  fmacc(T[0], b0, m0);
-  fmacc(T[3], b0, m1);
-  fmacc(T[5], b0, m2);
-  fmacc(T[1], b1, m1);
-  fmacc(T[4], b1, m2);
-  fmacc(T[2], b2, m2);
-}
-
 __device__ __forceinline__ void vote_acc(float T[6], float bse, float m0, float m1, float m2) {
   const float b0 = bse * m0, b1 = bse * m1, b2 = bse * m2;
   // accumulate in place (tied operands keep the six sums in fixed registers across the sweep;
@@ -164,7 +133,7 @@ __device__ __forceinline__ void vote_acc(float T[6], float bse, float m0, float 
 #define VH_TV_WAVES 8
 #endif
 
-template <bool MASKED_SRC, int MODE, bool FMA = false>
+template <bool MASKED_SRC, int MODE>
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MODE != 1 ? VH_TV_WAVES : 2, 8)))
 tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, float* __restrict__ ten,
                 const float* __restrict__ mask_src, const float* __restrict__ mask_dst,
@@ -310,7 +279,7 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
           const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
           if (f) {
             const int idx = running + (tb - below - 1);      // salient lanes above this one come first
-            float4 a = make_float4(FMA ? s * (MODE == 0 ? 0.25f : 0.5f) : s, 0.0f, 0.0f, 0.0f);   // (see vote_dir_fma)
+            float4 a = make_float4(s, 0.0f, 0.0f, 0.0f);
             if (MODE != 3) { a.y = buf_load(rd0, off); a.z = buf_load(rd1, off); a.w = buf_load(rd2, off); }
             unsigned mv = 0u;
             if (MASKED_SRC) mv = __float_as_uint(buf_load(rm, off));
@@ -343,13 +312,8 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
         } else {
           const f4v d = *lds_ptr<f4v>(ent + 16u * (unsigned)k);
           float bse, m0, m1, m2;
-          if (FMA) {
-            vote_dir_fma<MODE>(d.x, fv, tw.y, tw.z, tw.w, d.y, d.z, d.w, bse, m0, m1, m2);
-            vote_acc_fma(T, bse, m0, m1, m2);
-          } else {
-            vote_dir<MODE>(d.x, fv, tw.y, tw.z, tw.w, d.y, d.z, d.w, p.exponent, p.curves, bse, m0, m1, m2);
-            vote_acc(T, bse, m0, m1, m2);
-          }
+          vote_dir<MODE>(d.x, fv, tw.y, tw.z, tw.w, d.y, d.z, d.w, p.exponent, p.curves, bse, m0, m1, m2);
+          vote_acc(T, bse, m0, m1, m2);
         }
       };
       auto batch = [&](const uint4& ca, const uint4& cb, unsigned ent, int s0) {
@@ -498,7 +462,7 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
 
 }  // namespace
 
-// dtab: the vote tables on the device (tv.hip: tv_table_device): the exact one, then the tolerance mode's.  weights_only: ten receives ONE plane, the sum of the
+// dtab: the vote table on the device (tv.hip: tv_table_device).  weights_only: ten receives ONE plane, the sum of the
 // weights of the votes each receiver takes (the normalisation denominator of feature.hpp:1784-1822) instead of tensors.
 int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* ten,
                  const float* mask_src, const float* mask_dst, i64 nx, i64 ny, i64 nz, i64 z_out0,
@@ -564,25 +528,20 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
     (void)hipGetLastError();
   }
   if (!scratch) return VISFD_HIP_OK;
-#define VH_TV_LAUNCH(MSK, MD, FM)                                                                    \
+#define VH_TV_LAUNCH(MSK, MD)                                                                        \
   do {                                                                                               \
-    VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tv_tiled_kernel<MSK, MD, FM>),         \
+    VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tv_tiled_kernel<MSK, MD>),             \
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
-    tv_tiled_kernel<MSK, MD, FM><<<dim3((unsigned)ngrid), dim3(NT), lds, st>>>(                      \
-        sal, dir, ten, mask_src, mask_dst, fma ? dtab + (size_t)n * n * n : dtab, p, counter, (unsigned)nblk, scratch); \
+    tv_tiled_kernel<MSK, MD><<<dim3((unsigned)ngrid), dim3(NT), lds, st>>>(sal, dir, ten, mask_src,  \
+                                                                          mask_dst, dtab, p, counter, \
+                                                                          (unsigned)nblk, scratch);  \
   } while (0)
-  // tolerance mode (option tv_fma): surfaces with exponent 2 or 4 only; its table (R = sqrt(2) rhat) follows the exact one
-  const bool fma = ctx->opt.tv_fma && (mode == 0 || mode == 2);
   if (mask_src) {
-    if (mode == 0) { if (fma) VH_TV_LAUNCH(true, 0, true); else VH_TV_LAUNCH(true, 0, false); }
-    else if (mode == 2) { if (fma) VH_TV_LAUNCH(true, 2, true); else VH_TV_LAUNCH(true, 2, false); }
-    else if (mode == 3) VH_TV_LAUNCH(true, 3, false);
-    else VH_TV_LAUNCH(true, 1, false);
+    if (mode == 0) VH_TV_LAUNCH(true, 0); else if (mode == 2) VH_TV_LAUNCH(true, 2); else if (mode == 3) VH_TV_LAUNCH(true, 3);
+    else VH_TV_LAUNCH(true, 1);
   } else {
-    if (mode == 0) { if (fma) VH_TV_LAUNCH(false, 0, true); else VH_TV_LAUNCH(false, 0, false); }
-    else if (mode == 2) { if (fma) VH_TV_LAUNCH(false, 2, true); else VH_TV_LAUNCH(false, 2, false); }
-    else if (mode == 3) VH_TV_LAUNCH(false, 3, false);
-    else VH_TV_LAUNCH(false, 1, false);
+    if (mode == 0) VH_TV_LAUNCH(false, 0); else if (mode == 2) VH_TV_LAUNCH(false, 2); else if (mode == 3) VH_TV_LAUNCH(false, 3);
+    else VH_TV_LAUNCH(false, 1);
   }
 #undef VH_TV_LAUNCH
   VH_HIP(hipGetLastError());
