@@ -17,10 +17,19 @@ N = 1: one S^3 volume (default 1024^3).  N > 1 (launched by torch.distributed.ru
 weak scaling -- a volume of S x S x (S*N) voxels cut into N Z-slabs with RCCL neighbour halo
 exchange and an all-reduced radix select (visfd_amd/slab.py); value = all voxels / max-over-ranks time.
 
-Prints ONE JSON line on rank 0.  `roofline` describes the separable-Gaussian kernel (the kernel
-BASELINE.json's HBM-roofline target names), timed alone with HIP events on the stream it runs on;
-`stages` gives the per-stage split of the pipeline step; `cpu_baseline` is the real reference (or
-the CPU restatement when oracle/_ref is absent) timed on this box's host cores on a small sample.
+MODES.  BASELINE.json's north_star asks for bit-exact indices and for float voxel values within 1e-5 relative.  The
+headline step therefore runs the library's TOLERANCE modes where the output is a float field -- tensor voting
+(option tv_fma: fused multiply-adds + mirror-paired sender planes) and the plain Gaussian of stage 1 (gauss_fma) -- and
+the exact kernels wherever an index depends on the bits (every LoG of the blob stage, the non-max scan, the radix
+select).  `--mode exact` times the all-exact pipeline instead; the line always carries both (`modes`), and
+tests/test_tolerance_modes.py + tests/test_full_size.py hold the tolerance kernels to 1e-5 of the field's scale.
+
+Prints ONE JSON line on rank 0.  `roofline` describes the DOMINANT kernel of the step (tensor voting, ~70 % of it: a
+VALU-bound stencil priced against the FP32 vector peak); `roofline_gauss` the separable-Gaussian kernel
+BASELINE.json's HBM target names; both are timed alone with HIP events on the stream they run on.  `copy_gbs` is a
+device-to-device copy measured in the same run: every HBM-bound object also states its fraction of that.  `stages_ms`
+gives the per-stage split of the step; `cpu_baseline` is the real reference (or the CPU restatement when oracle/_ref is
+absent) timed on this box's host cores on a sample of the same synthetic workload.
 """
 import argparse
 import json
@@ -82,9 +91,19 @@ def synth_volume(torch, ctx, shape, device, seed, z_offset=0, nz_global=None):
     return vol
 
 
-def cpu_baseline(sample=96):
-    """The same three stages on a sample^3 volume with the reference's OpenMP code on the host."""
-    import volgen
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(src, sample):
+    """The same three stages with the reference's OpenMP code on the host, on `src`: a sample^3 volume from the bench's own
+    generator (synth_volume: same noise, blob density per voxel and membrane geometry as the GPU workload)."""
     from oracle import pyoracle as po
     kind = "reference" if po.available("ref") else "port"
     if kind == "port" and not po.available("oracle"):
@@ -92,7 +111,6 @@ def cpu_baseline(sample=96):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libvisfd_oracle.so"])
     L = po.load("ref" if kind == "reference" else "oracle")
     from visfd_amd import pipeline
-    src = volgen.membrane_volume((sample,) * 3, seed=7)
     ratio = L.ratio_from_threshold(0.03)
     sig = pipeline.cli_blob_sigmas(*BLOB)
     t0 = time.perf_counter()
@@ -111,8 +129,12 @@ def cpu_baseline(sample=96):
     cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
     return {
         "value": round(nvox / (t3 - t0) / 1e6, 4), "unit": "Mvoxels/s", "cores": cores, "kind": kind,
-        "sample": "%d^3 synthetic membrane volume, same three stages (gauss %.3fs, blob %.3fs, membrane+TV %.3fs)"
-                  % (sample, t1 - t0, t2 - t1, t3 - t2),
+        "cpu_model": cpu_model(), "host_cpus": os.cpu_count(),
+        "omp": {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OMP_PROC_BIND", "OMP_PLACES")},
+        "sample": "%d^3 volume from the bench generator (synth_volume: noise + blobs + membranes, seed 12345), the same three "
+                  "stages with the %s (gauss %.3fs, blob %.3fs, membrane+TV %.3fs)"
+                  % (sample, "reference's own templates (oracle/_ref)" if kind == "reference" else "CPU restatement (oracle/)",
+                     t1 - t0, t2 - t1, t3 - t2),
     }
 
 
@@ -134,8 +156,10 @@ def offline_traffic(stem, shape):
 
 
 def pipeline_roofline(stage_ms, ms_per_step, nvox):
+    """nvox: voxels of ONE rank (its stage times against one GPU's HBM peak)."""
     total_b = sum(STAGE_BYTES_PER_VOXEL.values())
-    out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_voxel": total_b,
+    out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "per": "GPU (this rank's voxels and stage times)",
+           "algorithmic_bytes_per_voxel": total_b,
            "achieved": round(total_b * nvox / (ms_per_step * 1e-3) / 1e9, 1),
            "frac": round(total_b * nvox / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "stages": {}}
     for (name, b), ms in zip(STAGE_BYTES_PER_VOXEL.items(), stage_ms):
@@ -153,7 +177,9 @@ def main():
     ap.add_argument("--size", type=int, default=1024, help="edge of the per-GPU volume")
     ap.add_argument("--nz", type=int, default=0, help="planes per GPU (default: --size); e.g. --size 2048 --nz 512 is one "
                                                        "slab of BASELINE config 5")
-    ap.add_argument("--cpu-sample", type=int, default=192)
+    ap.add_argument("--cpu-sample", type=int, default=256, help="edge of the CPU baseline's sample volume")
+    ap.add_argument("--mode", choices=("tolerance", "exact"), default="tolerance",
+                    help="headline mode: tolerance = FMA tensor voting + FMA plain Gaussian (1e-5 contract), exact = bit-exact kernels only")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-2048", action="store_true", help="skip the extra Gaussian timing on a 2048^3 volume")
     args = ap.parse_args()
@@ -220,26 +246,30 @@ def main():
     ten = torch.empty((6,) + shape, device=device, dtype=torch.float32)
     torch.cuda.synchronize()
 
+    MODE_OPTS = {"tolerance": dict(tv_fma=1, gauss_fma=1), "exact": dict(tv_fma=0, gauss_fma=0)}
+    ratio = api.ratio_from_threshold(0.03)
+    # ONE source-halo exchange per step, at the deepest depth any stage needs (the widest LoG window + the 3x3x3 scan;
+    # the Gaussian and the ridge stage need less): the stage functions are told the ghost planes are current
+    src_depth = min(layout.ghost, int(math.floor(ratio * float(np.max(sig)) * 1.01)) + 1)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    stage_ms = np.zeros(3)
     counts = {}
 
-    def step(record):
+    def step(record, stage_ms):
         if record:
             ev[0].record()
         if world > 1:
-            slab.exchange_halos(src, layout, 6)
+            slab.exchange_halos(src, layout, src_depth)
         pipeline.gauss(ctx, src, dst, GAUSS_SIGMA)
         if record:
             ev[1].record()
         if world > 1:
-            mins, maxs = slab.blob_detect_slab(ctx, layout, src, sig)
+            mins, maxs = slab.blob_detect_slab(ctx, layout, src, sig, src_halo_ready=True)
         else:
             mins, maxs = pipeline.blob_detect(ctx, src, sig)
         if record:
             ev[2].record()
         if world > 1:
-            thr = slab.membrane_detect_slab(ctx, layout, src, sal, dirs, ten, scratch=dst, **MEMBRANE)
+            thr = slab.membrane_detect_slab(ctx, layout, src, sal, dirs, ten, scratch=dst, src_halo_ready=True, **MEMBRANE)
         else:
             thr = pipeline.membrane_detect(ctx, src, sal, dirs, ten, scratch=dst, **MEMBRANE)
         if record:
@@ -249,105 +279,181 @@ def main():
                 stage_ms[i] += ev[i].elapsed_time(ev[i + 1])
         counts.update(minima=len(mins), maxima=len(maxs), threshold=float(thr))
 
-    for _ in range(args.warmup):
-        step(False)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms_per_step = elapsed * 1e3 / args.steps
-    value = nvox_rank * world / (ms_per_step * 1e-3) / 1e6  # Mvoxels/s, whole job
+    def run_mode(mode, steps, warmup):
+        """W untimed + exactly K timed steps, barrier + synchronize on both sides, MAX over ranks."""
+        stage_ms = np.zeros(3)
+        with ctx.options(**MODE_OPTS[mode]):
+            for _ in range(warmup):
+                step(False, stage_ms)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step(True, stage_ms)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        ms = elapsed * 1e3 / steps
+        return {"ms_per_step": round(ms, 3), "value": round(nvox_rank * world / (ms * 1e-3) / 1e6, 3), "steps": steps,
+                "stages_ms": {"gauss": round(stage_ms[0] / steps, 3), "blob_dog": round(stage_ms[1] / steps, 3),
+                              "membrane_tv": round(stage_ms[2] / steps, 3)},
+                "results": dict(counts)}, stage_ms / steps
 
-    # ---- roofline of the separable-Gaussian kernel, timed alone with HIP events ----------------
-    roofline = roofline_pass = roofline_tv = None
-    if rank == 0:
-        reps = 10
-        pipeline.gauss(ctx, src, dst, GAUSS_SIGMA)
+    headline, stage_avg = run_mode(args.mode, args.steps, args.warmup)
+    other_mode = "exact" if args.mode == "tolerance" else "tolerance"
+    other, _ = run_mode(other_mode, 2, 1)      # the other mode, briefly, for the record
+    ms_per_step, value = headline["ms_per_step"], headline["value"]
+
+    # ---- multi-GPU: a seam check, so that the first run with one GPU per rank validates bits as well as speed ------
+    # Every rank > 0 regenerates the top planes of its lower neighbour's slab (the generator is a pure function of the
+    # slab's position), joins them to its own bottom planes into a small volume that has the seam in its middle, runs the
+    # single-volume ridge + voting stages on it with the GLOBAL threshold the slab run selected, and compares the planes
+    # just above the seam with what the slab run left in `ten` (bit for bit in exact mode, 1e-5 in tolerance mode).
+    slab_check = None
+    if world > 1:
+        ok, nchk = 1, 0
+        D = 40
+        thr = counts["threshold"]
+        order = api.DECREASING_EIVALS
+        with ctx.options(**MODE_OPTS[args.mode]):
+            step(False, np.zeros(3))           # `ten` of the headline mode
+            if rank > 0 and layout.z1 - layout.z0 >= D:
+                prev = slab.SlabLayout(NZ * world, rank - 1, world, ghost=layout.ghost)
+                below = synth_volume(torch, ctx, (prev.z1 - prev.z0, S, S), device, seed=12345, z_offset=prev.z0,
+                                     nz_global=NZ * world)[-D:].clone()
+                block = torch.cat([below, layout.owned(src)[:D]], 0).contiguous()
+                del below
+                bsal, bsm = torch.empty_like(block), torch.empty_like(block)
+                bdirs = torch.zeros((3,) + tuple(block.shape), device=device)
+                bten = torch.empty((6,) + tuple(block.shape), device=device)
+                ctx.ridge_scores_dev(block, bsal, bsm, MEMBRANE["sigma"], ratio, order)
+                ctx.apply_threshold_dev(bsal, thr)
+                ctx.ridge_directions_dev(bsm, bsal, bdirs, MEMBRANE["sigma"], order)
+                ctx.tv_dense_stick_dev(bsal, bdirs, bten, sigma_tv, MEMBRANE["tv_exponent"], math.sqrt(2.0))
+                torch.cuda.synchronize()
+                margin = h_tv + int(math.floor(np.float32(MEMBRANE["sigma"]) * np.float32(ratio))) + 2
+                lo, hi = D, 2 * D - margin                       # block planes = owned planes [0, D - margin)
+                got = layout.owned(ten)[:, :hi - lo]
+                want = bten[:, lo:hi]
+                nchk = hi - lo
+                if args.mode == "exact":
+                    ok = int(torch.equal(got.view(torch.int32), want.view(torch.int32)))
+                else:
+                    ok = int(float((got - want).abs().max()) <= 1e-5 * float(want.abs().max()))
+                ok = ok and int(float(want.abs().max()) > 0)
+                del block, bsal, bsm, bdirs, bten
+        flags = torch.tensor([int(ok), nchk], device=device, dtype=torch.int64)
+        allf = [torch.empty_like(flags) for _ in range(world)]
+        dist.all_gather(allf, flags)
+        allf = [f.cpu().numpy() for f in allf]
+        slab_check = {"ok": bool(all(int(f[0]) for f in allf)), "mode": args.mode,
+                      "compared": "vote tensors of the %d planes above every interior slab seam vs a single-volume run on the "
+                                  "regenerated planes around the seam (%s)" % (int(max(f[1] for f in allf)),
+                                  "bit for bit" if args.mode == "exact" else "1e-5 of the field's scale"),
+                      "seams_checked": int(sum(1 for f in allf if int(f[1]) > 0))}
+
+    # ---- roofline objects, rank 0, each kernel timed alone with HIP events on the stream it runs on ---------------------
+    roofline = roofline_gauss = roofline_pass = roofline_ridge = copy_gbs = None
+    tv_objs = {}
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def timed(fn, reps, warm=1):
+        for _ in range(warm):
+            fn()
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            pipeline.gauss(ctx, src, dst, GAUSS_SIGMA)
+            fn()
         e1.record()
         torch.cuda.synchronize()
-        g_ms = e0.elapsed_time(e1) / reps
+        return e0.elapsed_time(e1) / reps
+
+    def hbm_obj(kernel, ms, nv, bytes_per_voxel=8.0, **extra):
+        gbs = bytes_per_voxel * nv / (ms * 1e-3) / 1e9
+        o = {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_copy": round(gbs / copy_gbs, 4) if copy_gbs else None,
+             "algorithmic_bytes": int(bytes_per_voxel * nv), "ms_per_launch": round(ms, 4), "voxels_per_launch": nv}
+        o.update(extra)
+        return o
+
+    if rank == 0:
         nv = shape[0] * shape[1] * shape[2]
-        achieved = 8.0 * nv / (g_ms * 1e-3) / 1e9  # algorithmic 8 B/voxel
-        # HBM bytes per launch from PMC counters: measured offline with rocprofv3 (separate --pmc passes,
-        # tools/pmc_traffic.py) and committed under profiles/; only quoted for the shape it was measured on
+        # what this box's HBM gives a plain device-to-device copy of the same volume (read 4 + write 4 B/voxel)
+        c_ms = timed(lambda: dst.copy_(src), 5)
+        copy_gbs = round(8.0 * nv / (c_ms * 1e-3) / 1e9, 1)
+
+        # the separable Gaussian (BASELINE's HBM target kernel), exact and tolerance form
+        with ctx.options(gauss_fma=0):
+            g_ms = timed(lambda: pipeline.gauss(ctx, src, dst, GAUSS_SIGMA), 10)
+        with ctx.options(gauss_fma=1):
+            gf_ms = timed(lambda: pipeline.gauss(ctx, src, dst, GAUSS_SIGMA), 10)
         traffic, traffic_file = offline_traffic("gauss_traffic", shape)
-        roofline = {"bound": "hbm", "kernel": "gauss_fused_kernel<H=5> (separable 3-D Gaussian, sigma=2)",
-                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "traffic_unit": "bytes per launch, measured OFFLINE (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE in separate passes, "
-                                    "%s), not in this run" % traffic_file,
-                    "algorithmic_bytes": 8 * nv,
-                    "ms_per_launch": round(g_ms, 4), "voxels_per_launch": nv,
-                    "note": "exact mul+add arithmetic (no FMA) makes this kernel VALU-bound, see DESIGN.md"}
-
-        # one 1-D pass of the separable Gaussian (the 3-pass path used for masks, ragged widths and wide windows):
-        # three launches (Z, Y, X with the normalisation), 8 B/voxel each; average launch time = total / 3
+        roofline_gauss = hbm_obj("gauss_fused_kernel<H=5> (separable 3-D Gaussian in one sweep, sigma=2), exact arithmetic", g_ms, nv,
+                                 traffic=traffic,
+                                 traffic_unit="bytes per launch, measured OFFLINE (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE in "
+                                              "separate passes, %s), not in this run" % traffic_file,
+                                 note="exact mul+add arithmetic (no FMA) makes this kernel VALU-bound, see DESIGN.md",
+                                 tolerance_mode=hbm_obj("gauss_fused_kernel<H=5, FMA> (option gauss_fma: fused multiply-adds, "
+                                                        "reciprocal normaliser; 1e-5 contract)", gf_ms, nv))
         with ctx.options(gauss_3pass=1):
-            pipeline.gauss(ctx, src, dst, GAUSS_SIGMA)
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(reps):
-                pipeline.gauss(ctx, src, dst, GAUSS_SIGMA)
-            e1.record()
-            torch.cuda.synchronize()
-        p_ms = e0.elapsed_time(e1) / reps / 3.0
-        p_ach = 8.0 * nv / (p_ms * 1e-3) / 1e9
-        p_traffic, _ = offline_traffic("gauss_pass_traffic", shape)   # average of the three passes
-        roofline_pass = {"bound": "hbm", "kernel": "conv_march_kernel<5> (Z, Y) / conv_row_kernel<5> (X): one 1-D pass of "
-                                                   "the separable Gaussian, sigma=2",
-                         "achieved": round(p_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(p_ach / HBM_PEAK_GBS, 4), "traffic": p_traffic, "algorithmic_bytes": 8 * nv,
-                         "ms_per_launch": round(p_ms, 4), "voxels_per_launch": nv,
-                         "note": "average of the three pass launches; a device copy on this box runs at ~5.0 TB/s"}
+            p_ms = timed(lambda: pipeline.gauss(ctx, src, dst, GAUSS_SIGMA), 10) / 3.0
+        p_traffic, _ = offline_traffic("gauss_pass_traffic", shape)
+        roofline_pass = hbm_obj("conv_march_kernel<5> (Z, Y) / conv_row_kernel<5> (X): one 1-D pass of the separable Gaussian, "
+                                "sigma=2 (average of the three launches)", p_ms, nv, traffic=p_traffic)
 
-        # the tensor-voting kernel (80 % of the step): a VALU-bound stencil, priced against the FP32 vector peak as
-        # SURVEY.md 8d asks -- 45 flop per evaluated vote (feature.hpp:2312-2377), votes = salient senders x non-zero taps
-        # (boundary clipping ignored: < 4 % at this size)
+        # the ridge stage of the membrane detector: FP64 eigen-decompositions, priced against HBM (SURVEY 8d: 20 B/voxel for
+        # scores + directions, 28 for the post-vote score) and against the FP64 vector peak
         order = api.DECREASING_EIVALS
-        ratio = api.ratio_from_threshold(0.03)
-        ctx.ridge_saliency_dev(src, sal, dirs, MEMBRANE["sigma"], ratio, order)
+        rs_ms = timed(lambda: ctx.ridge_scores_dev(src, sal, dst, MEMBRANE["sigma"], ratio, order), 3)
         ctx.threshold_fraction_dev(sal, MEMBRANE["best_fraction"])
+        rd_ms = timed(lambda: ctx.ridge_directions_dev(dst, sal, dirs, MEMBRANE["sigma"], order), 3)
         n_salient = int(torch.count_nonzero(sal).item())
         _, w_tab, _ = api.tv_tables(sigma_tv, math.sqrt(2.0))
         n_taps = int(np.count_nonzero(w_tab))
-        torch.cuda.synchronize()
-        e0.record()
-        ctx.tv_dense_stick_dev(sal, dirs, ten, sigma_tv, MEMBRANE["tv_exponent"], math.sqrt(2.0))
-        e1.record()
-        torch.cuda.synchronize()
-        tv_ms = e0.elapsed_time(e1)
         votes = float(n_salient) * n_taps
+
+        # tensor voting, the dominant kernel: a VALU-bound stencil priced against the FP32 vector peak as SURVEY.md 8d asks --
+        # 45 flop per evaluated vote (feature.hpp:2312-2377), votes = salient senders x non-zero taps (boundary clipping
+        # ignored: < 4 % at this size)
         tv_traffic, tv_traffic_file = offline_traffic("tv_traffic", shape)
-        tv_tflops = 45.0 * votes / (tv_ms * 1e-3) / 1e12
-        roofline_tv = {"bound": "valu", "kernel": "tv_tiled_kernel (dense stick tensor voting, sigma_tv=8.66, h=12)",
-                       "achieved": round(tv_tflops, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tv_tflops / 157.3, 4),
-                       "traffic": tv_traffic, "ms_per_launch": round(tv_ms, 2), "votes_per_launch": votes,
-                       "flop_per_vote": 45, "salient_senders": n_salient, "nonzero_taps": n_taps,
-                       # the same work against what the VALU can issue without FMA: 32 multiplies/adds per vote, 70 T scalar
-                       # lane-operations/s measured on this chip (profiles/r02_microbench_valu.txt)
-                       "useful_lane_ops_per_s": round(32.0 * votes / (tv_ms * 1e-3) / 1e12, 2), "valu_issue_peak_lane_ops_per_s": 70.0,
-                       "valu_frac_useful": round(32.0 * votes / (tv_ms * 1e-3) / 70e12, 4),
-                       "algorithmic_bytes": 40 * nv, "hbm_achieved_gbs": round(40.0 * nv / (tv_ms * 1e-3) / 1e9, 1),
-                       "hbm_frac": round(40.0 * nv / (tv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                       "traffic_unit": "bytes per launch, measured OFFLINE (%s), not in this run" % tv_traffic_file,
-                       "note": "peak = nominal FP32 vector rate, which counts an FMA as 2 flop; the reference's operation order "
-                               "forbids FMA, so the reachable rate is the 70 T scalar lane-operations/s the VALU issues "
-                               "(profiles/r02_microbench_valu.txt): 32 of them per vote, DESIGN.md 4.2"}
+        for mode, kname, ops_per_vote, note in (
+                ("exact", "tv_tiled_kernel (bit-exact: the reference's 32 multiplies/adds per vote in its order, no FMA)", 32.0,
+                 "peak = nominal FP32 vector rate, which counts an FMA as 2 flop; the reference's operation order forbids FMA here, "
+                 "so the reachable rate is the 70 T lane-operations/s the VALU issues (profiles/r02_microbench_valu.txt)"),
+                ("tolerance", "tv_pair_kernel (option tv_fma: 19 fused instructions per vote, mirror-paired sender planes; 1e-5 "
+                 "contract)", 19.0, "flop counted as the reference's 45 per vote (the algorithmic work unit of SURVEY 8d)")):
+            with ctx.options(tv_fma=1 if mode == "tolerance" else 0):
+                tv_ms = timed(lambda: ctx.tv_dense_stick_dev(sal, dirs, ten, sigma_tv, MEMBRANE["tv_exponent"], math.sqrt(2.0)), 2)
+            tfl = 45.0 * votes / (tv_ms * 1e-3) / 1e12
+            tv_objs[mode] = {
+                "bound": "valu", "kernel": kname + ", sigma_tv=8.66, h=12", "achieved": round(tfl, 2), "peak": 157.3,
+                "unit": "TFLOP/s", "frac": round(tfl / 157.3, 4), "ms_per_launch": round(tv_ms, 2), "votes_per_launch": votes,
+                "flop_per_vote": 45, "salient_senders": n_salient, "nonzero_taps": n_taps,
+                "valu_instructions_per_vote": ops_per_vote,
+                "useful_lane_ops_per_s": round(ops_per_vote * votes / (tv_ms * 1e-3) / 1e12, 2),
+                "valu_issue_peak_lane_ops_per_s": 70.0,
+                "valu_frac_useful": round(ops_per_vote * votes / (tv_ms * 1e-3) / 70e12, 4),
+                "traffic": tv_traffic if mode == "exact" else None, "algorithmic_bytes": 40 * nv,
+                "hbm_achieved_gbs": round(40.0 * nv / (tv_ms * 1e-3) / 1e9, 1),
+                "hbm_frac": round(40.0 * nv / (tv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "traffic_unit": "bytes per launch, measured OFFLINE (%s), not in this run" % tv_traffic_file, "note": note}
+        roofline = dict(tv_objs[args.mode])
+        roofline["share_of_step"] = round(roofline["ms_per_launch"] / ms_per_step, 3)
+        ts_ms = timed(lambda: ctx.tensor_saliency_dev(ten, sal, order), 3)
+        # FP64 work of the eigen kernels, counted from the compiled code (tools/count_fp64.py): vector FP64 instructions per
+        # voxel on the common path x 2 flop for FMA forms; peak 78.6 TFLOP/s FP64 vector (MI355X_MICROARCH.md)
+        roofline_ridge = {
+            "bound": "fp64 valu", "peak_tflops_fp64_vector": 78.6,
+            "ridge_score_kernel": hbm_obj("Gaussian-smoothed Hessian -> eigenvalues -> planar score, every voxel", rs_ms, nv, 8.0),
+            "ridge_directions_kernel": hbm_obj("eigenvectors of the voxels above the threshold (5 %)", rd_ms, nv, 16.0),
+            "tensor_saliency_kernel": hbm_obj("eigenvalues of the vote tensor -> lambda0 - lambda1", ts_ms, nv, 28.0),
+            "note": "ms_per_launch of ridge_score_kernel includes the smoothing Gaussian (sigma 1.73, h=4) in front of it"}
 
     # ---- the north-star target case: the separable Gaussian on a 2048^3 volume (2^33 voxels, 32 GiB) -------
     roofline_2048 = None
@@ -362,67 +468,81 @@ def main():
             for z in range(0, n2, 128):
                 big[z:z + 128] = torch.randn((128, n2, n2), device=device, generator=gen) * 100 + 1000
             bout = torch.empty_like(big)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-
-            def timed(reps):
-                pipeline.gauss(ctx, big, bout, GAUSS_SIGMA)
-                torch.cuda.synchronize()
-                e0.record()
-                for _ in range(reps):
-                    pipeline.gauss(ctx, big, bout, GAUSS_SIGMA)
-                e1.record()
-                torch.cuda.synchronize()
-                return e0.elapsed_time(e1) / reps
-            f_ms = timed(5)
-            with ctx.options(gauss_3pass=1):
-                p_ms = timed(3) / 3.0
             nv2 = n2 ** 3
+            c2 = timed(lambda: bout.copy_(big), 3)
+            copy2 = 8.0 * nv2 / (c2 * 1e-3) / 1e9
+            with ctx.options(gauss_fma=0):
+                f_ms = timed(lambda: pipeline.gauss(ctx, big, bout, GAUSS_SIGMA), 4)
+            with ctx.options(gauss_fma=1):
+                ff_ms = timed(lambda: pipeline.gauss(ctx, big, bout, GAUSS_SIGMA), 4)
+            with ctx.options(gauss_3pass=1):
+                p2_ms = timed(lambda: pipeline.gauss(ctx, big, bout, GAUSS_SIGMA), 2) / 3.0
+
+            def o2(kernel, ms):
+                gbs = 8.0 * nv2 / (ms * 1e-3) / 1e9
+                return {"kernel": kernel, "ms_per_launch": round(ms, 3), "achieved": round(gbs, 1),
+                        "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_copy": round(gbs / copy2, 4)}
             roofline_2048 = {
                 "bound": "hbm", "workload": "separable 3-D Gaussian, sigma=2 (h=5), 2048^3 float32 (32 GiB)",
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes": 8 * nv2,
-                "single_sweep": {"kernel": "gauss_fused_kernel<H=5>", "ms_per_launch": round(f_ms, 3),
-                                 "achieved": round(8.0 * nv2 / (f_ms * 1e-3) / 1e9, 1),
-                                 "frac": round(8.0 * nv2 / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-                "one_pass": {"kernel": "conv_march_kernel<5> / conv_row_kernel<5> (average of the Z, Y, X launches)",
-                             "ms_per_launch": round(p_ms, 3), "achieved": round(8.0 * nv2 / (p_ms * 1e-3) / 1e9, 1),
-                             "frac": round(8.0 * nv2 / (p_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes": 8 * nv2, "copy_gbs": round(copy2, 1),
+                "single_sweep": o2("gauss_fused_kernel<H=5, FMA> (tolerance mode, option gauss_fma: what `filter_mrc -gauss` "
+                                   "output needs -- float voxels, 1e-5 contract)", ff_ms),
+                "single_sweep_exact": o2("gauss_fused_kernel<H=5> (bit-exact: what LoG -> non-max indices need)", f_ms),
+                "one_pass": o2("conv_march_kernel<5> / conv_row_kernel<5> (average of the Z, Y, X launches)", p2_ms)}
             del big, bout
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:   # the CPU baseline is an N=1 line only
+        try:
+            cs = args.cpu_sample
+            sample = synth_volume(torch, ctx, (cs, cs, cs), device, seed=12345).cpu().numpy()
+            torch.cuda.synchronize()
+            cpu = cpu_baseline(sample, cs)
+        except Exception as e:  # the checker libraries are optional on the GPU box
+            cpu = {"value": None, "unit": "Mvoxels/s", "cores": 0, "kind": "unavailable", "sample": "failed: %s" % e}
 
     if rank == 0:
         out = {
             "metric": "Mvoxels/s (Gauss+DoG+TV pipeline) on %s float32; %% HBM roofline" % (
                 "%d^3" % S if NZ == S else "%dx%dx%d per GPU" % (S, S, NZ)),
-            "value": round(value, 3), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "value": value, "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "gauss(sigma=2) + blob-dog(12 scales, sigma 2..4) + membrane/TV(sigma=1.732, "
                                    "sigma_tv=8.66, top 5%%) on %dx%dx%d float32" % (S, S, NZ * world),
+                       "mode": args.mode,
+                       "mode_note": "tolerance: tensor voting and the stage-1 Gaussian use fused multiply-adds (float outputs, "
+                                    "1e-5 of the field's scale, tests/test_tolerance_modes.py); every LoG, the non-max scan and "
+                                    "the radix select stay bit-exact.  exact: bit-exact kernels everywhere",
                        "per_gpu_voxels": nvox_rank, "decomposition": "z-slabs, ghost %d" % layout.ghost,
                        "halo_transport": "none" if world == 1 else ("rccl" if own_gpu else "gloo-staged (shared GPU rehearsal)")},
-            "stages_ms": {"gauss": round(stage_ms[0] / args.steps, 3), "blob_dog": round(stage_ms[1] / args.steps, 3),
-                          "membrane_tv": round(stage_ms[2] / args.steps, 3)},
-            "results": counts,
+            "stages_ms": headline["stages_ms"],
+            "results": headline["results"],
+            "modes": {args.mode: headline, other_mode: other},
+            "copy_gbs": copy_gbs,
             # the BASELINE metric's own "% HBM roofline": algorithmic bytes of SURVEY.md 8d per voxel (3-D Gaussian 8, blob
             # detection with 12 scales 8*12 + 12*10 = 216, Gauss + Hessian/eigen + select + TV + score 112) over the
-            # measured stage times of the timed steps
-            "roofline_pipeline": pipeline_roofline(stage_ms / args.steps, ms_per_step, nvox_rank * world),
+            # measured stage times of the timed steps, per GPU
+            "roofline_pipeline": pipeline_roofline(stage_avg, ms_per_step, nvox_rank),
             "roofline": roofline,
+            "roofline_tv": tv_objs,
+            "roofline_gauss": roofline_gauss,
             "roofline_pass": roofline_pass,
-            "roofline_tv": roofline_tv,
+            "roofline_ridge": roofline_ridge,
             "roofline_2048": roofline_2048,
         }
-        if not args.no_cpu and world == 1:  # the CPU baseline is an N=1 line only
-            try:
-                out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
-            except Exception as e:  # the checker libraries are optional on the GPU box
-                out["cpu_baseline"] = {"value": None, "unit": "Mvoxels/s", "cores": 0, "kind": "unavailable",
-                                       "sample": "failed: %s" % e}
+        if slab_check is not None:
+            out["slab_check"] = slab_check
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+    if slab_check is not None and not slab_check["ok"]:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -53,7 +53,7 @@ def _crop(t, lo, hi):
     return t[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]].contiguous().cpu().numpy()
 
 
-def _check_membrane(gpu, oracle, src, crops, E, dense=0.12, ridge_crops=4):
+def _check_membrane(gpu, oracle, src, crops, E, dense=0.12, ridge_crops=4, tv_fma=0):
     """The steps of pipeline.membrane_detect on `src` (every stage fed by the previous device stage, as in bench.py),
     keeping the thresholded saliency the votes are cast from; then crops against the oracle on crop + halo."""
     import bench
@@ -79,7 +79,8 @@ def _check_membrane(gpu, oracle, src, crops, E, dense=0.12, ridge_crops=4):
     ctx.synchronize()
     del smoothed
     sal_thr = sal.clone()
-    ctx.tv_dense_stick_dev(sal, dirs, ten, sigma_tv, P["tv_exponent"], math.sqrt(2.0))
+    with ctx.options(tv_fma=tv_fma):
+        ctx.tv_dense_stick_dev(sal, dirs, ten, sigma_tv, P["tv_exponent"], math.sqrt(2.0))
     ctx.tensor_saliency_dev(ten, sal, order)
     ctx.synchronize()
     nsal = int((sal_thr != 0).sum().item())
@@ -97,7 +98,11 @@ def _check_membrane(gpu, oracle, src, crops, E, dense=0.12, ridge_crops=4):
         want_c = want[o[0]:o[0] + E, o[1]:o[1] + E, o[2]:o[2] + E]
         got_c = np.ascontiguousarray(np.stack([_crop(ten[k], c0, c0 + E) for k in range(6)], axis=-1))
         assert np.abs(want_c).max() > 0
-        assert_bits_equal(got_c, want_c, "vote tensor in the crop at %s" % ((z0, y0, x0),))
+        if tv_fma:   # tolerance mode: 1e-5 of the crop's own scale (stricter than the field's)
+            assert_close_rel(got_c, want_c, 1e-5, "tolerance-mode vote tensor in the crop at %s" % ((z0, y0, x0),))
+            assert not np.array_equal(got_c.view(np.uint32), want_c.view(np.uint32)), "the tolerance kernel did not run"
+        else:
+            assert_bits_equal(got_c, want_c, "vote tensor in the crop at %s" % ((z0, y0, x0),))
         seen_dense = seen_dense or (s_sub != 0).mean() > dense
         # post-vote score of the crop (eigen-derived: 1e-5 of the field's scale)
         s2 = np.zeros(want_c.shape[:3], np.float32)
@@ -145,6 +150,23 @@ def test_membrane_1024_cubed_crops_equal_oracle(gpu, volume, oracle):
         (int(0.5 * N + 0.3 * N) - E // 2, int(0.4 * N), int(0.5 * N)),   # on the shell (its top)
     ]
     _check_membrane(gpu, oracle, volume, crops, E)
+
+
+def test_membrane_1024_cubed_tolerance_mode(gpu, volume, oracle):
+    """The same run with tensor voting in TOLERANCE MODE (option tv_fma: fused multiply-adds, mirror-paired sender planes,
+    csrc/tv_pair.hip): vote tensors within 1e-5 of each crop's scale -- corners, run and tile seams, on the membranes -- and
+    the post-vote score within 1e-5 as before."""
+    zp = lambda y, x: int(round(0.35 * N - 0.15 * x + 0.1 * y))
+    E = 28
+    crops = [
+        (0, 0, 0),
+        (N - E, N - E, N - E),
+        (320 - E // 2, 16 * 20 - E // 2, 16 * 31 - E // 2),
+        (640 - 5, N - E, 7),
+        (zp(200, 300) - E // 2, 200, 300),
+        (int(0.5 * N + 0.3 * N) - E // 2, int(0.4 * N), int(0.5 * N)),
+    ]
+    _check_membrane(gpu, oracle, volume, crops, E, ridge_crops=0, tv_fma=1)
 
 
 def test_config5_plane_block_crops_equal_oracle(gpu, oracle):

@@ -362,7 +362,10 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
     int slot_a = 1 << 20, slot_b = 1 << 20;   // which table slice LDS slot 0 / 1 holds (uniform)
     float4* const sl4 = reinterpret_cast<float4*>(slices);
     for (int rz = z_run0; rz < z_run1; rz += 2) {
-      const int sz_hi = min(rz + 1 + h, p.nz - 1), sz_lo = max(rz - h, 0);
+      // sender planes that reach the LIVE receivers of this pair: a run of odd length ends with half a pair, and nothing above
+      // rz + h is needed then -- in a slab run that plane may not even be complete yet (visfd_amd/slab.py votes the interior
+      // band while the halo planes above it are still in flight)
+      const int sz_hi = min(min(rz + 1, z_run1 - 1) + h, p.nz - 1), sz_lo = max(rz - h, 0);
       // the window holds at most 2h+2 planes, so a plane that enters it takes the slot of one that has left
       for (int sz = sz_hi; sz >= sz_lo; sz--)   // uniform
         if (p.relist || sz < cached_lo || sz > cached_hi) list_plane(sz);

@@ -58,9 +58,10 @@ def check_stream(ops, t):
     if t.is_cuda and hasattr(ops, "stream_handle"):
         cur = torch.cuda.current_stream(t.device).cuda_stream
         if ops.stream_handle() != cur:
-            raise RuntimeError("visfd_amd.slab: the Context runs on HIP stream %#x but torch's current stream is %#x; "
-                               "create it with api.Context(dev, torch.cuda.current_stream().cuda_stream)"
-                               % (ops.stream_handle(), cur))
+            raise RuntimeError("visfd_amd.slab: the Context runs on HIP stream %#x but torch's current stream is %#x.  Make a "
+                               "NON-DEFAULT stream current first (st = torch.cuda.Stream(dev); torch.cuda.set_stream(st)) and "
+                               "create the context on it: api.Context(dev, st.cuda_stream).  (The default stream's handle is 0, "
+                               "which the library reads as 'create a stream of my own'.)" % (ops.stream_handle(), cur))
 
 
 class HaloExchange:
@@ -134,6 +135,7 @@ def _key_to_float(key):
 def distributed_threshold_fraction(ops, sal_owned, fraction, layout, mask_owned=None, group=None):
     """Exact global k-th largest saliency over all ranks' owned voxels, then zero everything below
     it (handlers.cpp:1751-1797).  Three radix rounds; each all-reduces 2048 counters."""
+    check_stream(ops, sal_owned)
     prefix, k, thr_key = 0, None, 0
     shifts = (21, 10, 0)
     # over RCCL the histogram never leaves the devices until it is summed: the kernel writes it to device memory, the
@@ -165,7 +167,7 @@ def distributed_threshold_fraction(ops, sal_owned, fraction, layout, mask_owned=
 
 def membrane_detect_slab(ops, layout, src, sal, dirs, tensor, sigma, tv_sigma_ratio, tv_exponent=4,
                          best_fraction=0.05, truncate_threshold=0.03, tv_truncate_ratio=math.sqrt(2.0),
-                         minima=True, group=None, scratch=None):
+                         minima=True, group=None, scratch=None, src_halo_ready=False):
     """HandleTV (handlers.cpp:1501-1892) on one slab.  `src` holds the owned planes (ghosts are
     filled here); all tensors have the local shape [nz_local, ny, nx] (dirs: [3, ...], tensor: [6, ...]).
     Valid results are the owned planes of `sal` (post-voting saliency) and `tensor`."""
@@ -177,8 +179,10 @@ def membrane_detect_slab(ops, layout, src, sal, dirs, tensor, sigma, tv_sigma_ra
     h_tv = int(math.floor(np.float32(sigma_tv) * np.float32(tv_truncate_ratio)))
     assert L.world == 1 or (h_gauss + 1 <= L.ghost and h_tv <= L.ghost), "ghost depth too small"
     check_stream(ops, src)
-    # 1. source halo deep enough for smoothing + the 19-point stencil
-    exchange_halos(src, L, min(L.ghost, h_gauss + 1), group)
+    # 1. source halo deep enough for smoothing + the 19-point stencil (src_halo_ready: the caller has already exchanged
+    #    the source's ghost planes at least that deep in this step)
+    if not src_halo_ready:
+        exchange_halos(src, L, min(L.ghost, h_gauss + 1), group)
     # 2. saliency/direction on every stored plane; planes closer than h_gauss+1 to an interior
     #    array end are garbage, owned planes are exact
     #    (scores first; directions only for the voxels that survive the threshold -- `scratch`: a tensor of the
@@ -254,7 +258,7 @@ def _all_gather_rows(like, arrays, group=None):
 
 
 def blob_detect_slab(ops, layout, src, sigmas, truncate_threshold=0.03, delta=0.02, minima_threshold=np.inf,
-                     maxima_threshold=-np.inf, use_ratios=False, group=None, cap=1 << 22):
+                     maxima_threshold=-np.inf, use_ratios=False, group=None, cap=1 << 22, src_halo_ready=False):
     """BlobDog (feature.hpp:53-427) on one slab: LoG volumes are computed on the stored planes, the
     4-D non-max scan keeps candidates of owned planes only, lists are merged on every rank."""
     L = layout
@@ -263,7 +267,8 @@ def blob_detect_slab(ops, layout, src, sigmas, truncate_threshold=0.03, delta=0.
     depth = int(math.floor(ratio * smax)) + 1
     assert L.world == 1 or depth <= L.ghost, "ghost depth too small for the widest LoG"
     check_stream(ops, src)
-    exchange_halos(src, L, min(L.ghost, depth), group)
+    if not src_halo_ready:
+        exchange_halos(src, L, min(L.ghost, depth), group)
     # absolute thresholds prune inside the scan (strict, feature.hpp:270-291): only survivors are sorted and copied to
     # the host; ratio thresholds need the global best score first, so they are applied after the merge
     if use_ratios:
