@@ -296,6 +296,161 @@ def test_eigen_solver(ctx, oracle):
         assert err <= 1e-5, "eigenvalues rel err %g" % err
 
 
+def _shoemake_frame(sm):
+    """Shoemake triple -> quaternion -> rotation matrix, the decoding half of the reference's frame round trip
+    (lin3_utils.hpp:311-337 Shoemake2Quaternion, :275-305 Quaternion2Matrix), in float64 for the checks below."""
+    sm = sm.astype(np.float64)
+    t1, t2 = 2 * np.pi * sm[:, 1], 2 * np.pi * sm[:, 2]
+    r1, r2 = np.sqrt(1.0 - sm[:, 0]), np.sqrt(sm[:, 0])
+    q0, q1, q2, q3 = np.sin(t1) * r1, np.cos(t1) * r1, np.sin(t2) * r2, np.cos(t2) * r2
+    M = np.empty((len(sm), 3, 3))
+    M[:, 0, 0] = 1 - 2 * q2 * q2 - 2 * q3 * q3
+    M[:, 1, 1] = 1 - 2 * q1 * q1 - 2 * q3 * q3
+    M[:, 2, 2] = 1 - 2 * q1 * q1 - 2 * q2 * q2
+    M[:, 0, 1] = 2 * (q1 * q2 - q3 * q0)
+    M[:, 1, 0] = 2 * (q1 * q2 + q3 * q0)
+    M[:, 1, 2] = 2 * (q2 * q3 - q1 * q0)
+    M[:, 2, 1] = 2 * (q2 * q3 + q1 * q0)
+    M[:, 0, 2] = 2 * (q1 * q3 + q2 * q0)
+    M[:, 2, 0] = 2 * (q1 * q3 - q2 * q0)
+    return M
+
+
+def test_eigen_solver_frames(ctx, oracle):
+    """All six outputs of visfd_hip_diagonalize_flat_sym3 (eigen3_simple.hpp:137-342, lin3_utils.hpp:231-375): the three
+    eigenvalues AND the Shoemake triple that encodes the eigenvector frame, on tests/golden/eigen.npz -- random matrices
+    over six orders of magnitude plus the degenerate, diagonal, tiny and huge cases.  The triple is decoded with the
+    reference's formulas and checked three ways: the frame is orthonormal; it diagonalises the matrix
+    (V^T diag(lambda) V = M within 1e-5 of the matrix's scale -- this also pins the arbitrary frames of degenerate
+    matrices); and where the eigenvalues are well separated every eigenvector equals the reference's up to sign."""
+    g = golden("eigen")
+    mats = g["mats"]
+    full = np.zeros((len(mats), 3, 3), np.float64)
+    for (a, b), k in {(0, 0): 0, (1, 1): 1, (2, 2): 2, (0, 1): 3, (1, 2): 4, (0, 2): 5}.items():
+        full[:, a, b] = full[:, b, a] = mats[:, k]
+    scale = np.max(np.abs(mats), axis=1).astype(np.float64) + 1e-300
+    for oname, order in (("inc", 0), ("dec", 1)):
+        d = ctx.diagonalize(mats, order)
+        ref = g["diag_" + oname]
+        assert np.all(np.isfinite(d)), "non-finite output"
+        vecs, rvecs = _shoemake_frame(d[:, 3:6]), _shoemake_frame(ref[:, 3:6])     # rows of vecs[i] = eigenvectors
+        V = vecs.astype(np.float64)
+        eye = np.einsum("nij,nkj->nik", V, V)
+        assert np.max(np.abs(eye - np.eye(3))) <= 2e-6, "frame not orthonormal: %g" % np.max(np.abs(eye - np.eye(3)))
+        assert np.all(np.linalg.det(V) > 0.99), "frame is not a proper rotation (eigen3_simple.hpp:316-319)"
+        recon = np.einsum("nki,nk,nkj->nij", V, d[:, :3].astype(np.float64), V)
+        err = np.max(np.abs(recon - full), axis=(1, 2)) / scale
+        assert np.max(err) <= 1e-5, "V^T diag(lambda) V != M: rel err %g at case %d" % (np.max(err), int(np.argmax(err)))
+        # well-separated spectra: the reference's own eigenvectors, up to sign
+        lam = np.sort(ref[:, :3].astype(np.float64), axis=1)
+        gap = np.minimum(lam[:, 1] - lam[:, 0], lam[:, 2] - lam[:, 1]) / scale
+        sep = gap > 1e-2
+        assert sep.sum() > 3000
+        dots = np.abs(np.einsum("nij,nij->ni", V[sep], rvecs[sep].astype(np.float64)))
+        assert np.min(dots) >= 1.0 - 1e-6, "eigenvector differs from the reference's: |cos| = %.9f" % np.min(dots)
+        # exactly degenerate inputs (multiples of the identity, the zero matrix): the reference returns the identity frame
+        for i in range(len(mats)):
+            if mats[i, 0] == mats[i, 1] == mats[i, 2] and not np.any(mats[i, 3:]):
+                assert np.max(np.abs(np.abs(V[i]) - np.eye(3))) <= 1e-6, "frame of a multiple of the identity (case %d)" % i
+                assert_close_rel(d[i, :3], ref[i, :3], 1e-6, "eigenvalues of a multiple of the identity")
+
+
+def test_gauss_512_cubed_crops_equal_oracle(ctx, oracle):
+    """BASELINE config 2 at its own size: the separable Gaussian (sigma 2, h = 5) on a synthetic 512^3 volume, single
+    sweep == three passes bit for bit, crops at corners / faces / interior equal to the oracle on crop + halo, and the
+    tolerance kernel within 1e-5."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 512
+    g = torch.Generator(device=dev).manual_seed(512)
+    src = torch.randn((n, n, n), device=dev, generator=g) * 100 + 1000
+    sigma, h = (2.0,) * 3, 5
+    dst = torch.empty_like(src)
+    torch.cuda.synchronize()
+    ctx.gauss_dev(src, dst, sigma, (h, h, h))
+    ctx.synchronize()
+    fused = dst.clone()
+    torch.cuda.synchronize()
+    with ctx.options(gauss_3pass=1):
+        ctx.gauss_dev(src, dst, sigma, (h, h, h))
+    ctx.synchronize()
+    assert torch.equal(fused, dst), "single sweep != three passes at 512^3"
+    with ctx.options(gauss_fma=1):
+        ctx.gauss_dev(src, dst, sigma, (h, h, h))
+    ctx.synchronize()
+    assert float((dst - fused).abs().max()) <= 1e-5 * float(fused.abs().max()), "tolerance kernel at 512^3"
+    assert not torch.equal(dst, fused)
+    got = torch.empty_like(src)
+    ctx.gauss_dev(src, got, sigma, (h, h, h), None, False)
+    ctx.synchronize()
+    E = 24
+    for (z0, y0, x0) in [(0, 0, 0), (n - E, n - E, n - E), (250, 0, 488), (100, 300, 200), (n - E, 17, 256)]:
+        lo = [max(0, z0 - h), max(0, y0 - h), max(0, x0 - h)]
+        hi = [min(n, z0 + E + h), min(n, y0 + E + h), min(n, x0 + E + h)]
+        sub = src[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]].cpu().numpy().copy()
+        want, _ = oracle.gauss_hw(sub, sigma, (h, h, h), None, False)
+        a = got[z0:z0 + E, y0:y0 + E, x0:x0 + E].cpu().numpy()
+        b = want[z0 - lo[0]:z0 - lo[0] + E, y0 - lo[1]:y0 - lo[1] + E, x0 - lo[2]:x0 - lo[2] + E]
+        assert_bits_equal(a, b, "crop at %s" % ((z0, y0, x0),))
+
+
+def _same_float_field(a, b, what):
+    """bitwise equal, except that any NaN equals any NaN (payloads are not part of the contract)"""
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    na, nb = np.isnan(a), np.isnan(b)
+    assert np.array_equal(na, nb), "%s: NaN patterns differ (%d vs %d NaNs)" % (what, na.sum(), nb.sum())
+    ok = na | (a.view(np.uint32) == b.view(np.uint32))
+    assert ok.all(), "%s: %d values differ; first at %s: %r vs %r" % (what, (~ok).sum(), tuple(np.argwhere(~ok)[0]),
+                                                                      a[tuple(np.argwhere(~ok)[0])], b[tuple(np.argwhere(~ok)[0])])
+
+
+@pytest.mark.parametrize("h", [2, 5, 7, 9])
+def test_gauss_non_finite_and_sparse_inputs(ctx, oracle, h):
+    """NaN / +-Inf voxels and long runs of zeros (the reference's sparse shortcut, filter1d.hpp:59-94, which forces +0.0
+    where every sample under the window is zero and otherwise sums NaN/Inf terms like any other): the GPU filters --
+    single sweep (h <= 8), three passes (h = 9 and gauss_3pass), masked, DoG/LoG -- reproduce the reference's field, NaN
+    for NaN and bit for bit elsewhere."""
+    rng = np.random.default_rng(100 + h)
+    shape = (30, 37, 52)
+    src = (rng.standard_normal(shape) * 100 + 1000).astype(np.float32)
+    src[:, :, 20:45] = 0.0                       # a slab of zeros wider than any window
+    src[10:25, 5:30, :] *= (rng.random((15, 25, 52)) < 0.1)      # sparse region
+    src[3, 4, 5] = np.nan
+    src[20, 30, 40] = np.inf                     # inside the zero slab: Inf * tap next to 0 * tap
+    src[12, 12, 12] = -np.inf
+    src[29, 36, 51] = np.nan                     # a corner
+    src[15, 18, 30] = -0.0
+    sigma = (h / 2.6,) * 3
+    mask = volgen.block_mask(shape, seed=9)
+    for opts in ({}, {"gauss_3pass": 1}):
+        with ctx.options(**opts):
+            for m, norm in ((None, True), (None, False), (mask, True), (mask, False)):
+                want, _ = oracle.gauss_hw(src, sigma, (h, h, h), m, norm)
+                got, _ = ctx.gauss_hw(src, sigma, (h, h, h), m, norm)
+                _same_float_field(got, want, "gaussian h=%d mask=%s normalize=%s %s" % (h, m is not None, norm, opts))
+    r = oracle.ratio_from_threshold(0.03)
+    s3 = (h / 2.7,) * 3
+    _same_float_field(ctx.log(src, s3, 0.02, r)[0], oracle.log(src, s3, 0.02, r)[0], "LoG h=%d" % h)
+    _same_float_field(ctx.log(src, s3, 0.02, r, mask)[0], oracle.log(src, s3, 0.02, r, mask)[0], "masked LoG h=%d" % h)
+
+
+def test_blob_detection_with_non_finite_voxels(ctx, oracle):
+    """A NaN voxel poisons the LoG values within a window of it; every comparison with a NaN is false in the reference's
+    scan (feature.hpp:245-304), which keeps or drops candidates accordingly: same lists from the GPU."""
+    rng = np.random.default_rng(4)
+    src = (rng.standard_normal((36, 40, 44)) * 100 + 1000).astype(np.float32)
+    src[18, 20, 22] = np.nan
+    src[5, 35, 40] = np.inf
+    sig = np.array([1.2, 1.5, 1.9, 2.4], np.float32)
+    r = oracle.ratio_from_threshold(0.03)
+    b = ctx.blob_dog(src, sig, None, None, 0.02, r)
+    bo = oracle.blob_dog(src, sig, None, None, 0.02, r)
+    for x, y, asc in ((b[0], bo[0], True), (b[1], bo[1], False)):
+        fin_x, fin_y = x[np.isfinite(x[:, 4])], y[np.isfinite(y[:, 4])]
+        assert_bits_equal(volgen.sort_blobs(fin_x, asc), volgen.sort_blobs(fin_y, asc), "blob lists next to NaN/Inf voxels")
+        assert len(x) == len(y), "number of blobs with non-finite scores: %d vs %d" % (len(x) - len(fin_x), len(y) - len(fin_y))
+
+
 def test_saliency_direction_threshold(ctx, oracle):
     g = golden("membrane_seeded")
     for tag, m in (("nomask", None), ("mask", volgen.block_mask(volgen.MEM_SHAPE, seed=302))):
