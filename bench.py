@@ -232,7 +232,12 @@ def main():
     sig = pipeline.cli_blob_sigmas(*BLOB)
     sigma_tv = float(np.float32(MEMBRANE["tv_sigma_ratio"]) * np.float32(MEMBRANE["sigma"]))
     h_tv = int(math.floor(np.float32(sigma_tv) * np.float32(math.sqrt(2.0))))
-    layout = slab.SlabLayout(NZ * world, rank, world, ghost=max(h_tv, 12))
+    # world > 1: the library's own slab handle (csrc/slab.hip behind the C ABI: RCCL halos on a transfer stream, overlapped
+    # interior votes, device-side histogram all-reduce); it doubles as the layout object
+    if world > 1:
+        layout = slab.make_slab(ctx, rank, world, NZ * world, max(h_tv, 12))
+    else:
+        layout = slab.SlabLayout(NZ, 0, 1, ghost=max(h_tv, 12))
     shape = (layout.nz_local, S, S)
 
     src = torch.empty(shape, device=device, dtype=torch.float32)
@@ -515,7 +520,8 @@ def main():
                                     "1e-5 of the field's scale, tests/test_tolerance_modes.py); every LoG, the non-max scan and "
                                     "the radix select stay bit-exact.  exact: bit-exact kernels everywhere",
                        "per_gpu_voxels": nvox_rank, "decomposition": "z-slabs, ghost %d" % layout.ghost,
-                       "halo_transport": "none" if world == 1 else ("rccl" if own_gpu else "gloo-staged (shared GPU rehearsal)")},
+                       "halo_transport": "none" if world == 1 else ("rccl (library-owned communicator, csrc/slab.hip)" if own_gpu
+                                                                    else "gloo-staged callbacks (shared GPU rehearsal)")},
             "stages_ms": headline["stages_ms"],
             "results": headline["results"],
             "modes": {args.mode: headline, other_mode: other},

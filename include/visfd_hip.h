@@ -444,6 +444,57 @@ int visfd_hip_apply_gauss_slab_dev(visfd_hip_ctx*, const float* src, float* dst,
                                    int64_t nz_global, const float sigma[3], const int halfwidth[3],
                                    int normalize, float* A_out);
 
+/* ---- e: Z-slab runs across the GPUs of one node ------------------------------------------------------
+ * The reference is single-process (OpenMP only): there is no reference interface to cite here.  These entry points are
+ * what a host started once per GPU calls so that a volume larger than one GPU's HBM -- or simply more throughput -- runs on
+ * the GPUs of a node: planes [z0, z1) of the volume per rank plus `ghost` planes on each INTERIOR face, halos exchanged
+ * point-to-point with the two Z-neighbours only (RCCL send/recv over one xGMI link each, on a transfer stream of the
+ * slab's own, overlapping the votes of the interior planes), three all-reduces of 2048 counters for the exact global
+ * top-fraction threshold.  Outputs of owned planes are bit-identical to the single-volume run (exact kernels).
+ * Volumes are DEVICE pointers of the local shape [nz_local][ny][nx]; everything is queued on the context's stream. */
+typedef struct visfd_hip_slab visfd_hip_slab;
+/* A transport other than RCCL (tests; MPI hosts).  Pointers are DEVICE pointers; work must be ordered on `stream`
+ * (a hipStream_t) or complete on return.  Every callback returns 0 on success. */
+typedef struct visfd_hip_transport {
+  /* send `bytes` from sendbuf to rank `peer` and receive as many from it into recvbuf (a paired exchange) */
+  int (*sendrecv)(void* user, int peer, const void* sendbuf, void* recvbuf, size_t bytes, void* stream);
+  /* sum `count` uint64 counters over all ranks, in place */
+  int (*allreduce_sum_u64)(void* user, uint64_t* buf, size_t count, void* stream);
+  int (*group_start)(void* user);   /* optional (may be NULL): brackets the sendrecv calls of one halo exchange */
+  int (*group_end)(void* user);
+  void* user;
+} visfd_hip_transport;
+/* RCCL: rank 0 obtains a 128-byte id (ncclGetUniqueId), the host hands it to every rank by its own means (a file, MPI,
+ * torch.distributed ...), every rank creates its slab with it (ncclCommInitRank).  librccl.so is loaded at run time. */
+int visfd_hip_slab_unique_id(void* id_out_128_bytes);
+int visfd_hip_slab_create_rccl(visfd_hip_ctx*, const void* unique_id_128_bytes, int rank, int world, int64_t nz_global,
+                               int ghost, visfd_hip_slab** out);
+int visfd_hip_slab_create_custom(visfd_hip_ctx*, const visfd_hip_transport*, int rank, int world, int64_t nz_global,
+                                 int ghost, visfd_hip_slab** out);
+int visfd_hip_slab_destroy(visfd_hip_slab*);
+/* out = {z0, z1, lo, hi, own0, own1, nz_local}: owned planes [z0, z1) and stored planes [lo, hi) of the volume; the owned
+ * planes are [own0, own1) of the local array */
+int visfd_hip_slab_layout(visfd_hip_slab*, int64_t out[7]);
+/* workgroup slots the voting grid leaves free for the transport's kernels while a halo is in flight (default 64) */
+int visfd_hip_slab_set_reserve(visfd_hip_slab*, int reserve_workgroups);
+/* fill the ghost planes of `nvol` volumes within `depth` planes of the owned range (one group of sends/receives) */
+int visfd_hip_slab_exchange_dev(visfd_hip_slab*, float* const* volumes, int nvol, int64_t nx, int64_t ny, int depth);
+/* HandleTV (bin/filter_mrc/handlers.cpp:1501-1892) on one slab: ridge scores, GLOBAL top-fraction threshold, directions,
+ * halo of (saliency, direction), votes (interior planes beside the transfer), post-vote score.  dirs: 3 planar channels,
+ * tensor: 6, scratch: one volume.  Valid results: the owned planes of sal and tensor.  src_halo_ready != 0: the caller has
+ * already exchanged src's ghost planes at least floor(sigma * ratio) + 1 deep in this step. */
+int visfd_hip_membrane_detect_slab_dev(visfd_hip_slab*, float* src, float* sal, float* dirs, float* tensor, float* scratch,
+                                       int64_t nx, int64_t ny, float sigma, float truncate_ratio, int eival_order,
+                                       float best_fraction, float sigma_tv, int exponent, float tv_truncate_ratio,
+                                       int src_halo_ready, float* threshold_out);
+/* BlobDog (lib/visfd/feature.hpp:53-427) on one slab with absolute thresholds: blobs of the OWNED planes only, iz as
+ * GLOBAL plane index.  The host merges the ranks' lists (and applies ratio thresholds, which need the global best). */
+int visfd_hip_blob_dog_slab_dev(visfd_hip_slab*, float* src, int64_t nx, int64_t ny, const float* blob_sigma, int n_sigma,
+                                float delta_sigma_over_sigma, float truncate_ratio, float minima_threshold,
+                                float maxima_threshold, int src_halo_ready,
+                                visfd_hip_blob* minima, int64_t minima_capacity, int64_t* n_minima,
+                                visfd_hip_blob* maxima, int64_t maxima_capacity, int64_t* n_maxima);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,13 +20,21 @@ def _free_port():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3])
-def test_slab_pipeline_on_gpu_equals_single_volume(world):
+@pytest.mark.parametrize("world,path", [(2, "c-abi"), (3, "c-abi"), (2, "python")])
+def test_slab_pipeline_on_gpu_equals_single_volume(world, path):
+    """c-abi: the slab entry points of csrc/slab.hip (visfd_hip_membrane_detect_slab_dev, visfd_hip_blob_dog_slab_dev) --
+    halo groups on the transfer stream, the global radix select with all-reduced histograms, overlapped interior votes --
+    driven through the callback transport (the ranks share this box's one GPU, so RCCL itself cannot run here);
+    python: the torch.distributed orchestration of visfd_amd/slab.py over the same kernels."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "tools", "slab_check.py")]
-    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "SLAB-OK world=%d" % world in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
+    env = dict(os.environ)
+    if path == "python":
+        env["SLAB_PY"] = "1"
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "SLAB-OK world=%d" % world in r.stdout and "path=%s" % path in r.stdout, \
+        (r.stdout[-3000:], r.stderr[-3000:])
 
 
 @pytest.mark.gpu

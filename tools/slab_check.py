@@ -41,24 +41,31 @@ def main():
     ctx = api.Context(dev_index, stream.cuda_stream)
     full = torch.from_numpy(volgen.membrane_volume(shape, seed=55))
 
-    L = slab.SlabLayout(shape[0], rank, world, ghost=ghost)
+    # the library's own slab handle: the C entry points of csrc/slab.hip (RCCL with one GPU per rank, torch-backed
+    # callbacks when the ranks share a card); SLAB_PY=1 keeps the Python orchestration of visfd_amd/slab.py instead
+    if os.environ.get("SLAB_PY"):
+        L = slab.SlabLayout(shape[0], rank, world, ghost=ghost)
+    else:
+        L = slab.make_slab(ctx, rank, world, shape[0], ghost)
     lshape = (L.nz_local,) + tuple(shape[1:])
     src = torch.full(lshape, float("nan"), device=dev)      # ghosts must come from the exchange
     L.owned(src).copy_(full[L.z0:L.z1])
     sal = torch.zeros(lshape, device=dev)
     dirs = torch.zeros((3,) + lshape, device=dev)
     ten = torch.zeros((6,) + lshape, device=dev)
-    # a context on a stream of its own would race with torch's halo copies: the slab functions must refuse it
-    other = api.Context(dev_index)
-    try:
-        slab.membrane_detect_slab(other, L, src, sal, dirs, ten, sigma, tv_ratio, 4, fraction)
-        refused = False
-    except RuntimeError as e:
-        refused = "current stream" in str(e)
-    other.close()
-    if not refused:
-        print("SLAB-MISMATCH: a context on its own stream was accepted", flush=True)
-        sys.exit(1)
+    if os.environ.get("SLAB_PY"):
+        # Python orchestration: a context on a stream of its own would race with torch's halo copies -- must be refused
+        # (the C path orders its transfer stream against the context's stream itself)
+        other = api.Context(dev_index)
+        try:
+            slab.membrane_detect_slab(other, L, src, sal, dirs, ten, sigma, tv_ratio, 4, fraction)
+            refused = False
+        except RuntimeError as e:
+            refused = "current stream" in str(e)
+        other.close()
+        if not refused:
+            print("SLAB-MISMATCH: a context on its own stream was accepted", flush=True)
+            sys.exit(1)
     thr = slab.membrane_detect_slab(ctx, L, src, sal, dirs, ten, sigma, tv_ratio, 4, fraction)
     src2 = torch.full(lshape, float("nan"), device=dev)
     L.owned(src2).copy_(full[L.z0:L.z1])
@@ -95,8 +102,9 @@ def main():
                 if a.shape != b.shape or not np.array_equal(a.view(np.uint32), b.view(np.uint32)):
                     bad.append("%s differ (%d vs %d)" % (name, len(a), len(b)))
         if not bad:
-            print("SLAB-OK world=%d backend=%s minima=%d maxima=%d thr=%.6g" %
-                  (world, dist.get_backend(), len(fmins), len(fmaxs), fthr), flush=True)
+            print("SLAB-OK world=%d backend=%s path=%s minima=%d maxima=%d thr=%.6g" %
+                  (world, dist.get_backend(), "python" if os.environ.get("SLAB_PY") else "c-abi", len(fmins), len(fmaxs), fthr),
+                  flush=True)
         else:
             print("SLAB-MISMATCH: " + "; ".join(bad), flush=True)
     flag = [bool(bad)]

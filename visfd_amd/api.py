@@ -11,6 +11,7 @@ context fails when no GPU is present.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -126,7 +127,28 @@ _SIGS = {
     "visfd_hip_discard_masked_blobs": (C.c_int, [_fp, _fp, _fp, C.POINTER(_i64), _vp, _i64, _i64, _i64]),
     "visfd_hip_discard_overlapping_blobs": (C.c_int, [_fp, _fp, _fp, C.POINTER(_i64), C.c_float, C.c_float,
                                                      C.c_float, C.c_int, C.c_int]),
+    # Z-slab runs (csrc/slab.hip)
+    "visfd_hip_slab_unique_id": (C.c_int, [_vp]),
+    "visfd_hip_slab_create_rccl": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _i64, C.c_int, C.POINTER(_vp)]),
+    "visfd_hip_slab_create_custom": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _i64, C.c_int, C.POINTER(_vp)]),
+    "visfd_hip_slab_destroy": (C.c_int, [_vp]),
+    "visfd_hip_slab_layout": (C.c_int, [_vp, C.POINTER(_i64)]),
+    "visfd_hip_slab_set_reserve": (C.c_int, [_vp, C.c_int]),
+    "visfd_hip_slab_exchange_dev": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, _i64, _i64, C.c_int]),
+    "visfd_hip_membrane_detect_slab_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, C.c_float, C.c_float, C.c_int,
+                                                     C.c_float, C.c_float, C.c_int, C.c_float, C.c_int, _fp]),
+    "visfd_hip_blob_dog_slab_dev": (C.c_int, [_vp, _vp, _i64, _i64, _fp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                                              C.c_int, _vp, _i64, C.POINTER(_i64), _vp, _i64, C.POINTER(_i64)]),
 }
+
+_SENDRECV = C.CFUNCTYPE(C.c_int, _vp, C.c_int, _vp, _vp, C.c_size_t, _vp)
+_ALLREDUCE = C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_size_t, _vp)
+_GROUP = C.CFUNCTYPE(C.c_int, _vp)
+
+
+class Transport(C.Structure):   # visfd_hip_transport
+    _fields_ = [("sendrecv", _SENDRECV), ("allreduce_sum_u64", _ALLREDUCE), ("group_start", _GROUP), ("group_end", _GROUP),
+                ("user", _vp)]
 
 _lib = None
 
@@ -720,3 +742,158 @@ class Context:
     def tensor_saliency_dev(self, tensor, sal, order, mask=None):
         self._chk(self._L.visfd_hip_tensor_saliency_dev(self._h, _dev(tensor), _dev(mask), sal.numel(), int(order),
                                                         _dev(sal)))
+
+
+class Slab:
+    """One rank's handle of a Z-slab run (include/visfd_hip.h, section e; csrc/slab.hip): the layout, the transport and the
+    slab forms of the stages.  `transport`:
+      "rccl"   -- the library's own RCCL communicator (librccl.so loaded at run time): grouped send/recv with the two
+                  Z-neighbours on the slab's transfer stream, all-reduces on the context's stream.  The 128-byte id is
+                  made on rank 0 and broadcast here through torch.distributed (any backend);
+      "torch"  -- callbacks into torch.distributed (host-staged copies): for backends without device point-to-point (gloo:
+                  CPU tests, ranks sharing one GPU in a rehearsal).  The same C code drives both."""
+
+    def __init__(self, ctx, rank, world, nz_global, ghost, transport="rccl", group=None):
+        import torch
+        import torch.distributed as dist
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        self._L = load_library()
+        self._h = _vp()
+        self._keep = None
+        if transport == "rccl" or world == 1:
+            idbuf = (C.c_char * 128)()
+            if world > 1:
+                if rank == 0:
+                    ctx._chk(self._L.visfd_hip_slab_unique_id(C.addressof(idbuf)))
+                box = [bytes(idbuf)]
+                dist.broadcast_object_list(box, src=0, group=group)
+                idbuf = (C.c_char * 128).from_buffer_copy(box[0])
+            ctx._chk(self._L.visfd_hip_slab_create_rccl(ctx._h, C.addressof(idbuf), rank, world, nz_global, ghost, C.byref(self._h)))
+        elif transport == "torch":
+            def sync(stream):
+                torch.cuda.ExternalStream(int(stream)).synchronize() if stream else torch.cuda.synchronize()
+
+            def view(ptr, nbytes, dtype):
+                itemsize = torch.empty((), dtype=dtype).element_size()
+                return _device_view(torch, int(ptr), nbytes // itemsize, dtype)
+            pending = []
+
+            def sendrecv(user, peer, sendbuf, recvbuf, nbytes, stream):
+                try:
+                    sync(stream)
+                    snd = view(sendbuf, nbytes, torch.float32).cpu()
+                    rcv = torch.empty_like(snd)
+                    pending.append((peer, snd, rcv, recvbuf, nbytes))
+                    return 0
+                except Exception as e:   # an exception must not cross the C frame
+                    sys.stderr.write("visfd_amd.Slab transport: %r\n" % (e,))
+                    return 1
+
+            def group_end(user):
+                try:
+                    ops = []
+                    for peer, snd, rcv, _, _ in pending:
+                        ops.append(dist.P2POp(dist.isend, snd, peer, group))
+                        ops.append(dist.P2POp(dist.irecv, rcv, peer, group))
+                    for r in dist.batch_isend_irecv(ops):
+                        r.wait()
+                    for peer, snd, rcv, recvbuf, nbytes in pending:
+                        view(recvbuf, nbytes, torch.float32).copy_(rcv)
+                    torch.cuda.synchronize()
+                    del pending[:]
+                    return 0
+                except Exception as e:
+                    sys.stderr.write("visfd_amd.Slab transport: %r\n" % (e,))
+                    return 1
+
+            def allreduce(user, buf, count, stream):
+                try:
+                    sync(stream)
+                    dv = view(buf, count * 8, torch.int64)
+                    h = dv.cpu()
+                    dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+                    dv.copy_(h)
+                    torch.cuda.synchronize()
+                    return 0
+                except Exception as e:
+                    sys.stderr.write("visfd_amd.Slab transport: %r\n" % (e,))
+                    return 1
+            tr = Transport(_SENDRECV(sendrecv), _ALLREDUCE(allreduce), _GROUP(lambda user: 0), _GROUP(group_end), None)
+            self._keep = tr   # the C side copies the struct; the CFUNCTYPE objects inside must outlive the slab
+            ctx._chk(self._L.visfd_hip_slab_create_custom(ctx._h, C.addressof(tr), rank, world, nz_global, ghost, C.byref(self._h)))
+        else:
+            raise ValueError("transport must be 'rccl' or 'torch'")
+        lay = (_i64 * 7)()
+        ctx._chk(self._L.visfd_hip_slab_layout(self._h, lay))
+        self.z0, self.z1, self.lo, self.hi, self.own0, self.own1, self.nz_local = [int(v) for v in lay]
+        self.nz_global, self.ghost = int(nz_global), int(ghost)
+
+    def close(self):
+        if self._h:
+            self._L.visfd_hip_slab_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def owned(self, t):
+        return t[..., self.own0:self.own1, :, :]
+
+    def set_reserve(self, workgroups):
+        self.ctx._chk(self._L.visfd_hip_slab_set_reserve(self._h, int(workgroups)))
+
+    def exchange(self, tensors, depth):
+        tensors = tensors if isinstance(tensors, (list, tuple)) else [tensors]
+        nz, ny, nx = tensors[0].shape
+        assert nz == self.nz_local
+        arr = (_vp * len(tensors))(*[_dev(t) for t in tensors])
+        self.ctx._chk(self._L.visfd_hip_slab_exchange_dev(self._h, arr, len(tensors), nx, ny, int(depth)))
+
+    def membrane_detect(self, src, sal, dirs, tensor, scratch, sigma, ratio, order, best_fraction, sigma_tv, exponent=4,
+                        cutoff=2.0 ** 0.5, src_halo_ready=False):
+        nz, ny, nx = src.shape
+        assert nz == self.nz_local and dirs.shape[0] == 3 and tensor.shape[0] == 6
+        thr = C.c_float()
+        self.ctx._chk(self._L.visfd_hip_membrane_detect_slab_dev(
+            self._h, _dev(src), _dev(sal), _dev(dirs), _dev(tensor), _dev(scratch), nx, ny, float(sigma), float(ratio), int(order),
+            float(best_fraction), float(sigma_tv), int(exponent), float(cutoff), int(bool(src_halo_ready)), C.byref(thr)))
+        return float(thr.value)
+
+    def blob_dog(self, src, sigmas, delta=0.02, ratio=2.5, minima_threshold=np.inf, maxima_threshold=-np.inf,
+                 src_halo_ready=False, cap=1 << 22):
+        """-> (minima, maxima) rows x, y, z (GLOBAL plane index), sigma, score of the OWNED planes."""
+        nz, ny, nx = src.shape
+        sig = np.ascontiguousarray(sigmas, np.float32)
+        while True:
+            mn, mx = (Blob * cap)(), (Blob * cap)()
+            nmin, nmax = _i64(), _i64()
+            rc = self._L.visfd_hip_blob_dog_slab_dev(self._h, _dev(src), nx, ny, sig.ctypes.data_as(_fp), len(sig), float(delta),
+                                                     float(ratio), float(minima_threshold), float(maxima_threshold),
+                                                     int(bool(src_halo_ready)), C.addressof(mn), cap, C.byref(nmin),
+                                                     C.addressof(mx), cap, C.byref(nmax))
+            if rc == 4:   # VISFD_HIP_ECAPACITY
+                cap = max(int(nmin.value), int(nmax.value)) + 16
+                continue
+            self.ctx._chk(rc)
+            break
+
+        def rows(arr, n):
+            a = np.frombuffer(arr, dtype=np.dtype([("ix", "<i4"), ("iy", "<i4"), ("iz", "<i4"), ("scale", "<i4"),
+                                                   ("sigma", "<f4"), ("score", "<f4")]), count=n)
+            out = np.empty((n, 5), np.float32)
+            out[:, 0], out[:, 1], out[:, 2], out[:, 3], out[:, 4] = a["ix"], a["iy"], a["iz"], a["sigma"], a["score"]
+            return out
+        return rows(mn, int(nmin.value)), rows(mx, int(nmax.value))
+
+
+def _device_view(torch, ptr, count, dtype):
+    """A torch tensor over `count` elements of device memory at `ptr` (the library's buffers inside a transport callback)."""
+    class _Iface:
+        pass
+    typestr = {torch.float32: "<f4", torch.int64: "<i8"}[dtype]
+    obj = _Iface()
+    obj.__cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(obj, device="cuda")

@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(ROOT, "build", "visfd_hip")
 LIB = os.path.join(HERE, "libvisfd_hip.so")
 
-SOURCES = ["host_math.cpp", "blob_post.cpp", "connect.cpp", "api.hip", "gauss.hip", "blob.hip", "ridge.hip", "select.hip", "tv.hip", "resample.hip"]
+SOURCES = ["host_math.cpp", "blob_post.cpp", "connect.cpp", "api.hip", "gauss.hip", "blob.hip", "ridge.hip", "select.hip", "tv.hip", "resample.hip", "slab.hip"]
 # (source, object stem, extra flags): the fused Gaussian is compiled once per window half-width
 # the vote loop is faster without the SLP vectoriser's packed-f32 shuffles (profiles/r01 notes)
 TV_VARIANT = [("tv_tiled.hip", "tv_tiled", ["-fno-slp-vectorize"]), ("tv_pair.hip", "tv_pair", ["-fno-slp-vectorize"])]

@@ -118,6 +118,12 @@ static int pick_bin_descending(const std::vector<uint64_t>& h, uint64_t* k) {
   return -1;
 }
 
+// the host steps of one radix round on an (all-reduced) histogram, for the multi-rank select of slab.hip
+int select_pick_digit(const uint64_t* hist, uint64_t* k) {
+  return pick_bin_descending(std::vector<uint64_t>(hist, hist + NBINS), k);
+}
+float select_key_to_float(uint32_t key) { return key_to_float(key); }
+
 int dev_threshold_fraction(visfd_hip_ctx* ctx, float* sal, const float* mask, i64 nvox, float fraction,
                            float* thr_out) {
   std::vector<uint64_t> h(NBINS);

@@ -53,6 +53,15 @@ class SlabLayout:
         return t[..., self.own0:self.own1, :, :]
 
 
+def make_slab(ctx, rank, world, nz_global, ghost, group=None):
+    """The library's own slab handle (api.Slab -> csrc/slab.hip: halo exchange, global threshold and overlapped voting in
+    C++ behind the C ABI).  Over an RCCL process group ("nccl") the library opens its own RCCL communicator; over any
+    other backend (gloo: CPU-side rehearsals, ranks sharing one GPU) the same C code runs on a torch.distributed-backed
+    transport.  The handle doubles as the layout object of the functions below."""
+    transport = "rccl" if (world == 1 or dist.get_backend(group) == "nccl") else "torch"
+    return api.Slab(ctx, rank, world, nz_global, ghost, transport, group)
+
+
 def check_stream(ops, t):
     """The library's stream must be torch's current stream on t's device (see the module docstring)."""
     if t.is_cuda and hasattr(ops, "stream_handle"):
@@ -113,6 +122,8 @@ class HaloExchange:
 
 def exchange_halos(t, layout, depth, group=None):
     """Fill the ghost planes of `t` (or of every tensor of a list) within `depth` planes of the owned range."""
+    if isinstance(layout, api.Slab):
+        return layout.exchange(t, depth)
     HaloExchange(t if isinstance(t, (list, tuple)) else [t], layout, depth, group).start().wait()
 
 
@@ -176,6 +187,10 @@ def membrane_detect_slab(ops, layout, src, sal, dirs, tensor, sigma, tv_sigma_ra
     ratio = api.ratio_from_threshold(truncate_threshold)
     h_gauss = int(math.floor(np.float32(sigma) * np.float32(ratio)))
     sigma_tv = float(np.float32(tv_sigma_ratio) * np.float32(sigma))
+    if isinstance(L, api.Slab):   # the C-ABI path: everything below happens in csrc/slab.hip
+        smoothed = scratch if scratch is not None else src.new_empty(src.shape)
+        return L.membrane_detect(src, sal, dirs, tensor, smoothed, sigma, ratio, order, best_fraction, sigma_tv, tv_exponent,
+                                 tv_truncate_ratio, src_halo_ready)
     h_tv = int(math.floor(np.float32(sigma_tv) * np.float32(tv_truncate_ratio)))
     assert L.world == 1 or (h_gauss + 1 <= L.ghost and h_tv <= L.ghost), "ghost depth too small"
     check_stream(ops, src)
@@ -266,6 +281,11 @@ def blob_detect_slab(ops, layout, src, sigmas, truncate_threshold=0.03, delta=0.
     smax = float(np.max(sigmas)) * (1.0 + 0.5 * delta)
     depth = int(math.floor(ratio * smax)) + 1
     assert L.world == 1 or depth <= L.ghost, "ghost depth too small for the widest LoG"
+    if isinstance(L, api.Slab) and not use_ratios:   # the C-ABI path (absolute thresholds prune inside the scan)
+        mins, maxs = L.blob_dog(src, sigmas, delta, ratio, minima_threshold, maxima_threshold, src_halo_ready, cap)
+        if L.world > 1:
+            mins, maxs = _all_gather_rows(src, (mins, maxs), group)
+        return mins, maxs
     check_stream(ops, src)
     if not src_halo_ready:
         exchange_halos(src, L, min(L.ghost, depth), group)
