@@ -229,6 +229,8 @@ def both(cli, ref_cli, tmp_path, args, out_name="out.rec"):
     ["-gauss-aniso", 30, 45, 25, "-w", 19.6],
     ["-gauss", 2, "-w", 1, "-mask", os.path.join(GOLDEN, "test_blob_detect_mask.rec")],
     ["-dog", 30, 48, "-w", 19.6],
+    ["-dog-aniso", 30, 40, 25, 48, 60, 44, "-w", 19.6],
+    ["-dog-aniso", 2, 3, 2.5, 3, 4, 3.5, "-w", 1, "-mask", os.path.join(GOLDEN, "test_blob_detect_mask.rec")],
     ["-log-d", 120, "-w", 19.6, "-mask", os.path.join(GOLDEN, "test_blob_detect_mask.rec")],
     ["-gauss", 60, "-w", 19.6, "-bin", 2],
     ["-fluct", 80, "-w", 19.6],
@@ -314,6 +316,8 @@ def test_cli_membrane_and_options_equal_reference_program(cli, ref_cli, tmp_path
     ["-blob-r", "maxima", "b.txt", 40.0, 80.0, 1.25],
     ["-blob-s", "all", "b", 1.0, 2.4, 1.3],                      # scales far below a voxel: both lists empty
     ["-blob", "minima", "b.txt", 60.0, 150.0, 1.2, "-dog-delta", 0.05, "-truncate-threshold", 0.02],
+    ["-blob-s", "all", "b", 20.0, 48.0, 1.3, "-blob-aspect-ratio", 1.0, 1.3, 0.8],
+    ["-blob", "minima", "b.txt", 60.0, 150.0, 1.2, "-blob-aspect-ratio", 1.5, 1.0, 1.0, "-minima-threshold", -10],
 ])
 def test_cli_blob_variants_equal_reference_program(cli, ref_cli, tmp_path, flags):
     """Blob detector spellings (-blob = diameters, -blob-s = sigmas, -blob-r = radii; minima / maxima / all) and
@@ -337,6 +341,7 @@ def test_cli_blob_variants_equal_reference_program(cli, ref_cli, tmp_path, flags
     ["-connect", 5e8, "-connect-vector-saliency", 0.5, "-connect-vector-neighbor", 0.7, "-connect-tensor-saliency", 0.1,
      "-connect-tensor-neighbor", 0.6],
     ["-connect", 2e9],
+    ["-connect-dark", 1e9, "-connect-angle", 30],
 ])
 def test_cli_clustering_options_equal_reference_program(cli, ref_cli, tmp_path, flags):
     """Clustering of the SAME vote tensors (written once by the reference's -save-progress) with different

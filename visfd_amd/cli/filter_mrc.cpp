@@ -148,6 +148,7 @@ struct Settings {
   bool normalize = true;
   // blobs
   vector<float> blob_diameters;
+  float blob_aspect_ratio[3] = {1.0f, 1.0f, 1.0f};            // settings.cpp:134-136, -blob-aspect-ratio
   string blob_min_file, blob_max_file;
   float score_lower = -std::numeric_limits<float>::infinity();
   float score_upper = std::numeric_limits<float>::infinity();
@@ -231,6 +232,18 @@ Settings parse(int argc, char** argv) {
       s.width_b[0] = s.width_b[1] = s.width_b[2] = num(v, i + 2, f);
       s.type = Settings::DOG; i += 3;
     }
+    else if (f == "-dog-aniso") {                                                         // settings.cpp:1275-1305
+      if (i + 6 >= v.size()) throw VisfdErr("Error: The " + f + " argument must be followed by 6 positive numbers.\n");
+      for (int k = 1; k <= 6; k++)
+        if (v[i + k].empty() || v[i + k][0] == '-') throw VisfdErr("Error: The " + f + " argument must be followed by 6 positive numbers.\n");
+      for (int d = 0; d < 3; d++) { s.width_a[d] = num(v, i + 1 + d, f); s.width_b[d] = num(v, i + 4 + d, f); }
+      s.type = Settings::DOG; i += 7;
+    }
+    else if (f == "-blob-aspect-ratio") {                                                 // settings.cpp:1628-1644
+      need(3);
+      for (int d = 0; d < 3; d++) s.blob_aspect_ratio[d] = num(v, i + 1 + d, f);
+      i += 4;
+    }
     else if (f == "-log" || f == "-log-r" || f == "-log-d") {
       need(1);
       float m = 1.0f;
@@ -312,7 +325,9 @@ Settings parse(int argc, char** argv) {
     else if (f == "-detection-threshold") { need(1); s.hessian_thr = num(v, i + 1, f); s.hessian_thr_is_fraction = false; i += 2; }
     else if (f == "-save-progress") { need(1); s.save_base = v[i + 1]; i += 2; }
     else if (f == "-load-progress") { need(1); s.load_base = v[i + 1]; i += 2; }
-    else if (f == "-connect" || f == "-connect-bright" || f == "-connect-saliency") {   // settings.cpp:3036-3052
+    // (-connect-dark differs from -connect only in clusters_begin_at_maxima, settings.cpp:3057-3060, a flag that nothing on
+    //  the membrane path reads: handlers.cpp:1341 is its only use, in the watershed handler)
+    else if (f == "-connect" || f == "-connect-bright" || f == "-connect-saliency" || f == "-connect-dark") {   // settings.cpp:3036-3072
       need(1); s.cluster_connected_voxels = true; s.connect_threshold_saliency = num(v, i + 1, f); i += 2;
     }
     else if (f == "-connect-angle") {                                                    // settings.cpp:3075-3094
@@ -643,7 +658,7 @@ int main(int argc, char** argv) {
     } else if (s.type == Settings::BLOB) {
       vector<std::array<float, 3> > cmin, cmax;
       vector<float> dmin, dmax, smin, smax;
-      BlobDogD(size, tomo_in.a, M, s.blob_diameters, &cmin, &cmax, &dmin, &dmax, &smin, &smax, nullptr, s.delta, ratio,
+      BlobDogD(size, tomo_in.a, M, s.blob_diameters, &cmin, &cmax, &dmin, &dmax, &smin, &smax, s.blob_aspect_ratio, s.delta, ratio,
                s.score_upper, s.score_lower, false, &cerr);
       // physical units + sort by score (handlers.cpp:853-909), ties keep list order
       for (int side = 0; side < 2; side++) {
