@@ -405,7 +405,8 @@ def main():
                                               "separate passes, %s), not in this run" % traffic_file,
                                  note="exact mul+add arithmetic (no FMA) makes this kernel VALU-bound, see DESIGN.md",
                                  tolerance_mode=hbm_obj("gauss_fused_kernel<H=5, FMA> (option gauss_fma: fused multiply-adds, "
-                                                        "reciprocal normaliser; 1e-5 contract)", gf_ms, nv))
+                                                        "reciprocal normaliser; 1e-5 contract)", gf_ms, nv,
+                                                        traffic=offline_traffic("gauss_fma_traffic", shape)[0]))
         with ctx.options(gauss_3pass=1):
             p_ms = timed(lambda: pipeline.gauss(ctx, src, dst, GAUSS_SIGMA), 10) / 3.0
         p_traffic, _ = offline_traffic("gauss_pass_traffic", shape)
@@ -426,7 +427,7 @@ def main():
         # tensor voting, the dominant kernel: a VALU-bound stencil priced against the FP32 vector peak as SURVEY.md 8d asks --
         # 45 flop per evaluated vote (feature.hpp:2312-2377), votes = salient senders x non-zero taps (boundary clipping
         # ignored: < 4 % at this size)
-        tv_traffic, tv_traffic_file = offline_traffic("tv_traffic", shape)
+        tv_traffic_of = {"exact": offline_traffic("tv_traffic", shape), "tolerance": offline_traffic("tv_pair_traffic", shape)}
         for mode, kname, ops_per_vote, note in (
                 ("exact", "tv_tiled_kernel (bit-exact: the reference's 32 multiplies/adds per vote in its order, no FMA)", 32.0,
                  "peak = nominal FP32 vector rate, which counts an FMA as 2 flop; the reference's operation order forbids FMA here, "
@@ -444,10 +445,10 @@ def main():
                 "useful_lane_ops_per_s": round(ops_per_vote * votes / (tv_ms * 1e-3) / 1e12, 2),
                 "valu_issue_peak_lane_ops_per_s": 70.0,
                 "valu_frac_useful": round(ops_per_vote * votes / (tv_ms * 1e-3) / 70e12, 4),
-                "traffic": tv_traffic if mode == "exact" else None, "algorithmic_bytes": 40 * nv,
+                "traffic": tv_traffic_of[mode][0], "algorithmic_bytes": 40 * nv,
                 "hbm_achieved_gbs": round(40.0 * nv / (tv_ms * 1e-3) / 1e9, 1),
                 "hbm_frac": round(40.0 * nv / (tv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "traffic_unit": "bytes per launch, measured OFFLINE (%s), not in this run" % tv_traffic_file, "note": note}
+                "traffic_unit": "bytes per launch, measured OFFLINE (%s), not in this run" % tv_traffic_of[mode][1], "note": note}
         roofline = dict(tv_objs[args.mode])
         roofline["share_of_step"] = round(roofline["ms_per_launch"] / ms_per_step, 3)
         ts_ms = timed(lambda: ctx.tensor_saliency_dev(ten, sal, order), 3)

@@ -17,7 +17,7 @@ import csv, glob, sys
 rows = list(csv.DictReader(open(glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0])))
 groups = {}
 for r in rows:
-    if "gauss_fused_kernel<5" not in r["Kernel_Name"]:
+    if "gauss_fused_kernel<5" not in r["Kernel_Name"]:   # (exact and FMA instantiations together)
         continue
     key = (int(r["Grid_Size_X"]), int(r["Grid_Size_Y"]), int(r["Grid_Size_Z"]))
     groups.setdefault(key, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
@@ -27,10 +27,16 @@ for k, v in sorted(groups.items()):
     print("grid %s: %d launches, mean %.4f  median %.4f  min %.4f  max %.4f" % (k, len(v), sum(v) / len(v), v[len(v) // 2], v[0], v[-1]))
 PY
 rm -rf $out/prof
+# HBM traffic per launch from PMC counters, each counter in a pass of its own (MI355X_MICROARCH.md): the exact and the
+# tolerance form of the Gaussian and of tensor voting
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/g_$c -- python3 tools/pmc_traffic.py $n > $out/g_$c.log 2>&1
+  VISFD_HIP_GAUSS_FMA=1 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/gf_$c -- python3 tools/pmc_traffic.py $n > $out/gf_$c.log 2>&1
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/t_$c -- python3 tools/pmc_tv.py $n synth > $out/t_$c.log 2>&1
+  VISFD_HIP_TV_FMA=1 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/tp_$c -- python3 tools/pmc_tv.py $n synth > $out/tp_$c.log 2>&1
 done
-python3 tools/pmc_traffic_collect.py $out/g_FETCH_SIZE $out/g_WRITE_SIZE gauss_fused_kernel $out/gauss_traffic.json 8 $n "sigma=2 h=5"
-python3 tools/pmc_traffic_collect.py $out/t_FETCH_SIZE $out/t_WRITE_SIZE tv_tiled_kernel $out/tv_traffic.json 40 $n "sigma_tv=8.66 h=12, 5 % salient, bench synthetic volume"
-rm -rf $out/g_FETCH_SIZE $out/g_WRITE_SIZE $out/t_FETCH_SIZE $out/t_WRITE_SIZE
+python3 tools/pmc_traffic_collect.py $out/g_FETCH_SIZE $out/g_WRITE_SIZE gauss_fused_kernel $out/gauss_traffic.json 8 $n "sigma=2 h=5, exact"
+python3 tools/pmc_traffic_collect.py $out/gf_FETCH_SIZE $out/gf_WRITE_SIZE gauss_fused_kernel $out/gauss_fma_traffic.json 8 $n "sigma=2 h=5, tolerance mode (gauss_fma)"
+python3 tools/pmc_traffic_collect.py $out/t_FETCH_SIZE $out/t_WRITE_SIZE tv_tiled_kernel $out/tv_traffic.json 40 $n "sigma_tv=8.66 h=12, 5 % salient, bench synthetic volume, exact kernel"
+python3 tools/pmc_traffic_collect.py $out/tp_FETCH_SIZE $out/tp_WRITE_SIZE tv_pair_kernel $out/tv_pair_traffic.json 40 $n "sigma_tv=8.66 h=12, 5 % salient, bench synthetic volume, tolerance mode (tv_fma)"
+rm -rf $out/g_FETCH_SIZE $out/g_WRITE_SIZE $out/gf_FETCH_SIZE $out/gf_WRITE_SIZE $out/t_FETCH_SIZE $out/t_WRITE_SIZE $out/tp_FETCH_SIZE $out/tp_WRITE_SIZE

@@ -17,8 +17,9 @@ rows = list(csv.DictReader(open(stats)))
 with open(os.path.join(P, "%s_bench_1024_summary.txt" % tag), "w") as f:
     f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu"
             "   (MI355X, 1024^3, %s)\n" % tag)
-    f.write("# 3 pipeline steps + the extra launches of the roofline objects (Gaussian at 1024^3 and 2048^3, single-axis\n"
-            "#   passes, tensor voting) + synthetic-input generation\n")
+    f.write("# 2 timed + 1 warm-up step in the headline (tolerance) mode, 2 + 1 in the other mode, and the extra launches of the\n"
+            "#   roofline objects (device copy, Gaussian exact/FMA at 1024^3 and 2048^3, single-axis passes, ridge kernels, tensor voting\n"
+            "#   in both modes) + synthetic-input generation\n")
     f.write("# gauss_fused_kernel<5,...>: the roofline launches and the pipeline's plain Gaussians are 8 B/voxel launches (the\n"
             "#   roofline object's ms_per_launch); the second Gaussians of LoG scales also read the minuend (12 B/voxel), and\n"
             "#   the 2048^3 launches take 8x as long, so the average over all calls differs from ms_per_launch\n")
@@ -28,6 +29,7 @@ with open(os.path.join(P, "%s_bench_1024_summary.txt" % tag), "w") as f:
                                                      float(r["AverageNs"]) / 1e6, r["Percentage"]))
 for a, b in (("bench.json", "%s_bench_1024.json"), ("bench_under_rocprof.json", "%s_bench_1024_under_rocprof.json"),
              ("gauss_traffic.json", "%s_gauss_traffic.json"), ("tv_traffic.json", "%s_tv_traffic.json"),
+             ("gauss_fma_traffic.json", "%s_gauss_fma_traffic.json"), ("tv_pair_traffic.json", "%s_tv_pair_traffic.json"),
              ("gauss_launches.txt", "%s_bench_1024_gauss_launches.txt"), ("pytest_gpu.log", "%s_pytest_gpu.txt")):
     if os.path.exists(os.path.join(src_dir, a)):
         shutil.copy(os.path.join(src_dir, a), os.path.join(P, b % tag))
