@@ -162,8 +162,8 @@ typedef struct visfd_hip_blob {
  *   maxima_threshold = -inf: no maximum is ever recorded (feature.hpp:286-289: -inf * (-1) = +inf in every thread).
  * ONE FENCE: with BOTH sides infinite in ratio mode the reference keeps, of the minima, the first one each OpenMP
  * thread meets (its result depends on the thread count); this library returns all minima there (and no maxima).
- * Volumes are expected to be finite: NaN/Inf voxels are outside the contract (the reference's sparse-input shortcut,
- * filter1d.hpp:59-94, hides Inf*0 where the plain sums here would produce NaN).
+ * NaN / Inf voxels propagate as in the reference (every comparison with a NaN is false in its scan, feature.hpp:245-304):
+ * same lists (tests/test_gpu_parity.py::test_blob_detection_with_non_finite_voxels).
  * src and mask are HOST pointers in the first form, DEVICE pointers in the _dev form; the blob lists are always host
  * arrays of the given capacities. */
 int visfd_hip_blob_dog(visfd_hip_ctx*, const float* src, const float* mask,
