@@ -29,12 +29,22 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     rf = out["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in rf, key
-    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    # `roofline` describes the DOMINANT kernel of the step (tensor voting: a VALU-bound stencil priced in TFLOP/s against the
+    # FP32 vector peak); the HBM-bound kernel BASELINE.json names is `roofline_gauss`
+    assert rf["bound"] == "valu" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert "tv_pair_kernel" in rf["kernel"] and 0 < rf["share_of_step"] <= 1.0
+    rg = out["roofline_gauss"]
+    assert rg["bound"] == "hbm" and rg["unit"] == "GB/s" and abs(rg["frac"] - rg["achieved"] / rg["peak"]) < 1e-3
+    assert abs(rg["frac_of_copy"] - rg["achieved"] / out["copy_gbs"]) < 1e-3 and rg["tolerance_mode"]["bound"] == "hbm"
+    assert out["config"]["mode"] == "tolerance" and set(out["modes"]) == {"tolerance", "exact"}
+    assert out["modes"]["exact"]["results"]["minima"] == out["modes"]["tolerance"]["results"]["minima"]   # indices: exact in both
+    assert out["modes"]["exact"]["results"]["maxima"] == out["modes"]["tolerance"]["results"]["maxima"]
     cb = out["cpu_baseline"]
-    for key in ("value", "unit", "cores", "kind", "sample"):
+    for key in ("value", "unit", "cores", "kind", "sample", "cpu_model", "omp"):
         assert key in cb, key
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0
-    assert out["roofline_tv"]["bound"] == "valu" and out["roofline_pass"]["bound"] == "hbm"
+    assert set(out["roofline_tv"]) == {"exact", "tolerance"} and out["roofline_tv"]["exact"]["bound"] == "valu"
+    assert out["roofline_pass"]["bound"] == "hbm" and "ridge_score_kernel" in out["roofline_ridge"]
     rp = out["roofline_pipeline"]   # the BASELINE metric's own "% HBM roofline"
     assert rp["algorithmic_bytes_per_voxel"] == 336.0 and set(rp["stages"]) == {"gauss", "blob_dog", "membrane_tv"}
     assert abs(rp["frac"] - rp["achieved"] / rp["peak"]) < 1e-3
