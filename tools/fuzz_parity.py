@@ -23,6 +23,11 @@ def bits_equal(a, b):
     return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
+def close_rel(a, b, rtol=1e-5):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return a.shape == b.shape and float(np.max(np.abs(a - b), initial=0.0)) <= rtol * float(np.max(np.abs(b), initial=0.0)) + 1e-300
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
@@ -32,7 +37,7 @@ def main():
     O = po.load("oracle")
     ctx = api.Context(0)
     t0 = time.time()
-    counts = {"gauss": 0, "log": 0, "blob": 0, "tv": 0, "bin": 0}
+    counts = {"gauss": 0, "log": 0, "blob": 0, "tv": 0, "bin": 0, "gauss_fma": 0, "tv_fma": 0}
     bad = []
     it = 0
     t_report = t0
@@ -61,8 +66,15 @@ def main():
                     hw = tuple(int(v) for v in rng.integers(0, 9, 3))
                     sigma = tuple(float(v) for v in rng.uniform(0.3, 4.0, 3))
                 norm = bool(rng.random() < 0.7)
-                ok = bits_equal(ctx.gauss_hw(src, sigma, hw, mask, norm)[0], O.gauss_hw(src, sigma, hw, mask, norm)[0])
+                want = O.gauss_hw(src, sigma, hw, mask, norm)[0]
+                ok = bits_equal(ctx.gauss_hw(src, sigma, hw, mask, norm)[0], want)
                 desc = "gauss shape=%s hw=%s sigma=%s mask=%s norm=%s" % (shape, hw, sigma, mask is not None, norm)
+                with ctx.options(gauss_fma=1):     # the tolerance mode on the same case (takes effect where it applies)
+                    okf = close_rel(ctx.gauss_hw(src, sigma, hw, mask, norm)[0], want)
+                counts["gauss_fma"] += 1
+                if not okf:
+                    bad.append("gauss_fma " + desc)
+                    print("MISMATCH (tolerance mode):", desc, flush=True)
             elif kind == "log":
                 sigma = (float(rng.uniform(0.5, 3.0)),) * 3
                 ok = bits_equal(ctx.log(src, sigma, 0.02, 2.6482, mask)[0], O.log(src, sigma, 0.02, 2.6482, mask)[0])
@@ -89,8 +101,15 @@ def main():
                         opts["tv_no_replay"] = 1
                 with ctx.options(**opts):
                     got = ctx.tv_dense_stick(sal, d, sigma_tv, ex, 2.0 ** 0.5, mask, mask)
-                ok = bits_equal(got, O.tv_dense_stick(sal, d, sigma_tv, ex, 2.0 ** 0.5, mask, mask))
+                want = O.tv_dense_stick(sal, d, sigma_tv, ex, 2.0 ** 0.5, mask, mask)
+                ok = bits_equal(got, want)
                 desc = "tv shape=%s sigma_tv=%g exponent=%d mask=%s opts=%s" % (shape, sigma_tv, ex, mask is not None, opts)
+                with ctx.options(tv_fma=1, **opts):     # the tolerance kernel on the same case
+                    okf = close_rel(ctx.tv_dense_stick(sal, d, sigma_tv, ex, 2.0 ** 0.5, mask, mask), want)
+                counts["tv_fma"] += 1
+                if not okf:
+                    bad.append("tv_fma " + desc)
+                    print("MISMATCH (tolerance mode):", desc, flush=True)
             else:
                 b = tuple(int(v) for v in rng.integers(1, 5, 3))
                 ds = tuple(max(1, shape[i] // b[i]) for i in range(3))
