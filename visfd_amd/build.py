@@ -18,10 +18,13 @@ CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(ROOT, "build", "visfd_hip")
 LIB = os.path.join(HERE, "libvisfd_hip.so")
 
-SOURCES = ["host_math.cpp", "blob_post.cpp", "connect.cpp", "api.hip", "gauss.hip", "blob.hip", "ridge.hip", "select.hip", "tv.hip", "resample.hip", "slab.hip"]
+SOURCES = ["host_math.cpp", "blob_post.cpp", "connect.cpp", "api.hip", "gauss.hip", "blob.hip", "select.hip", "tv.hip", "resample.hip", "slab.hip"]
 # (source, object stem, extra flags): the fused Gaussian is compiled once per window half-width
 # the vote loop is faster without the SLP vectoriser's packed-f32 shuffles (profiles/r01 notes)
-TV_VARIANT = [("tv_tiled.hip", "tv_tiled", ["-fno-slp-vectorize"]), ("tv_pair.hip", "tv_pair", ["-fno-slp-vectorize"])]
+TV_VARIANT = [("tv_tiled.hip", "tv_tiled", ["-fno-slp-vectorize"]), ("tv_pair.hip", "tv_pair", ["-fno-slp-vectorize"]),
+              # the device eigen solver takes its one angle (atan2, sin, cos) in single precision: eigenvalues move by ~1e-7 of the
+              # matrix's scale, the order of the difference between the device's and glibc's double-precision libm (csrc/eigen3.hpp)
+              ("ridge.hip", "ridge", ["-DVH_EIG_F32_TRIG"])]
 VARIANTS = TV_VARIANT + [("gauss_fused.hip", "gauss_fused_h%d" % h, ["-DVH_FUSED_H=%d" % h, "-fno-slp-vectorize"])
                          for h in range(1, 9)]
 if os.environ.get("VISFD_FUSED_EXTRA_CFGS"):

@@ -109,11 +109,22 @@ VH_HD void eig_sym3(const float m6[6], int order, double lam[3], D3 E[3],
     double q = a_3 * a_3 * a_3 - half_b * half_b;
     q = fmax(q, 0.0);
     const double rho = sqrt(a_3);
-    const double theta = atan2(sqrt(q), half_b) * inv3;
     double st, ct;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(VH_EIG_F32_TRIG)
+    // the angle and its sine / cosine in single precision (the matrix is scaled to max |entry| = 1, so both arguments
+    // are of order one or smaller): the eigenvalues move by ~1e-7 of the matrix's scale, as they already do between the
+    // device's and glibc's double-precision libm; everything around the angle stays in double
+    {
+      const float thf = atan2f(sqrtf((float)q), (float)half_b) * (1.0f / 3.0f);
+      float sf, cf;
+      sincosf(thf, &sf, &cf);
+      st = (double)sf; ct = (double)cf;
+    }
+#elif defined(__HIP_DEVICE_COMPILE__)
+    const double theta = atan2(sqrt(q), half_b) * inv3;
     sincos(theta, &st, &ct);
 #else
+    const double theta = atan2(sqrt(q), half_b) * inv3;
     ct = std::cos(theta); st = std::sin(theta);
 #endif
     lam[0] = c2_3 - rho * (ct + sqrt3 * st);
