@@ -467,14 +467,18 @@ typedef struct visfd_hip_transport {
 /* RCCL: rank 0 obtains a 128-byte id (ncclGetUniqueId), the host hands it to every rank by its own means (a file, MPI,
  * torch.distributed ...), every rank creates its slab with it (ncclCommInitRank).  librccl.so is loaded at run time. */
 int visfd_hip_slab_unique_id(void* id_out_128_bytes);
-int visfd_hip_slab_create_rccl(visfd_hip_ctx*, const void* unique_id_128_bytes, int rank, int world, int64_t nz_global,
-                               int ghost, visfd_hip_slab** out);
+int visfd_hip_slab_create_rccl(visfd_hip_ctx*, const void* unique_id_128_bytes /* may be NULL when world == 1 */, int rank,
+                               int world, int64_t nz_global, int ghost, visfd_hip_slab** out);
 int visfd_hip_slab_create_custom(visfd_hip_ctx*, const visfd_hip_transport*, int rank, int world, int64_t nz_global,
                                  int ghost, visfd_hip_slab** out);
 int visfd_hip_slab_destroy(visfd_hip_slab*);
 /* out = {z0, z1, lo, hi, own0, own1, nz_local}: owned planes [z0, z1) and stored planes [lo, hi) of the volume; the owned
  * planes are [own0, own1) of the local array */
 int visfd_hip_slab_layout(visfd_hip_slab*, int64_t out[7]);
+/* The transport's smoke test: a grouped send/receive of `count` floats from this rank to itself on the transfer stream and
+ * an all-reduce of 2048 counters, both verified.  A slab created with world == 1 AND an id owns a one-rank RCCL communicator:
+ * that is what a one-GPU box can run of the RCCL path (run-time loading, call signatures, stream ordering). */
+int visfd_hip_slab_selftest(visfd_hip_slab*, int64_t count);
 /* workgroup slots the voting grid leaves free for the transport's kernels while a halo is in flight (default 64) */
 int visfd_hip_slab_set_reserve(visfd_hip_slab*, int reserve_workgroups);
 /* fill the ghost planes of `nvol` volumes within `depth` planes of the owned range (one group of sends/receives) */

@@ -52,3 +52,20 @@ def test_bench_launches_its_own_ranks():
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["per_gpu_voxels"] == 96 ** 3
     assert abs(out["value"] - 2 * 96 ** 3 / (out["ms_per_step"] * 1e-3) / 1e6) <= 1e-3 * out["value"]
+
+
+@pytest.mark.gpu
+def test_rccl_transport_loopback():
+    """What a one-GPU box can run of the RCCL path of csrc/slab.hip: librccl.so loaded at run time, a one-rank communicator
+    (ncclGetUniqueId / ncclCommInitRank), a grouped ncclSend + ncclRecv of 4 MiB to itself on the slab's transfer stream
+    ordered against the context's stream by events, and an ncclAllReduce(uint64, sum) of the 2048 histogram counters --
+    both verified on the host.  (Run in a child process: RCCL initialises its own state.)"""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from visfd_amd import api\n"
+            "ctx = api.Context(0)\n"
+            "s = api.Slab(ctx, 0, 1, 64, 12, transport='rccl_loopback')\n"
+            "s.selftest(1 << 20)\n"
+            "assert (s.z0, s.z1, s.nz_local) == (0, 64, 64)\n"
+            "s.close(); ctx.close(); print('RCCL-LOOPBACK-OK')\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL-LOOPBACK-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

@@ -134,6 +134,7 @@ _SIGS = {
     "visfd_hip_slab_destroy": (C.c_int, [_vp]),
     "visfd_hip_slab_layout": (C.c_int, [_vp, C.POINTER(_i64)]),
     "visfd_hip_slab_set_reserve": (C.c_int, [_vp, C.c_int]),
+    "visfd_hip_slab_selftest": (C.c_int, [_vp, _i64]),
     "visfd_hip_slab_exchange_dev": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, _i64, _i64, C.c_int]),
     "visfd_hip_membrane_detect_slab_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, C.c_float, C.c_float, C.c_int,
                                                      C.c_float, C.c_float, C.c_int, C.c_float, C.c_int, _fp]),
@@ -760,7 +761,12 @@ class Slab:
         self._L = load_library()
         self._h = _vp()
         self._keep = None
-        if transport == "rccl" or world == 1:
+        if transport == "rccl_loopback":   # a one-rank RCCL communicator (selftest on a one-GPU box)
+            assert world == 1
+            idbuf = (C.c_char * 128)()
+            ctx._chk(self._L.visfd_hip_slab_unique_id(C.addressof(idbuf)))
+            ctx._chk(self._L.visfd_hip_slab_create_rccl(ctx._h, C.addressof(idbuf), 0, 1, nz_global, ghost, C.byref(self._h)))
+        elif transport == "rccl" or world == 1:
             idbuf = (C.c_char * 128)()
             if world > 1:
                 if rank == 0:
@@ -768,7 +774,8 @@ class Slab:
                 box = [bytes(idbuf)]
                 dist.broadcast_object_list(box, src=0, group=group)
                 idbuf = (C.c_char * 128).from_buffer_copy(box[0])
-            ctx._chk(self._L.visfd_hip_slab_create_rccl(ctx._h, C.addressof(idbuf), rank, world, nz_global, ghost, C.byref(self._h)))
+            ctx._chk(self._L.visfd_hip_slab_create_rccl(ctx._h, C.addressof(idbuf) if world > 1 else None, rank, world, nz_global,
+                                                        ghost, C.byref(self._h)))
         elif transport == "torch":
             def sync(stream):
                 torch.cuda.ExternalStream(int(stream)).synchronize() if stream else torch.cuda.synchronize()
@@ -841,6 +848,10 @@ class Slab:
 
     def owned(self, t):
         return t[..., self.own0:self.own1, :, :]
+
+    def selftest(self, count=1 << 20):
+        """visfd_hip_slab_selftest: self send/receive on the transfer stream + all-reduce, verified (raises on failure)."""
+        self.ctx._chk(self._L.visfd_hip_slab_selftest(self._h, int(count)))
 
     def set_reserve(self, workgroups):
         self.ctx._chk(self._L.visfd_hip_slab_set_reserve(self._h, int(workgroups)))

@@ -237,7 +237,7 @@ int visfd_hip_slab_create_rccl(visfd_hip_ctx* ctx, const void* unique_id, int ra
   VH_REQUIRE(unique_id || world == 1, "null unique id");
   visfd_hip_slab* s = nullptr;
   VH_TRY(slab_common(ctx, rank, world, nz_global, ghost, &s));
-  if (world > 1) {
+  if (world > 1 || unique_id) {   // (world == 1 with an id: a one-rank communicator, for visfd_hip_slab_selftest)
     int rc = load_rccl(&s->rccl);
     if (rc != VISFD_HIP_OK) { visfd_hip_slab_destroy(s); return rc; }
     NcclId id;
@@ -280,6 +280,70 @@ int visfd_hip_slab_destroy(visfd_hip_slab* s) {
 int visfd_hip_slab_layout(visfd_hip_slab* s, int64_t out[7]) {
   VH_REQUIRE(s && out, "null argument");
   out[0] = s->z0; out[1] = s->z1; out[2] = s->lo; out[3] = s->hi; out[4] = s->own0; out[5] = s->own1; out[6] = s->nz_local;
+  return VISFD_HIP_OK;
+}
+
+// The transport's own smoke test: a grouped send/receive of `count` floats from this rank to ITSELF on the transfer stream
+// (RCCL allows self send/recv inside a group) and an all-reduce of 2048 counters on the context's stream, both verified.
+// With one rank per GPU it checks the wiring of every rank; with a one-rank communicator (world == 1 created with an id) it
+// is what a one-GPU box can run of the RCCL path: the run-time loading of librccl.so, the call signatures and enums, the
+// stream/event ordering.
+int visfd_hip_slab_selftest(visfd_hip_slab* s, int64_t count) {
+  VH_REQUIRE(s && count > 0, "bad argument");
+  VH_REQUIRE(s->use_custom || s->comm, "the slab has no communicator (world == 1 created without an id)");
+  visfd_hip_ctx* ctx = s->ctx;
+  VH_HIP(hipSetDevice(ctx->device));
+  float *a = nullptr, *b = nullptr;
+  VH_HIP(hipMalloc(reinterpret_cast<void**>(&a), sizeof(float) * (size_t)count));
+  VH_HIP(hipMalloc(reinterpret_cast<void**>(&b), sizeof(float) * (size_t)count));
+  std::vector<float> h((size_t)count), back((size_t)count, 0.0f);
+  for (int64_t i = 0; i < count; i++) h[(size_t)i] = (float)(i % 977) + 0.25f * (float)s->rank;
+  int rc = VISFD_HIP_OK;
+  auto check = [&](hipError_t e) { if (e != hipSuccess && rc == VISFD_HIP_OK) rc = fail(VISFD_HIP_EDEVICE, hipGetErrorString(e)); };
+  check(hipMemcpyAsync(a, h.data(), sizeof(float) * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
+  check(hipMemsetAsync(b, 0, sizeof(float) * (size_t)count, ctx->stream));
+  check(hipEventRecord(s->ev_ready, ctx->stream));
+  check(hipStreamWaitEvent(s->xfer, s->ev_ready, 0));
+  if (rc == VISFD_HIP_OK) {
+    if (s->use_custom) {
+      if (s->custom.group_start && s->custom.group_start(s->custom.user) != 0) rc = fail(VISFD_HIP_EDEVICE, "transport: group_start failed");
+      if (rc == VISFD_HIP_OK && s->custom.sendrecv(s->custom.user, s->rank, a, b, sizeof(float) * (size_t)count, (void*)s->xfer) != 0)
+        rc = fail(VISFD_HIP_EDEVICE, "transport: sendrecv failed");
+      if (rc == VISFD_HIP_OK && s->custom.group_end && s->custom.group_end(s->custom.user) != 0) rc = fail(VISFD_HIP_EDEVICE, "transport: group_end failed");
+    } else {
+      int r = s->rccl->GroupStart();
+      if (r == 0) r = s->rccl->Send(a, (size_t)count, kNcclFloat, s->rank, s->comm, s->xfer);
+      if (r == 0) r = s->rccl->Recv(b, (size_t)count, kNcclFloat, s->rank, s->comm, s->xfer);
+      const int r2 = s->rccl->GroupEnd();
+      if (r == 0) r = r2;
+      if (r != 0) rc = fail(VISFD_HIP_EDEVICE, std::string("RCCL self send/recv: ") + s->rccl->GetErrorString(r));
+    }
+  }
+  check(hipEventRecord(s->ev_done, s->xfer));
+  check(hipStreamWaitEvent(ctx->stream, s->ev_done, 0));
+  check(hipMemcpyAsync(back.data(), b, sizeof(float) * (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
+  // all-reduce: every rank contributes i + 1 in counter i
+  std::vector<uint64_t> hh(2048), hs(2048);
+  for (int i = 0; i < 2048; i++) hh[(size_t)i] = (uint64_t)i + 1;
+  check(hipMemcpyAsync(s->hist_dev, hh.data(), sizeof(uint64_t) * 2048, hipMemcpyHostToDevice, ctx->stream));
+  if (rc == VISFD_HIP_OK) {
+    if (s->use_custom) {
+      if (s->custom.allreduce_sum_u64(s->custom.user, s->hist_dev, 2048, (void*)ctx->stream) != 0) rc = fail(VISFD_HIP_EDEVICE, "transport: allreduce failed");
+    } else {
+      const int r = s->rccl->AllReduce(s->hist_dev, s->hist_dev, 2048, kNcclUint64, kNcclSum, s->comm, ctx->stream);
+      if (r != 0) rc = fail(VISFD_HIP_EDEVICE, std::string("ncclAllReduce: ") + s->rccl->GetErrorString(r));
+    }
+  }
+  check(hipMemcpyAsync(hs.data(), s->hist_dev, sizeof(uint64_t) * 2048, hipMemcpyDeviceToHost, ctx->stream));
+  check(hipStreamSynchronize(ctx->stream));
+  (void)hipFree(a);
+  (void)hipFree(b);
+  if (rc != VISFD_HIP_OK) return rc;
+  for (int64_t i = 0; i < count; i++)
+    if (back[(size_t)i] != h[(size_t)i]) return fail(VISFD_HIP_EDEVICE, "slab self-test: the self send/receive returned wrong data at element " + std::to_string(i));
+  for (int i = 0; i < 2048; i++)
+    if (hs[(size_t)i] != (uint64_t)s->world * ((uint64_t)i + 1))
+      return fail(VISFD_HIP_EDEVICE, "slab self-test: the all-reduce returned a wrong sum in counter " + std::to_string(i));
   return VISFD_HIP_OK;
 }
 
