@@ -141,19 +141,21 @@ static int tv_table_device(visfd_hip_ctx* ctx, float sigma_tv, float cutoff, int
   VH_HIP(hipStreamSynchronize(ctx->stream));
   std::vector<float> w(m), rh(3 * m);
   host_tv_tables(sigma_tv, h, w.data(), rh.data());
-  // two tables: [0, m) the reference's {w, rhat}; behind it the tolerance mode's {w, sqrt(2) rhat} (tv_pair.hip: vote_fma)
-  // with rows padded to tv_padded_row(h) entries (the pad entries are never read)
+  // three tables: [0, m) the reference's {w, rhat}, packed (baseline kernel); then the same with rows padded to
+  // tv_padded_row(h) entries (tiled kernel: LDS banks); then the tolerance mode's {w, sqrt(2) rhat}, padded as well
+  // (tv_pair.hip: vote_fma).  Pad entries are never read.
   const size_t sp = (size_t)tv_padded_row(h), m2 = n * n * sp;
-  std::vector<float4> tab(m + m2, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+  std::vector<float4> tab(m + 2 * m2, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
   const float rt2 = 1.41421356237309504880f;
   for (size_t k = 0; k < m; k++) {
     tab[k] = make_float4(w[k], rh[3 * k], rh[3 * k + 1], rh[3 * k + 2]);
-    tab[m + (k / n) * sp + (k % n)] = make_float4(w[k], rt2 * rh[3 * k], rt2 * rh[3 * k + 1], rt2 * rh[3 * k + 2]);
+    tab[m + (k / n) * sp + (k % n)] = tab[k];
+    tab[m + m2 + (k / n) * sp + (k % n)] = make_float4(w[k], rt2 * rh[3 * k], rt2 * rh[3 * k + 1], rt2 * rh[3 * k + 2]);
   }
   float4* dtab = nullptr;
   ctx->tv_table_dev = nullptr;
-  VH_TRY(ws(ctx, WS_TVTAB, m + m2, &dtab));
-  VH_HIP(hipMemcpyAsync(dtab, tab.data(), sizeof(float4) * (m + m2), hipMemcpyHostToDevice, ctx->stream));
+  VH_TRY(ws(ctx, WS_TVTAB, m + 2 * m2, &dtab));
+  VH_HIP(hipMemcpyAsync(dtab, tab.data(), sizeof(float4) * (m + 2 * m2), hipMemcpyHostToDevice, ctx->stream));
   VH_HIP(hipStreamSynchronize(ctx->stream));
   ctx->tv_table_dev = reinterpret_cast<float*>(dtab);
   ctx->tv_table_h = h;
@@ -176,15 +178,17 @@ int dev_tv_dense_stick(visfd_hip_ctx* ctx, const float* sal, const float* dir, f
   const float4* dtab = nullptr;
   VH_TRY(tv_table_device(ctx, sigma_tv, cutoff, h, &dtab));
 
+  const size_t m_packed = (size_t)(2 * h + 1) * (2 * h + 1) * (2 * h + 1);
+  const size_t m_padded = (size_t)(2 * h + 1) * (2 * h + 1) * (size_t)tv_padded_row(h);
   bool handled = false;
   // tolerance mode (option tv_fma): fused multiply-adds and mirror-paired sender planes (tv_pair.hip); windows and vote
   // forms it does not take fall through to the exact kernels
   if (!ctx->opt.tv_dense && ctx->opt.tv_fma && !curves)
     VH_TRY(dev_tv_pair(ctx, sal, dir, ten, mask_src, mask_dst, nx, ny, nz, z_out0, z_out1, h,
-                       dtab + (size_t)(2 * h + 1) * (2 * h + 1) * (2 * h + 1), exponent, &handled));
+                       dtab + m_packed + m_padded, exponent, &handled));
   if (handled) return VISFD_HIP_OK;
   if (!ctx->opt.tv_dense)
-    VH_TRY(dev_tv_tiled(ctx, sal, dir, ten, mask_src, mask_dst, nx, ny, nz, z_out0, z_out1, h, dtab, exponent, curves,
+    VH_TRY(dev_tv_tiled(ctx, sal, dir, ten, mask_src, mask_dst, nx, ny, nz, z_out0, z_out1, h, dtab + m_packed, exponent, curves,
                         false, &handled));
   if (handled) return VISFD_HIP_OK;
 
@@ -211,7 +215,8 @@ int dev_tv_weight_sum(visfd_hip_ctx* ctx, const float* sal, float* den, const fl
   const float4* dtab = nullptr;
   VH_TRY(tv_table_device(ctx, sigma_tv, cutoff, h, &dtab));
   bool handled = false;
-  VH_TRY(dev_tv_tiled(ctx, sal, nullptr, den, mask_src, mask_dst, nx, ny, nz, 0, nz, h, dtab, 4, false, true, &handled));
+  VH_TRY(dev_tv_tiled(ctx, sal, nullptr, den, mask_src, mask_dst, nx, ny, nz, 0, nz, h,
+                      dtab + (size_t)(2 * h + 1) * (2 * h + 1) * (2 * h + 1), 4, false, true, &handled));
   if (!handled) return fail(VISFD_HIP_EINVAL, "volume shape not supported by the weight-sum kernel");
   return VISFD_HIP_OK;
 }

@@ -85,6 +85,7 @@ struct TiledParams {
   int exponent, curves;
   int zrun;              // receiver planes per unit of work
   int relist;            // 1: list every sender plane for every receiver plane (option tv_no_replay; tests)
+  int sp;                // row stride of a table slice in float4 entries (>= 2h+1)
 };
 
 __device__ __forceinline__ void acc(float& t, float x) {
@@ -161,7 +162,11 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
   const int lane = tid & 63, wave = tid >> 6;
   const int h = p.h;
   const int S = 2 * h + 1;       // table row length = planes per ring
-  const int nsl = S * S;         // float4 entries per slice
+  // LDS rows of a slice are SP >= S float4 apart and the lanes of a half wave are dealt to its 8 x 4 receivers as two
+  // 4-column blocks, one per 16-lane group of ds_read_b128: 2 instead of 4 LDS cycles per half-wave table read
+  // (tv_pair.hip, tools/lds_bank_model.py; round 3).  Which lane holds which receiver does not touch any receiver's sums.
+  const int SP = p.sp;
+  const int nsl = S * SP;        // float4 entries per slice (the table in global memory has the same padded rows)
   const int R = p.rw * p.rh;     // region positions per plane
   const i64 plane = (i64)p.nx * p.ny;
   const i64 nvox = plane * p.nz;
@@ -196,7 +201,9 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
     // as wide as one wave's reach in x, and list order is row order, so the senders a wave can reach are one
     // contiguous stretch of the list (see the replay below).
     const int half = lane >> 5;                       // 0: receiver plane rz, 1: plane rz + 1
-    const int lx = lane & 7, ly = wave * 4 + ((lane & 31) >> 3);
+    const int l5 = lane & 31;
+    const int lrow = (l5 < 8) ? 0 : (l5 < 16) ? 1 : (l5 < 24) ? 2 : 3;
+    const int lx = (l5 & 3) + (((0xc33cu >> (l5 >> 1)) & 1u) ? 4 : 0), ly = wave * 4 + lrow;
     const int rx = x0 + lx, ry = y0 + ly;
     const bool r_in = rx < p.nx && ry < p.ny;
     // Distance test  |r - e|^2 <= h^2  as ONE dot product per (receiver, sender): with coordinates
@@ -210,7 +217,7 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
     const int recv_c = rpx * rpx + rpy * rpy - h * h - 1;
     constexpr unsigned NEVER_HIT = 0x009c0000u;   // operand whose dot product is positive for every receiver (-128 * -100)
     // (jy+h)*S + (jx+h) with jx = lx+h-ex, jy = ly+h-ey  =  [(ly+2h)*S + lx+2h] - [ey*S + ex]
-    const unsigned r16_0 = lds_addr(slices) + (unsigned)(16 * ((ly + 2 * h) * S + lx + 2 * h));   // in LDS slice slot 0
+    const unsigned r16_0 = lds_addr(slices) + (unsigned)(16 * ((ly + 2 * h) * SP + lx + 2 * h));   // in LDS slice slot 0
     unsigned r16s = r16_0;                                                                        // in this lane's slot
     const unsigned ent_base = lds_addr(l_ent);
 
@@ -288,7 +295,7 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
             *reinterpret_cast<float4*>(dst_e) = a;
             *reinterpret_cast<uint4*>(dst_e + 16) =
                 make_uint4((unsigned)(epx & 0xff) | ((unsigned)(epy & 0xff) << 8), (unsigned)(epx * epx + epy * epy),
-                           (unsigned)(16 * (ey * S + ex)), mv);
+                           (unsigned)(16 * (ey * SP + ex)), mv);
           }
           running += tb;
         }
@@ -465,7 +472,7 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
 
 }  // namespace
 
-// dtab: the vote table on the device (tv.hip: tv_table_device).  weights_only: ten receives ONE plane, the sum of the
+// dtab: the vote table on the device with padded rows (tv.hip: tv_table_device).  weights_only: ten receives ONE plane, the sum of the
 // weights of the votes each receiver takes (the normalisation denominator of feature.hpp:1784-1822) instead of tensors.
 int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* ten,
                  const float* mask_src, const float* mask_dst, i64 nx, i64 ny, i64 nz, i64 z_out0,
@@ -487,7 +494,8 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
   p.rw_magic = ((1 << 20) + p.rw - 1) / p.rw;
   for (int q = 0; q < p.nchunk * NT; q++)   // (<= 9216 positions)
     if ((int)(((unsigned)q * (unsigned)p.rw_magic) >> 20) != q / p.rw) return fail(VISFD_HIP_EINVAL, "tv_tiled: region index division");
-  const size_t slice_bytes = sizeof(float4) * (size_t)n * n;
+  p.sp = tv_padded_row(h);
+  const size_t slice_bytes = sizeof(float4) * (size_t)n * p.sp;
   p.tiles_x = (int)((nx + TX - 1) / TX);
   p.tiles_y = (int)((ny + TY - 1) / TY);
   p.exponent = exponent;
