@@ -143,3 +143,44 @@ def test_gauss_fma_leaves_index_paths_exact(ctx, oracle):
     assert_bits_equal(got, want, "LoG under gauss_fma")
     for x, y, asc in ((b[0], bo[0], True), (b[1], bo[1], False)):
         assert_bits_equal(volgen.sort_blobs(x, asc), volgen.sort_blobs(y, asc), "blob list under gauss_fma")
+
+
+# ------------------------------------------------------------------- vote weight sums (normalisation denominators)
+@pytest.mark.parametrize("sigma_tv,shape", [(3.0, (17, 21, 26)), (8.66, (12, 30, 33)), (30.0, (6, 9, 11))])
+def test_tv_weight_sum_kernels_agree(ctx, oracle, sigma_tv, shape):
+    """visfd_hip_tv_weight_sum (the denominators of TVDenseStick(normalize = true), feature.hpp:1761-1822, 2376-2382): the
+    tiled kernel, the baseline kernel's weights-only form (option tv_dense, and the fallback for windows the tiled kernel
+    declines: h = 42 here) and a direct numpy sum in the reference's order agree bit for bit."""
+    sal, _ = _sparse_field(shape, seed=int(sigma_tv * 7), frac=0.2)
+    mask = volgen.block_mask(shape, seed=5)
+    h, w, _ = oracle.tv_tables(sigma_tv, 2.0 ** 0.5)
+    w = np.asarray(w, np.float32).reshape(2 * h + 1, 2 * h + 1, 2 * h + 1)
+    nz, ny, nx = shape
+    for m in (None, mask):
+        want = np.zeros(shape, np.float32)
+        for iz in range(nz):
+            for iy in range(ny):
+                for ix in range(nx):
+                    if m is not None and m[iz, iy, ix] == 0:
+                        continue
+                    acc = np.float32(0)
+                    for jz in range(max(-h, iz - nz + 1), min(h, iz) + 1):       # sender = receiver - j, in bounds
+                        for jy in range(max(-h, iy - ny + 1), min(h, iy) + 1):
+                            row_s = sal[iz - jz, iy - jy]
+                            row_m = m[iz - jz, iy - jy] if m is not None else None
+                            for jx in range(max(-h, ix - nx + 1), min(h, ix) + 1):
+                                fv = w[jz + h, jy + h, jx + h]
+                                if row_m is not None:
+                                    if row_m[ix - jx] == 0:
+                                        continue
+                                    fv = np.float32(fv * row_m[ix - jx])
+                                if row_s[ix - jx] == 0 or fv == 0:
+                                    continue
+                                acc = np.float32(acc + fv)
+                    want[iz, iy, ix] = acc
+        got = {}
+        for dense in (0, 1):
+            with ctx.options(tv_dense=dense):
+                got[dense] = ctx.tv_weight_sum(sal, sigma_tv, 2.0 ** 0.5, m, m)
+        assert_bits_equal(got[0], got[1], "weight sums: tiled (or its fallback) vs baseline kernel, sigma_tv=%g mask=%s" % (sigma_tv, m is not None))
+        assert_bits_equal(got[1], want, "weight sums vs the direct sum, sigma_tv=%g mask=%s" % (sigma_tv, m is not None))

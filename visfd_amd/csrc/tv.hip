@@ -26,6 +26,7 @@ struct TvParams {
   int h;
   int exponent;
   int curves;
+  int weights_only;      // 1: no tensors -- the sum of the vote weights of every receiver into ONE plane (feature.hpp:2376-2377)
 };
 
 __device__ __forceinline__ float decay_of(float ang, int exponent) {
@@ -107,11 +108,13 @@ tv_dense_kernel(const float* __restrict__ sal, const float* __restrict__ dir,
         const float sv = sal[s];
         if (sv == 0.0f) continue;
         if (fv == 0.0f) continue;
+        if (p.weights_only) { T[0] = T[0] + fv; continue; }     // "denominator += filter_val"
         add_vote(T, sv, fv, t.y, t.z, t.w, dir[s], dir[nvox + s], dir[2 * nvox + s], p.exponent,
                  p.curves);
       }
     }
   }
+  if (p.weights_only) { ten[c] = T[0]; return; }
 #pragma unroll
   for (int k = 0; k < 6; k++) ten[k * nvox + c] = T[k];
 }
@@ -196,7 +199,7 @@ int dev_tv_dense_stick(visfd_hip_ctx* ctx, const float* sal, const float* dir, f
   TvParams p;
   p.nx = (int)nx; p.ny = (int)ny; p.nz = (int)nz;
   p.z_out0 = (int)z_out0; p.z_out1 = (int)z_out1;
-  p.h = h; p.exponent = exponent; p.curves = curves ? 1 : 0;
+  p.h = h; p.exponent = exponent; p.curves = curves ? 1 : 0; p.weights_only = 0;
   const i64 nb = ((nx + BLOCK - 1) / BLOCK) * ny * (z_out1 - z_out0);
   if (nb > 0x7fffffffLL) return fail(VISFD_HIP_EINVAL, "volume too large for one launch");
   tv_dense_kernel<<<dim3((unsigned)nb), dim3(BLOCK), 0, st>>>(sal, dir, ten, mask_src, mask_dst, dtab, p);
@@ -210,14 +213,26 @@ int dev_tv_dense_stick(visfd_hip_ctx* ctx, const float* sal, const float* dir, f
 int dev_tv_weight_sum(visfd_hip_ctx* ctx, const float* sal, float* den, const float* mask_src, const float* mask_dst, i64 nx,
                       i64 ny, i64 nz, float sigma_tv, float cutoff) {
   VH_TRY(check_dims(nx, ny, nz));
+  if (nx >= (1LL << 31) || ny >= (1LL << 31) || nz >= (1LL << 31)) return fail(VISFD_HIP_EINVAL, "dimension too large");
   const int h = host_tv_halfwidth(sigma_tv, cutoff);
-  VH_REQUIRE(h >= 1 && h <= 40, "tensor-voting window halfwidth out of range for the weight sums");
+  VH_REQUIRE(h >= 0 && h <= 255, "tensor-voting window halfwidth out of range");
   const float4* dtab = nullptr;
   VH_TRY(tv_table_device(ctx, sigma_tv, cutoff, h, &dtab));
   bool handled = false;
-  VH_TRY(dev_tv_tiled(ctx, sal, nullptr, den, mask_src, mask_dst, nx, ny, nz, 0, nz, h,
-                      dtab + (size_t)(2 * h + 1) * (2 * h + 1) * (2 * h + 1), 4, false, true, &handled));
-  if (!handled) return fail(VISFD_HIP_EINVAL, "volume shape not supported by the weight-sum kernel");
+  if (!ctx->opt.tv_dense)
+    VH_TRY(dev_tv_tiled(ctx, sal, nullptr, den, mask_src, mask_dst, nx, ny, nz, 0, nz, h,
+                        dtab + (size_t)(2 * h + 1) * (2 * h + 1) * (2 * h + 1), 4, false, true, &handled));
+  if (handled) return VISFD_HIP_OK;
+  // windows the tiled kernel declines (h = 0, h > 40, slices beyond LDS) and the tv_dense option: the baseline kernel in
+  // its weights-only form, same order of accumulation
+  TvParams p;
+  p.nx = (int)nx; p.ny = (int)ny; p.nz = (int)nz;
+  p.z_out0 = 0; p.z_out1 = (int)nz;
+  p.h = h; p.exponent = 4; p.curves = 0; p.weights_only = 1;
+  const i64 nb = ((nx + BLOCK - 1) / BLOCK) * ny * nz;
+  if (nb > 0x7fffffffLL) return fail(VISFD_HIP_EINVAL, "volume too large for one launch");
+  tv_dense_kernel<<<dim3((unsigned)nb), dim3(BLOCK), 0, ctx->stream>>>(sal, nullptr, den, mask_src, mask_dst, dtab, p);
+  VH_HIP(hipGetLastError());
   return VISFD_HIP_OK;
 }
 

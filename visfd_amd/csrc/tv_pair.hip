@@ -64,6 +64,10 @@ __device__ unsigned long long g_pair_stamps[8];
 #define VH_STAMP(i) do {} while (0)
 #endif
 
+#ifdef VH_TV_COUNT   // development build: how many senders the waves test, how many of those vote, how many lanes they reach
+__device__ unsigned long long g_pair_counts[4];
+#endif
+
 struct PairParams {
   int nx, ny, nz;
   int z_out0, z_out1;    // receiver planes [z_out0, z_out1)
@@ -359,6 +363,9 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
     };
 
     float T[6];
+#ifdef VH_TV_COUNT
+    unsigned cnt_tested = 0, cnt_voted = 0, cnt_lanes = 0;
+#endif
 
     // ---- the SWEEP over list entries [i0, i1) of one list (base = its first LDS entry), in list order ------------------
     // r16: this lane's table base in its slice slot; rcl: its accumulator operand of the distance test (large: never hit)
@@ -406,6 +413,18 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
         if (__builtin_expect(d1 < 0, 1)) vote_one(ent, 1, s0 + 1, ca.w);
         if (__builtin_expect(d2 < 0, 1)) vote_one(ent, 2, s0 + 2, cb.y);
         if (__builtin_expect(d3 < 0, 1)) vote_one(ent, 3, s0 + 3, cb.w);
+#endif
+#ifdef VH_TV_COUNT
+        {
+          const int dd[4] = {d0, d1, d2, d3};
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const unsigned long long b = __builtin_amdgcn_ballot_w64(dd[k] < 0);
+            cnt_tested += 1;
+            cnt_voted += b ? 1 : 0;
+            cnt_lanes += __builtin_popcountll(b);
+          }
+        }
 #endif
       };
       int s0 = base + (i0 & ~1);
@@ -573,6 +592,14 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
         }
       }
       up = !up;
+#ifdef VH_TV_COUNT
+      if (lane == 0) {
+        atomicAdd(&g_pair_counts[0], (unsigned long long)cnt_tested);
+        atomicAdd(&g_pair_counts[1], (unsigned long long)cnt_voted);
+        atomicAdd(&g_pair_counts[2], (unsigned long long)cnt_lanes);
+      }
+      cnt_tested = cnt_voted = cnt_lanes = 0;
+#endif
 
       if (r_live) {
 #pragma unroll
@@ -661,6 +688,16 @@ int dev_tv_pair(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* t
   else          { if (exponent == 4) VH_PAIR_LAUNCH(false, 0); else VH_PAIR_LAUNCH(false, 2); }
 #undef VH_PAIR_LAUNCH
   VH_HIP(hipGetLastError());
+#ifdef VH_TV_COUNT
+  {
+    unsigned long long c4[4], z4[4] = {};
+    VH_HIP(hipStreamSynchronize(st));
+    VH_HIP(hipMemcpyFromSymbol(c4, HIP_SYMBOL(g_pair_counts), sizeof(c4)));
+    fprintf(stderr, "[tv_pair counts] tested (incl. batch padding) %.4g  voted wave-steps %.4g  votes (lane hits) %.4g  -> lane use of a vote step %.3f, "
+            "tested / voted %.3f\n", (double)c4[0], (double)c4[1], (double)c4[2], (double)c4[2] / (64.0 * (double)c4[1]), (double)c4[0] / (double)c4[1]);
+    VH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_pair_counts), z4, sizeof(z4)));
+  }
+#endif
 #ifdef VH_TV_STAMPS
   {
     unsigned long long st8[8], z8[8] = {};
