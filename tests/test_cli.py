@@ -211,13 +211,15 @@ def ref_cli():
     return REF_CLI
 
 
-def both(cli, ref_cli, tmp_path, args, out_name="out.rec"):
-    """Runs the same command line through both programs in separate directories; returns the two directories."""
+def both(cli, ref_cli, tmp_path, args, out_name="out.rec", env=None):
+    """Runs the same command line through both programs in separate directories; returns the two directories.
+    `env`: extra environment of this repo's program (e.g. the tolerance-mode options)."""
     dirs = []
     for tag, exe in (("mine", cli), ("ref", ref_cli)):
         d = tmp_path / tag
         d.mkdir(exist_ok=True)
-        r = subprocess.run([exe] + [str(a) for a in args] + ["-out", out_name], cwd=str(d), capture_output=True, text=True)
+        e = dict(os.environ, **env) if (env and tag == "mine") else None
+        r = subprocess.run([exe] + [str(a) for a in args] + ["-out", out_name], cwd=str(d), capture_output=True, text=True, env=e)
         assert r.returncode == 0, (tag, r.stderr[-2000:])
         dirs.append(d)
     return dirs
@@ -261,6 +263,29 @@ def test_cli_blob_files_equal_reference_program(cli, ref_cli, tmp_path):
     for f in outs["ref"]:
         assert outs["mine"][f] == outs["ref"][f], f
     assert len(outs["ref"]["kept.txt"].strip().split("\n")) == 2
+
+
+@pytest.mark.gpu
+def test_cli_tolerance_modes_from_the_environment(cli, ref_cli, tmp_path):
+    """VISFD_HIP_TV_FMA=1 / VISFD_HIP_GAUSS_FMA=1 switch the command line to the tolerance kernels (a context starts from the
+    environment): vote tensors and the post-vote saliency within 1e-5 of the reference program's, but not its bits; a plain
+    -gauss within 1e-5; a LoG -- whose values feed index comparisons -- still bit for bit."""
+    env = {"VISFD_HIP_TV_FMA": "1", "VISFD_HIP_GAUSS_FMA": "1"}
+    inp = os.path.join(GOLDEN, "test_image_membrane.rec")
+    base = ["-w", 19.2, "-in", inp, "-membrane", "minima", 55, "-tv", 4, "-tv-angle-exponent", 4, "-bin", 1]
+    mine, ref = both(cli, ref_cli, tmp_path, base + ["-save-progress", "prog"], "sal.rec", env=env)
+    differs = False
+    for c in range(6):
+        a, b = volgen.read_mrc(str(mine / ("prog_tensor_%d.rec" % c))), volgen.read_mrc(str(ref / ("prog_tensor_%d.rec" % c)))
+        assert_close_rel(a, b, 1e-5, "tolerance-mode vote tensor channel %d" % c)
+        differs = differs or not np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert differs, "the tolerance kernels did not run"
+    assert_close_rel(volgen.read_mrc(str(mine / "sal.rec")), volgen.read_mrc(str(ref / "sal.rec")), 1e-5, "post-vote saliency")
+    blob = os.path.join(GOLDEN, "test_blob_detect.rec")
+    mine, ref = both(cli, ref_cli, tmp_path, ["-in", blob, "-gauss", 40, "-w", 19.6], "g.rec", env=env)
+    assert_close_rel(volgen.read_mrc(str(mine / "g.rec")), volgen.read_mrc(str(ref / "g.rec")), 1e-5, "-gauss in tolerance mode")
+    mine, ref = both(cli, ref_cli, tmp_path, ["-in", blob, "-log-d", 120, "-w", 19.6], "l.rec", env=env)
+    assert_bits_equal(volgen.read_mrc(str(mine / "l.rec")), volgen.read_mrc(str(ref / "l.rec")), "-log-d under the tolerance options")
 
 
 @pytest.mark.gpu

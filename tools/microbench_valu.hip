@@ -61,11 +61,16 @@ typedef float v2 __attribute__((ext_vector_type(2)));
 #define OP_MAX3(r) "v_max3_f32 " r ", " r ", %16, %17\n"
 #define OP_READLANE(r) "v_readfirstlane_b32 s20, " r "\n"
 #define OP_PKADD(r) "v_pk_add_f32 " r ", " r ", %16\n"
+#define OP_SUBCO(r) "v_sub_co_u32 " r ", vcc, " r ", %16\n"
+#define OP_CMPX(r) "v_cmp_gt_i32_e64 s[20:21], 0, " r "\n"
+#define OP_CMPF(r) "v_cmp_lt_f32 vcc, " r ", %16\n"
+#define OP_ASHR(r) "v_ashrrev_i32 " r ", 31, " r "\n"
 
 enum Mode { MUL, ADD, FMA, MULADD, MUL_E64, PKMUL, PKFMA, MUL_SGPR, CHAIN1, CHAIN2, CHAIN4, DOT4, INT_AND,
             MUL_F64, FMA_F64, ADD_F64, VOTE_LDS,
             MUL_INLINE, MUL_LITERAL, ADD_SGPR, MUL_SGPR_E64, FMAC, DOT4_ONLY, ALIGNBIT_ONLY, FFBL, LSHL_ADD, CMP_VCC, CNDMASK,
             SUB_INLINE, MOV_DPP, ADD_DPP, MAD_U24, ADD_U32, BPERMUTE, SWIZZLE, PERM, BFE, MAX3, READFIRSTLANE, PKADD,
+            SUB_CO, CMP_SGPRPAIR, CMP_F32, ASHR,
             BANK_SAME, BANK_DIFF, BANK_MIX, MUL_EXEC_LO32, MUL_EXEC_HI32, MUL_EXEC_LO16, MUL_EXEC_ALT, NMODES };
 static const char* mode_name[NMODES] = {
     "v_mul_f32 (16 independent)", "v_add_f32 (16 independent)", "v_fma_f32 (16 independent)", "v_mul_f32/v_add_f32 alternating",
@@ -77,14 +82,15 @@ static const char* mode_name[NMODES] = {
     "v_dot4_i32_i8", "v_alignbit_b32", "v_ffbl_b32", "v_lshl_add_u32", "v_cmp_eq_u32 -> vcc", "v_cndmask_b32 (vcc)",
     "v_sub_f32 inline constant 1.0", "v_mov_b32_dpp row_shr:1", "v_add_f32_dpp quad_perm", "v_mad_u32_u24", "v_add_u32", "ds_bpermute_b32",
     "ds_swizzle_b32", "v_perm_b32", "v_bfe_u32", "v_max3_f32", "v_readfirstlane_b32", "v_pk_add_f32 (2 lane-ops each)",
+    "v_sub_co_u32 -> vcc (carry out as a compare)", "v_cmp_gt_i32_e64 -> s[20:21]", "v_cmp_lt_f32 -> vcc", "v_ashrrev_i32 31",
     "v_add_f32 vD, vA, vB: A, B, D all = 0 mod 4", "v_add_f32 vD, vA, vB: A, B, D in three banks (mod 4)",
     "v_mul/v_add pairs, sources A = 0, B = 1 mod 4, 2 mod 4 dest",
     "v_mul_f32 with exec = lanes 0-31 only", "v_mul_f32 with exec = lanes 32-63 only", "v_mul_f32 with exec = lanes 0-15 only",
     "v_mul_f32 with exec = every other lane"};
 // lane-operations per instruction (packed = 2) and instructions per loop trip
-static const int mode_ops[NMODES] = {1, 1, 1, 1, 1, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,  1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1};
+static const int mode_ops[NMODES] = {1, 1, 1, 1, 1, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,  1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
 static const int mode_inst[NMODES] = {256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 128, 128, 128, 280,
-                                      256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256};
+                                      256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256};
 
 struct Stamp { unsigned long long c0, c1, r0, r1; unsigned hwid, pad; };
 
@@ -228,6 +234,10 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 8)
     else if (MODE == BANK_DIFF) { _Pragma("unroll") for (int u = 0; u < 16; u++) asm volatile("v_add_f32 v16, v49, v70\n v_add_f32 v20, v53, v74\n v_add_f32 v24, v57, v78\n v_add_f32 v28, v61, v66\n v_add_f32 v32, v49, v70\n v_add_f32 v36, v53, v74\n v_add_f32 v40, v57, v78\n v_add_f32 v44, v61, v66\n v_add_f32 v16, v49, v70\n v_add_f32 v20, v53, v74\n v_add_f32 v24, v57, v78\n v_add_f32 v28, v61, v66\n v_add_f32 v32, v49, v70\n v_add_f32 v36, v53, v74\n v_add_f32 v40, v57, v78\n v_add_f32 v44, v61, v66" ::: "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83"); }
     else if (MODE == BANK_MIX) { _Pragma("unroll") for (int u = 0; u < 16; u++) asm volatile("v_mul_f32 v18, v48, v69\n v_add_f32 v22, v52, v73\n v_mul_f32 v26, v56, v77\n v_add_f32 v30, v60, v65\n v_mul_f32 v34, v48, v69\n v_add_f32 v38, v52, v73\n v_mul_f32 v42, v56, v77\n v_add_f32 v46, v60, v65\n v_mul_f32 v18, v48, v69\n v_add_f32 v22, v52, v73\n v_mul_f32 v26, v56, v77\n v_add_f32 v30, v60, v65\n v_mul_f32 v34, v48, v69\n v_add_f32 v38, v52, v73\n v_mul_f32 v42, v56, v77\n v_add_f32 v46, v60, v65" ::: "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83"); }
     else if (MODE == PKADD) { _Pragma("unroll") for (int u = 0; u < 16; u++) asm volatile(R16(OP_PKADD) : P16 : "v"(ab), "v"(ab)); }
+    else if (MODE == SUB_CO) { _Pragma("unroll") for (int u = 0; u < 16; u++) asm volatile(R16(OP_SUBCO) : X16 : "v"(a), "v"(b) : "vcc"); }
+    else if (MODE == CMP_SGPRPAIR) { _Pragma("unroll") for (int u = 0; u < 16; u++) asm volatile(R16(OP_CMPX) : X16 : "v"(a), "v"(b) : "s20", "s21"); }
+    else if (MODE == CMP_F32) { _Pragma("unroll") for (int u = 0; u < 16; u++) asm volatile(R16(OP_CMPF) : X16 : "v"(a), "v"(b) : "vcc"); }
+    else if (MODE == ASHR) { _Pragma("unroll") for (int u = 0; u < 16; u++) asm volatile(R16(OP_ASHR) : X16 : "v"(a), "v"(b)); }
     else if (MODE == BPERMUTE) { _Pragma("unroll") for (int u = 0; u < 16; u++) { asm volatile(R16(OP_BPERM) : X16 : "v"(laddr), "v"(b)); asm volatile("s_waitcnt lgkmcnt(0)" : X16); } }
     else if (MODE == SWIZZLE) { _Pragma("unroll") for (int u = 0; u < 16; u++) { asm volatile(R16(OP_SWIZ) : X16 : "v"(laddr), "v"(b)); asm volatile("s_waitcnt lgkmcnt(0)" : X16); } }
   }
@@ -318,9 +328,10 @@ int main(int argc, char** argv) {
                         k<CHAIN4>, k<DOT4>, k<INT_AND>, k<MUL_F64>, k<FMA_F64>, k<ADD_F64>, k<VOTE_LDS>,
                         k<MUL_INLINE>, k<MUL_LITERAL>, k<ADD_SGPR>, k<MUL_SGPR_E64>, k<FMAC>, k<DOT4_ONLY>, k<ALIGNBIT_ONLY>, k<FFBL>,
                         k<LSHL_ADD>, k<CMP_VCC>, k<CNDMASK>, k<SUB_INLINE>, k<MOV_DPP>, k<ADD_DPP>, k<MAD_U24>, k<ADD_U32>, k<BPERMUTE>,
-                        k<SWIZZLE>, k<PERM>, k<BFE>, k<MAX3>, k<READFIRSTLANE>, k<PKADD>, k<BANK_SAME>, k<BANK_DIFF>, k<BANK_MIX>, k<MUL_EXEC_LO32>, k<MUL_EXEC_HI32>, k<MUL_EXEC_LO16>, k<MUL_EXEC_ALT>};
+                        k<SWIZZLE>, k<PERM>, k<BFE>, k<MAX3>, k<READFIRSTLANE>, k<PKADD>, k<SUB_CO>, k<CMP_SGPRPAIR>, k<CMP_F32>, k<ASHR>, k<BANK_SAME>, k<BANK_DIFF>, k<BANK_MIX>, k<MUL_EXEC_LO32>, k<MUL_EXEC_HI32>, k<MUL_EXEC_LO16>, k<MUL_EXEC_ALT>};
   const int m0 = argc > 2 ? atoi(argv[2]) : 0;
-  for (int m = m0; m < NMODES; m++)
+  const int m1 = argc > 3 ? atoi(argv[3]) : NMODES;
+  for (int m = m0; m < m1 && m < NMODES; m++)
     for (int w : {1, 2, 4, 8}) run(m, fns[m], w, num_cus, out, dstamps, f);
   if (f) fclose(f);
   return 0;
