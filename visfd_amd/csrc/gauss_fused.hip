@@ -39,6 +39,12 @@
 #error "compile with -DVH_FUSED_H=<halfwidth>"
 #endif
 
+// Cache policy of the output stores: nt (aux = 2).  The result is not read again by this kernel, and stores that allocate
+// in L2 push out the input rows neighbouring tiles share; measured on the tolerance kernel at 2048^3 (same box, alternating
+// runs): 16.5 / 16.1 / 18.0 ms with default-policy stores, 15.3 / 15.2 / 14.9 ms with nt; 1-2 % at 1024^3, every variant.
+#ifndef VH_FUSED_STORE_AUX
+#define VH_FUSED_STORE_AUX 2
+#endif
 #ifndef VH_FUSED_ZFILL
 #define VH_FUSED_ZFILL 1
 #endif
@@ -282,8 +288,17 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
   // first input plane of the march (the topmost one, ze-1+H); planes outside the image read as 0.0f
   const int ktop = ze - 1 + (ZPASS ? H : 0);
   const int nout = ze - zs;
-  float xin[C::NC];
-  auto request_plane = [&](int zn, bool wanted) {   // a zero-length descriptor fetches nothing and returns 0.0f
+  // Input planes in flight.  The exact kernel is VALU-bound and keeps ONE plane ahead (a second set was slower there,
+  // profiles/r02_gauss_experiments.txt).  The tolerance kernel has half the arithmetic: at 2048^3 a workgroup has ~1.9 us per
+  // plane, less than a loaded HBM round trip, so it keeps TWO planes ahead (PF = 2: plane k + 2 is requested into the
+  // registers plane k has just left; the march is unrolled 2W times so that the set index stays a compile-time constant).
+#ifndef VH_FUSED_PF
+#define VH_FUSED_PF 2
+#endif
+  constexpr int PF = (FMA && ZPASS) ? VH_FUSED_PF : 1;
+  float xin2[PF][C::NC];
+  float (&xin)[C::NC] = xin2[0];
+  auto request_plane = [&](int zn, bool wanted, int par = 0) {   // a zero-length descriptor fetches nothing and returns 0.0f
 #if defined(VH_FUSED_EXP) && VH_FUSED_EXP == 1   // experiment: every request re-reads one (cache-resident) plane
     zn = ktop < nz ? ktop : nz - 1;
 #endif
@@ -291,9 +306,10 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(src + (zin ? (i64)zn * plane : 0)), 0, zin ? plane_bytes : 0, 0x00020000);
 #pragma unroll
-    for (int c = 0; c < C::NC; c++) xin[c] = buf_load(rs, col_off[c]);
+    for (int c = 0; c < C::NC; c++) xin2[par][c] = buf_load(rs, col_off[c]);
   };
   request_plane(ktop, true);
+  if constexpr (PF == 2) request_plane(ktop - 1, true, 1);
 #ifdef VH_FUSED_STAMPS
   unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long st_last = __builtin_amdgcn_s_memtime();
@@ -307,7 +323,7 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
   // (checked on the host, bit for bit), so t[j]*f[k] and t[-j]*f[k] are the same IEEE product and only
   // H+1 multiplies are needed per input instead of 2H+1.  Slot of output i: (ktop + H - i) mod W
   // = (u + H - j) mod W at step number congruent to u.
-  auto z_scatter_cols = [&](int u, int c_lo, int c_hi) {   // (columns [c_lo, c_hi); all arguments constants after inlining)
+  auto z_scatter_cols = [&](int u, int c_lo, int c_hi, int par = 0) {   // (columns [c_lo, c_hi); all arguments constants after inlining)
 #pragma unroll
     for (int c = 0; c < C::NC; c++) {
       if (c < c_lo || c >= c_hi) continue;
@@ -315,8 +331,8 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
 #pragma unroll
         for (int j = -H; j <= H; j++) {
           const int s = (u + H - j) % W;
-          if (j == -H) ring[c][s] = tap_z(H) * xin[c];
-          else ring[c][s] = __builtin_fmaf(tap_z(j < 0 ? -j : j), xin[c], ring[c][s]);
+          if (j == -H) ring[c][s] = tap_z(H) * xin2[par][c];
+          else ring[c][s] = __builtin_fmaf(tap_z(j < 0 ? -j : j), xin2[par][c], ring[c][s]);
         }
         continue;
       }
@@ -331,7 +347,7 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
       }
     }
   };
-  auto z_scatter = [&](int u) { z_scatter_cols(u, 0, C::NC); };
+  auto z_scatter = [&](int u, int par = 0) { z_scatter_cols(u, 0, C::NC, par); };
   // FILL: the Z pass of the NEXT plane is independent of the Y and X passes of this one, and every Y or X round starts
   // with an LDS round trip that four waves per SIMD do not cover.  With VH_FUSED_ZFILL the ring update is cut into three
   // column groups that run right after the reads of the first Y round, the last Y round and the first X round have
@@ -344,7 +360,7 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
     else return acc + t * v;
   };
   // Y and X passes of output plane z from the Z-filtered (or, without a Z pass, the source) tile sZ
-  auto yx_passes = [&](int z, const float* sZ, auto&& zfill) {
+  auto yx_passes = [&](int z, const float* sZ, auto&& zfill, int next_par = 0) {
         // Y pass: two adjacent x per lane; source rows y+2H (j=-H) down to y (j=+H)
 #pragma unroll
         for (int r = 0; r < NYR; r++) {
@@ -583,7 +599,7 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
           VH_STAMP(5);
           if (r == 0) {
 #pragma unroll
-            for (int c = 0; c < C::NC; c++) asm volatile("" : "+v"(xin[c]));
+            for (int c = 0; c < C::NC; c++) asm volatile("" : "+v"(xin2[next_par][c]));   // (the set the next Z pass consumes)
           }
 #if defined(VH_FUSED_EXP) && VH_FUSED_EXP == 2   // experiment: no output stores (values kept live)
           asm volatile("" :: "v"(a[0]), "v"(a[1]));
@@ -592,10 +608,10 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
           if (C::XV == 4) {
 #endif
             v4f out = {a[0], a[1], a[2], a[3]};
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, out), ro, (int)o_off[r], 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, out), ro, (int)o_off[r], 0, VH_FUSED_STORE_AUX);
           } else {
             v2f out = {a[0], a[1]};
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, out), ro, (int)o_off[r], 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, out), ro, (int)o_off[r], 0, VH_FUSED_STORE_AUX);
           }
           if (RAGGED) {
 #pragma unroll
@@ -621,28 +637,30 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
   }
   // warm-up: the first 2H input planes complete no output of this chunk (each step waits for its plane;
   // a separate code region, so that the main loop below has a single wait state at its step boundaries)
+  // (input plane number k = ktop - z, k = 0, 1, ...: consumed from set k % PF, which then takes plane k + PF;
+  //  the last plane any output of this chunk needs is number nout - 1 + 2H)
   static_for<0, W - 1>([&](auto U) {
     constexpr int u = decltype(U)::value;
-    z_scatter(u);
-    request_plane(ktop - u - 1, true);
+    z_scatter(u, u % PF);
+    request_plane(ktop - u - PF, true, u % PF);
   });
   // Z pass of the step that completes output plane number n (z = ze-1-n; ring phase u = (n + W-1) % W, a constant at
   // every call site), its tile into LDS buffer n & 1, and the request for the next input plane, whose latency the
   // rest of the interval covers
-  auto z_store = [&](auto U, int n) {   // the completed sums of plane n into its LDS buffer; request of the next input plane
+  auto z_store = [&](auto U, int n, int par = 0) {   // the completed sums of plane n into its LDS buffer; request of the next input plane
     constexpr int u = decltype(U)::value;
     float* sZ = sZ2[n & 1];
 #pragma unroll
     for (int c = 0; c < C::NC; c++)
       *reinterpret_cast<float*>(reinterpret_cast<char*>(sZ) + lds_base + 4 * NT * c) = ring[c][u];
-    request_plane(ze - 1 - n - H - 1, n + 1 < nout);
+    request_plane(ze - 1 - n - H - PF, n + PF < nout, par);   // plane number n + 2H + PF; the last one needed is nout - 1 + 2H
   };
-  auto z_step = [&](auto U, int n) {
+  auto z_step = [&](auto U, int n, int par = 0) {   // consumes input plane number n + 2H (set par = (n + 2H) % PF = n % PF)
     constexpr int u = decltype(U)::value;
-    z_scatter(u);
-    z_store(U, n);
+    z_scatter(u, par);
+    z_store(U, n, par);
   };
-  z_step(std::integral_constant<int, W - 1>{}, 0);
+  z_step(std::integral_constant<int, W - 1>{}, 0, 0);
   // Main loop, one workgroup barrier per plane.  Between two barriers every wave runs the Y and X passes of plane n
   // (reading buffer n & 1, complete since the barrier) AND the Z pass of plane n+1 (writing the other buffer, whose
   // readers finished before the barrier); the two pieces are independent.  VH_FUSED_STAGGER=1 lets the two halves of
@@ -653,10 +671,13 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
 #define VH_FUSED_STAGGER 0
 #endif
   const bool z_first = VH_FUSED_STAGGER && __builtin_amdgcn_readfirstlane(wave) >= C::NW / 2;
-  for (int nb = 0; nb < nout; nb += W) {
-    static_for<0, W>([&](auto V) {
-      constexpr int v = decltype(V)::value;
-      const int n = nb + v;
+  for (int nb = 0; nb < nout; nb += PF * W) {
+    static_for<0, PF * W>([&](auto V2) {
+      constexpr int v2 = decltype(V2)::value;
+      constexpr int v = v2 % W;               // ring phase of plane n + 1
+      constexpr int npar = (v2 + 1) % PF;     // input set of plane n + 1 (nb is a multiple of PF)
+      const std::integral_constant<int, v> V{};
+      const int n = nb + v2;
       if (n < nout) {  // uniform across the workgroup
         VH_STAMP(0);
 #if !(defined(VH_FUSED_EXP) && VH_FUSED_EXP == 3)   // experiment 3: no workgroup barrier (wrong results)
@@ -672,19 +693,19 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
           // -6...-9 %, H = 4: +-0, H = 5: +2.5 % (profiles/r02_gauss_experiments.txt)
           const bool more = n + 1 < nout;   // uniform
           yx_passes(ze - 1 - n, sZ2[n & 1], [&](int k) {
-            if (more) z_scatter_cols(v, k == 0 ? 0 : (k == 1 ? ZF0 : ZF1), k == 0 ? ZF0 : (k == 1 ? ZF1 : C::NC));
-          });
-          if (more) z_store(V, n + 1);
+            if (more) z_scatter_cols(v, k == 0 ? 0 : (k == 1 ? ZF0 : ZF1), k == 0 ? ZF0 : (k == 1 ? ZF1 : C::NC), npar);
+          }, npar);
+          if (more) z_store(V, n + 1, npar);
           VH_STAMP(1);
         } else {
           if (!z_first) {   // uniform per wave
-            yx_passes(ze - 1 - n, sZ2[n & 1], [](int) {});
+            yx_passes(ze - 1 - n, sZ2[n & 1], [](int) {}, npar);
             VH_STAMP(6);
           }
-          if (n + 1 < nout) z_step(V, n + 1);
+          if (n + 1 < nout) z_step(V, n + 1, npar);
           VH_STAMP(1);
           if (z_first) {
-            yx_passes(ze - 1 - n, sZ2[n & 1], [](int) {});
+            yx_passes(ze - 1 - n, sZ2[n & 1], [](int) {}, npar);
             VH_STAMP(6);
           }
         }

@@ -603,7 +603,7 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
 
       if (r_live) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) ten[k * nvox + rc] = T[k];
+        for (int k = 0; k < 6; k++) __builtin_nontemporal_store(T[k], &ten[k * nvox + rc]);   // written once, not read here
       }
     }   // next pair of receiver planes of the run
   }   // next unit

@@ -463,7 +463,7 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
           ten[rc] = T[0];
         } else {
 #pragma unroll
-          for (int k = 0; k < 6; k++) ten[k * nvox + rc] = T[k];
+          for (int k = 0; k < 6; k++) __builtin_nontemporal_store(T[k], &ten[k * nvox + rc]);   // written once, not read here
         }
       }
     }   // next pair of receiver planes of the run
