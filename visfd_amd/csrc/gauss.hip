@@ -14,6 +14,17 @@
 
 #include "common.hpp"
 
+// Outputs that this kernel does not read again are stored non-temporally: stores that allocate in L2 push out the rows
+// neighbouring workgroups share (measured on the single sweep: csrc/gauss_fused.hip).  -DVH_STREAM_STORES=0 restores plain stores.
+#ifndef VH_STREAM_STORES
+#define VH_STREAM_STORES 1
+#endif
+#if VH_STREAM_STORES
+#define VH_STREAM_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#else
+#define VH_STREAM_STORE(v, p) (*(p) = (v))
+#endif
+
 namespace vh {
 
 namespace {
@@ -145,7 +156,7 @@ conv_march_kernel(const float* __restrict__ in, float* __restrict__ out, const f
       if (!any) { acc = 0.0f; den = 0.0f; }
       if (den_out) den_out[c] = den;
     }
-    out[c] = acc;
+    VH_STREAM_STORE(acc, &out[c]);
   }
 }
 
@@ -225,7 +236,7 @@ conv_row_kernel(const float* __restrict__ in, float* __restrict__ out, const flo
       const float dd = minuend[c] - acc;
       acc = dd * log_scale;
     }
-    out[c] = acc;
+    VH_STREAM_STORE(acc, &out[c]);
   }
 }
 

@@ -148,7 +148,7 @@ ridge_score_kernel(const float* __restrict__ S, const float* __restrict__ mask, 
   const double l1 = (float)lam[0], l2 = (float)lam[1];   // stored as float by DiagonalizeFlatSym3, re-read as double
   double N = l1 * l1 - l2 * l2;
   N *= N;
-  sal[v] = (float)N;
+  __builtin_nontemporal_store((float)N, &sal[v]);
 }
 
 // ... and the principal direction of the voxels whose saliency is non-zero.  A workgroup scans DIR_CHUNK
@@ -235,7 +235,7 @@ tensor_saliency_kernel(const float* __restrict__ ten, const float* __restrict__ 
   eig::D3 E[3];
   eig::eig_sym3(t6, order, lam, E, false);
   const double l1 = (float)lam[0], l2 = (float)lam[1];  // stored as float, re-read as double
-  sal[v] = (float)(l1 - l2);
+  __builtin_nontemporal_store((float)(l1 - l2), &sal[v]);
 }
 
 __global__ void __launch_bounds__(BLOCK)
