@@ -545,6 +545,7 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
+        layout.close()      # the slab handle (its RCCL communicator and transfer stream) before the context it points to
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

@@ -109,6 +109,8 @@ def main():
             print("SLAB-MISMATCH: " + "; ".join(bad), flush=True)
     flag = [bool(bad)]
     dist.broadcast_object_list(flag, src=0)
+    if hasattr(L, "close"):
+        L.close()
     ctx.close()
     dist.destroy_process_group()
     sys.exit(1 if flag[0] else 0)

@@ -440,6 +440,12 @@ class Context:
             raise VisfdHipError(rc, self._L.visfd_hip_last_error().decode())
 
     def close(self):
+        # slab handles hold a pointer to this context: they go first
+        for ref in getattr(self, "_slabs", []):
+            s = ref()
+            if s is not None:
+                s.close()
+        self._slabs = []
         if getattr(self, "_h", None):
             self._L.visfd_hip_destroy(self._h)
             self._h = None
@@ -830,6 +836,10 @@ class Slab:
             ctx._chk(self._L.visfd_hip_slab_create_custom(ctx._h, C.addressof(tr), rank, world, nz_global, ghost, C.byref(self._h)))
         else:
             raise ValueError("transport must be 'rccl' or 'torch'")
+        import weakref
+        if not hasattr(ctx, "_slabs"):
+            ctx._slabs = []
+        ctx._slabs.append(weakref.ref(self))    # Context.close() destroys its slabs first
         lay = (_i64 * 7)()
         ctx._chk(self._L.visfd_hip_slab_layout(self._h, lay))
         self.z0, self.z1, self.lo, self.hi, self.own0, self.own1, self.nz_local = [int(v) for v in lay]
