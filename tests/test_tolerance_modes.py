@@ -184,3 +184,45 @@ def test_tv_weight_sum_kernels_agree(ctx, oracle, sigma_tv, shape):
                 got[dense] = ctx.tv_weight_sum(sal, sigma_tv, 2.0 ** 0.5, m, m)
         assert_bits_equal(got[0], got[1], "weight sums: tiled (or its fallback) vs baseline kernel, sigma_tv=%g mask=%s" % (sigma_tv, m is not None))
         assert_bits_equal(got[1], want, "weight sums vs the direct sum, sigma_tv=%g mask=%s" % (sigma_tv, m is not None))
+
+
+@pytest.mark.parametrize("sigma_tv,h", [(19.2, 27), (24.1, 34)])
+def test_tv_fma_very_wide_windows(ctx, oracle, sigma_tv, h):
+    """windows whose table slices fill most of a CU's LDS (one workgroup per CU) and whose regions need the one-plane lister"""
+    shape = (7, 40, 21)
+    sal, dirs = _sparse_field(shape, seed=h, frac=0.02)
+    ref = oracle.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5)
+    for opts in ({}, {"tv_max_wg": 2, "tv_zrun": 3}):
+        with ctx.options(tv_fma=1, **opts):
+            assert_close_rel(ctx.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5), ref, TOL, "fma tensor h=%d %s" % (h, opts))
+
+
+def test_tv_fma_receiver_plane_ranges(ctx, oracle):
+    """the slab form (visfd_hip_tv_dense_stick_slab_dev: receiver planes [z0, z1) of a local array, as the multi-GPU host
+    votes its interior and its two bands) in tolerance mode: odd and even ranges, ranges of one plane, the whole array in
+    three pieces -- each piece within 1e-5 of the oracle's planes and untouched outside its range"""
+    import torch
+    shape = (23, 26, 35)
+    sal, dirs = _sparse_field(shape, seed=99, frac=0.08)
+    want = oracle.tv_dense_stick(sal, dirs, 3.0, 4, 2.0 ** 0.5)
+    dev = torch.device("cuda:0")
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        from visfd_amd import api
+        c2 = api.Context(0, st.cuda_stream)
+        tsal = torch.from_numpy(sal).to(dev)
+        tdir = torch.from_numpy(np.ascontiguousarray(np.moveaxis(dirs, -1, 0))).to(dev)
+        scale = float(np.abs(want).max())
+        for ranges in ([(0, 23)], [(0, 7), (7, 18), (18, 23)], [(4, 5), (5, 16)], [(3, 4)], [(0, 1), (22, 23)]):
+            ten = torch.full((6,) + shape, 7.5, device=dev)
+            with c2.options(tv_fma=1):
+                for (a, b) in ranges:
+                    c2.tv_dense_stick_dev(tsal, tdir, ten, 3.0, 4, 2.0 ** 0.5, None, None, False, (a, b))
+            c2.synchronize()
+            got = np.moveaxis(ten.cpu().numpy(), 0, -1)
+            covered = np.zeros(shape[0], bool)
+            for (a, b) in ranges:
+                covered[a:b] = True
+                assert np.max(np.abs(got[a:b] - want[a:b])) <= TOL * scale, "planes %d..%d" % (a, b)
+            assert np.all(got[~covered] == 7.5), "planes outside the requested ranges were written"
+        c2.close()
