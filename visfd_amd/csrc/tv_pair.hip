@@ -37,10 +37,31 @@ namespace {
 #endif
 constexpr int NT = VH_PAIR_NT;
 constexpr int NW = NT / 64;
-constexpr int TX = 8, TY = 4 * NW;
-constexpr int CAPH = NT / 2;           // list entries per sender plane held in LDS per sweep: one per thread of a half workgroup
-constexpr int NCH_MAX = NT >= 512 ? 4 : 5;   // chunks of the region per wave the two-plane lister handles
-constexpr int LSTRIDE = CAPH + 8;      // entries of list B start here (8 never-hit entries of slack behind each list)
+// RECEIVERS PER LANE.  A wave's patch is 8 x 4 receivers (x 2 mirrored planes); with TX = 16 every lane owns the receivers at x
+// and x + 8 of a 16 x 4 patch (NS = 2 sub-patches).  Both see the same list entries, so the position words and the sender's
+// {saliency, normal} are read from LDS once for two votes (the LDS pipe is the kernel's second limiter: ~11 LDS cycles per
+// vote against ~50 issue cycles per SIMD and four SIMDs per CU), and the region a tile lists shrinks from 7.0 to 4.4 voxels
+// per receiver column.
+#ifndef VH_PAIR_TX
+#define VH_PAIR_TX 8
+#endif
+constexpr int TX = VH_PAIR_TX, TY = 4 * NW;
+constexpr int NS = TX / 8;             // receivers per lane and plane pair
+static_assert(TX == 8 || TX == 16, "one or two 8-column sub-patches per wave");
+// RECEIVER PAIRS PER PASS.  The sender planes of the receiver pairs (z, z+1) and (z+2, z+3) at step d are four different
+// planes, but they need the SAME two table slices S_(d-1), S_d: with NP = 2 a workgroup takes both pairs through the
+// steps together -- four lists and four sweeps per barrier interval (each wave: 2 x 6 sums), the same two slices, half as
+// many intervals, fills and barriers per vote.  LDS is unchanged: 4 lists of 128 entries instead of 2 of 256.
+#ifndef VH_PAIR_NP
+#define VH_PAIR_NP (VH_PAIR_TX == 8 ? 2 : 1)
+#endif
+constexpr int NP = VH_PAIR_NP;
+constexpr int NLIST = 2 * NP;          // lists per interval: (A, B) of pair 0, (A, B) of pair 1
+constexpr int CAPH = NT / NLIST;       // list entries per sender plane held in LDS per sweep: one per thread of its share of the workgroup
+constexpr int WPL = NW / NLIST;        // waves that bring (and count the row ranges of) one list
+static_assert(CAPH % 64 == 0 && WPL >= 1, "a list is brought by whole waves");
+constexpr int NCH_MAX = (NT >= 512 && TX == 8) ? 4 : 5;   // chunks of the region per wave the two-plane lister handles
+constexpr int LSTRIDE = CAPH + 8;      // LDS entries per list (8 never-hit entries of slack behind each list)
 constexpr unsigned OOB = 0x7ffffff0u;  // byte offset beyond any plane descriptor: reads give 0
 
 __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
@@ -118,13 +139,13 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
   //           [0, CAPH), list B (the plane below) in [LSTRIDE, LSTRIDE + CAPH)
   // l_pos[e]  {distance-test operand, table offset E}: packed signed bytes (e'x, e'y, -(|e'|^2 >> 7), |e'|^2 & 127) with e' =
   //           sender position relative to the tile centre and the LOWER receiver plane; 8 never-hit entries behind each list
-  __shared__ __attribute__((aligned(16))) float4 l_ent[2 * LSTRIDE];
-  __shared__ __attribute__((aligned(16))) uint2 l_pos[2 * LSTRIDE];
-  __shared__ float l_mv[MASKED_SRC ? 2 * LSTRIDE : 1];
+  __shared__ __attribute__((aligned(16))) float4 l_ent[NLIST * LSTRIDE];
+  __shared__ __attribute__((aligned(16))) uint2 l_pos[NLIST * LSTRIDE];
+  __shared__ float l_mv[MASKED_SRC ? NLIST * LSTRIDE : 1];
   __shared__ int wave_tot[2][2][NW];
   __shared__ int cull[NW][2 * NW];           // per wave holding entries (0-3: list A, 4-7: list B): entries above / not below each wave's rows
   __shared__ unsigned claimed_tile;
-  __shared__ int plane_cnt[84];              // entries per ring slot, [2h+2] (h <= 40)
+  __shared__ int plane_cnt[88];              // entries per ring slot, [2h + 2 NP] (h <= 40)
   extern __shared__ __attribute__((aligned(16))) unsigned char slices[];   // two table slices: S_j (jz = +j) in slot j & 1
 
   const int tid = threadIdx.x;
@@ -144,7 +165,7 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
   const int plane_bytes = (int)(plane * 4);
   constexpr int ENT_BYTES = MASKED_SRC ? 24 : 20;
   const size_t plane_stride = (size_t)R * ENT_BYTES;   // a ring slot: float4 ent[R]; unsigned pos[R]; (float mv[R])
-  const int P = S + 1;
+  const int P = S + 2 * NP - 1;   // sender planes the receiver planes of a pass reach = slots of the ring
   unsigned char* const ring = scratch + (size_t)blockIdx.x * plane_stride * P;
   int npar = 0;
   int slot_has[2] = {-1, -1};                // which slice S_j each LDS slot holds (uniform)
@@ -362,14 +383,14 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
       if (tid == 0) plane_cnt[slot] = total;
     };
 
-    float T[6];
+    float TT[NP][6];
 #ifdef VH_TV_COUNT
     unsigned cnt_tested = 0, cnt_voted = 0, cnt_lanes = 0;
 #endif
 
     // ---- the SWEEP over list entries [i0, i1) of one list (base = its first LDS entry), in list order ------------------
     // r16: this lane's table base in its slice slot; rcl: its accumulator operand of the distance test (large: never hit)
-    auto sweep = [&](auto ZN, int base, int i0, int i1, unsigned r16, int rcl) {
+    auto sweep = [&](auto ZN, float (&T)[6], int base, int i0, int i1, unsigned r16, int rcl) {
       constexpr bool ZNEG = decltype(ZN)::value;
       auto vote_one = [&](unsigned ent, int k, int s, unsigned e16) {
         const f4v tw = *lds_ptr<f4v>(r16 - e16);
@@ -448,10 +469,10 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
     };
 
     int cached_lo = 1, cached_hi = 0;
-    for (int rz = z_run0; rz < z_run1; rz += 2) {
-      // sender planes that reach the live receivers of this pair (an odd run ends with half a pair: nothing above
-      // rz + h is needed -- or, in a slab run, complete -- then)
-      const int sz_hi = min(min(rz + 1, z_run1 - 1) + h, p.nz - 1), sz_lo = max(rz - h, 0);
+    for (int rz = z_run0; rz < z_run1; rz += 2 * NP) {
+      // sender planes that reach the LIVE receivers of this pass (a run may end inside a pass: nothing above the last
+      // live receiver + h is needed -- or, in a slab run, complete -- then)
+      const int sz_hi = min(min(rz + 2 * NP - 1, z_run1 - 1) + h, p.nz - 1), sz_lo = max(rz - h, 0);
 #ifndef VH_PAIR_LIST2
 #define VH_PAIR_LIST2 1
 #endif
@@ -474,25 +495,41 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
       cached_lo = sz_lo;
       cached_hi = sz_hi;
 
-      const int rzl = rz + half;
-      const bool z_in = rzl < z_run1;
-      const i64 rc = (i64)rzl * plane + (i64)ry * p.nx + rx;
-      const bool r_live = r_in && z_in && !(mask_dst && mask_dst[(r_in && z_in) ? rc : 0] == 0.0f);
+      // this lane's receivers: plane rz + 2 pp + half of pair pp
+      i64 rc[NP];
+      bool r_live[NP];
 #pragma unroll
-      for (int k = 0; k < 6; k++) T[k] = 0.0f;
-      __syncthreads();   // ring entries and counts of this pair of receiver planes are visible
+      for (int pp = 0; pp < NP; pp++) {
+        const int rzl = rz + 2 * pp + half;
+        const bool z_in = rzl < z_run1;
+        rc[pp] = (i64)rzl * plane + (i64)ry * p.nx + rx;
+        r_live[pp] = r_in && z_in && !(mask_dst && mask_dst[(r_in && z_in) ? rc[pp] : 0] == 0.0f);
+#pragma unroll
+        for (int k = 0; k < 6; k++) TT[pp][k] = 0.0f;
+      }
+      __syncthreads();   // ring entries and counts of this pass are visible
       VH_STAMP(0);
 
-      // d = 1 .. h+1: sender planes A = rz + d (above: jz = -d for the lower receiver plane, 1-d for the upper one) and
-      // B = rz + 1 - d (below: jz = d-1 and d).  Both need the slices S_(d-1) and S_d; the direction alternates from pair
-      // to pair, so that every step -- the first of a pair included -- finds one of its two slices in LDS already.
+      // d = 1 .. h+1.  Pair pp (receiver planes z = rz + 2 pp and z + 1): sender planes A = z + d (above: jz = -d for the
+      // lower receiver plane, 1-d for the upper one) and B = z + 1 - d (below: jz = d-1 and d).  All of them need the slices
+      // S_(d-1) and S_d; the direction of d alternates from pass to pass, so that every step -- the first of a pass
+      // included -- finds one of its two slices in LDS already.
       for (int step = 0; step <= h; step++) {
         const int d = up ? step + 1 : h + 1 - step;
-        const int szA = rz + d, szB = rz + 1 - d;
-        const int cntA = (szA <= sz_hi) ? __builtin_amdgcn_readfirstlane(plane_cnt[szA % P]) : 0;
-        const int cntB = (szB >= sz_lo) ? __builtin_amdgcn_readfirstlane(plane_cnt[szB % P]) : 0;
-        if (cntA + cntB == 0) continue;   // uniform
-        // slices S_(d-1) and S_d (S_(h+1) does not exist: its lanes never hit); list and slices are free: every sweep ends
+        int lsz[NLIST], lcnt[NLIST];     // list 2 pp: plane A of pair pp; list 2 pp + 1: its plane B
+        int cmax = 0;
+#pragma unroll
+        for (int pp = 0; pp < NP; pp++) {
+          const int z = rz + 2 * pp;
+          const bool pair_live = z < z_run1;                   // (uniform) a pair beyond the end of the run takes no votes
+          lsz[2 * pp] = z + d;
+          lsz[2 * pp + 1] = z + 1 - d;
+          lcnt[2 * pp] = (pair_live && lsz[2 * pp] <= sz_hi) ? __builtin_amdgcn_readfirstlane(plane_cnt[lsz[2 * pp] % P]) : 0;
+          lcnt[2 * pp + 1] = (pair_live && lsz[2 * pp + 1] >= sz_lo) ? __builtin_amdgcn_readfirstlane(plane_cnt[lsz[2 * pp + 1] % P]) : 0;
+          cmax = max(cmax, max(lcnt[2 * pp], lcnt[2 * pp + 1]));
+        }
+        if (cmax == 0) continue;   // uniform
+        // slices S_(d-1) and S_d (S_(h+1) does not exist: its lanes never hit); lists and slices are free: every sweep ends
         // with a barrier
         int need[2];
 #pragma unroll
@@ -506,17 +543,17 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
         int rho = (int)__builtin_sqrtf((float)(h * h - jn));
         while (rho * rho > h * h - jn) rho--;
         while ((rho + 1) * (rho + 1) <= h * h - jn) rho++;
-        const bool isB = wave >= NW / 2;                       // (uniform) this thread brings entries of list B
-        const int my_sz = isB ? szB : szA;
-        const int my_cnt = isB ? cntB : cntA;
+        const int li = wave / WPL;                             // (uniform) the list this thread brings entries of
+        int my_sz = lsz[0], my_cnt = lcnt[0];
+#pragma unroll
+        for (int k = 1; k < NLIST; k++)
+          if (li == k) { my_sz = lsz[k]; my_cnt = lcnt[k]; }
         const unsigned char* ring_plane = ring + (size_t)(((my_sz % P) + P) % P) * plane_stride;
         const int ltid = tid & (CAPH - 1);
-        const int lbase = isB ? LSTRIDE : 0;
-        for (int done = 0; done < cntA || done < cntB; done += CAPH) {   // uniform
+        const int lbase = li * LSTRIDE;
+        for (int done = 0; done < cmax; done += CAPH) {   // uniform
           const int take = min(CAPH, max(my_cnt - done, 0));
           int epy = -128;                                      // threads without an entry: below every range
-          // requests first -- this thread's ring entry, then its share of the missing slice (one per step as a rule) -- so
-          // that the fill of a step is ONE memory round trip
           float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
           unsigned m = 0u;
           float mvv = 0.0f;
@@ -533,14 +570,7 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
               const int j = need[k];
               const float4* src4 = table + (i64)(j + h) * nsl;
               float4* dst4 = sl4 + (j & 1) * nsl;
-              if (VH_PAIR_FILL_FIRST && nsl <= 2 * NT) {
-                const float4 v0 = tid < nsl ? src4[tid] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                const float4 v1 = tid + NT < nsl ? src4[tid + NT] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (tid < nsl) dst4[tid] = v0;
-                if (tid + NT < nsl) dst4[tid + NT] = v1;
-              } else {
-                for (int i = tid; i < nsl; i += NT) dst4[i] = src4[i];
-              }
+              for (int i = tid; i < nsl; i += NT) dst4[i] = src4[i];
             }
           }
           if (ltid < take) {
@@ -563,28 +593,34 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
           VH_STAMP(1);
           __syncthreads();   // lists (and slices) complete
           VH_STAMP(2);
-          int iA0 = 0, iA1 = 0, iB0 = 0, iB1 = 0;
+          int i0[NLIST], i1[NLIST];
 #pragma unroll
-          for (int w = 0; w < NW / 2; w++) {
-            iA0 += cull[w][2 * wave]; iA1 += cull[w][2 * wave + 1];
-            iB0 += cull[NW / 2 + w][2 * wave]; iB1 += cull[NW / 2 + w][2 * wave + 1];
+          for (int k = 0; k < NLIST; k++) {
+            int s0 = 0, s1 = 0;
+#pragma unroll
+            for (int w = 0; w < WPL; w++) { s0 += cull[k * WPL + w][2 * wave]; s1 += cull[k * WPL + w][2 * wave + 1]; }
+            i0[k] = __builtin_amdgcn_readfirstlane(s0);
+            i1[k] = __builtin_amdgcn_readfirstlane(s1);
           }
-          iA0 = __builtin_amdgcn_readfirstlane(iA0); iA1 = __builtin_amdgcn_readfirstlane(iA1);
-          iB0 = __builtin_amdgcn_readfirstlane(iB0); iB1 = __builtin_amdgcn_readfirstlane(iB1);
-          // plane A (above): the lower receiver plane sees it at jz = -d (slice S_d, rhat_z negated), the upper one at
-          // 1-d (S_(d-1)); |r-e|^2 of the upper plane's receivers differs by 1 - 2 e'z
-          if (iA1 > iA0) {
-            const int jl = d, ju = d - 1;
-            const bool ok = r_live && (half ? ju <= h : jl <= h);
-            const unsigned r16 = r16_0 + (unsigned)(16 * nsl) * (unsigned)((half ? ju : jl) & 1);
-            sweep(std::true_type{}, 0, iA0, iA1, r16, ok ? recv_c + d * d + (half ? 1 - 2 * d : 0) : 0x100000);
-          }
-          // plane B (below): jz = d-1 for the lower plane (S_(d-1)), d for the upper one (S_d)
-          if (iB1 > iB0) {
-            const int jl = d - 1, ju = d;
-            const bool ok = r_live && (half ? ju <= h : jl <= h);
-            const unsigned r16 = r16_0 + (unsigned)(16 * nsl) * (unsigned)((half ? ju : jl) & 1);
-            sweep(std::false_type{}, LSTRIDE, iB0, iB1, r16, ok ? recv_c + (1 - d) * (1 - d) + (half ? 1 - 2 * (1 - d) : 0) : 0x100000);
+#pragma unroll
+          for (int pp = 0; pp < NP; pp++) {
+            // plane A (above): the lower receiver plane sees it at jz = -d (slice S_d, rhat_z negated), the upper one at
+            // 1-d (S_(d-1)); |r-e|^2 of the upper plane's receivers differs by 1 - 2 e'z
+            if (i1[2 * pp] > i0[2 * pp]) {
+              const int jl = d, ju = d - 1;
+              const bool ok = r_live[pp] && (half ? ju <= h : jl <= h);
+              const unsigned r16 = r16_0 + (unsigned)(16 * nsl) * (unsigned)((half ? ju : jl) & 1);
+              sweep(std::true_type{}, TT[pp], (2 * pp) * LSTRIDE, i0[2 * pp], i1[2 * pp], r16,
+                    ok ? recv_c + d * d + (half ? 1 - 2 * d : 0) : 0x100000);
+            }
+            // plane B (below): jz = d-1 for the lower plane (S_(d-1)), d for the upper one (S_d)
+            if (i1[2 * pp + 1] > i0[2 * pp + 1]) {
+              const int jl = d - 1, ju = d;
+              const bool ok = r_live[pp] && (half ? ju <= h : jl <= h);
+              const unsigned r16 = r16_0 + (unsigned)(16 * nsl) * (unsigned)((half ? ju : jl) & 1);
+              sweep(std::false_type{}, TT[pp], (2 * pp + 1) * LSTRIDE, i0[2 * pp + 1], i1[2 * pp + 1], r16,
+                    ok ? recv_c + (1 - d) * (1 - d) + (half ? 1 - 2 * (1 - d) : 0) : 0x100000);
+            }
           }
           VH_STAMP(3);
           __syncthreads();   // everyone done reading before the lists or the slices are refilled
@@ -601,11 +637,13 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
       cnt_tested = cnt_voted = cnt_lanes = 0;
 #endif
 
-      if (r_live) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) __builtin_nontemporal_store(T[k], &ten[k * nvox + rc]);   // written once, not read here
-      }
-    }   // next pair of receiver planes of the run
+      for (int pp = 0; pp < NP; pp++)
+        if (r_live[pp]) {
+#pragma unroll
+          for (int k = 0; k < 6; k++) __builtin_nontemporal_store(TT[pp][k], &ten[k * nvox + rc[pp]]);   // written once, not read here
+        }
+    }   // next pass of the run
   }   // next unit
 #ifdef VH_TV_STAMPS
   VH_STAMP(5);
@@ -655,7 +693,7 @@ int dev_tv_pair(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* t
   if (nblk > 0x7fffffffLL) return fail(VISFD_HIP_EINVAL, "volume too large for one launch");
   if (nblk <= 0) { *handled = true; return VISFD_HIP_OK; }
   const size_t lds = 2 * slice_bytes;
-  const size_t lds_static = (sizeof(float4) + sizeof(uint2) + (mask_src ? sizeof(float) : 0)) * 2 * LSTRIDE + 2048;
+  const size_t lds_static = (sizeof(float4) + sizeof(uint2) + (mask_src ? sizeof(float) : 0)) * NLIST * LSTRIDE + 2048;
   if (lds + lds_static > 150 * 1024) return VISFD_HIP_OK;   // window too wide: the caller falls back
   unsigned* counter = nullptr;
   VH_TRY(ws(ctx, WS_COUNTER, 16, &counter));
@@ -667,7 +705,7 @@ int dev_tv_pair(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* t
   if (ctx->opt.tv_max_wg > 0 && ngrid > ctx->opt.tv_max_wg) ngrid = ctx->opt.tv_max_wg;
   if (ngrid > nblk) ngrid = nblk;
   unsigned char* scratch = nullptr;
-  const size_t per_wg = (size_t)(n + 1) * R * (mask_src ? 24 : 20);
+  const size_t per_wg = (size_t)(n + 2 * NP - 1) * R * (mask_src ? 24 : 20);
   if ((size_t)ngrid * per_wg > ((size_t)16 << 30)) ngrid = (i64)(((size_t)16 << 30) / per_wg);
   for (; ngrid >= 1; ngrid /= 2) {
     if (ws(ctx, WS_TVSCRATCH, per_wg * (size_t)ngrid, &scratch) == VISFD_HIP_OK) break;
