@@ -37,11 +37,12 @@ namespace {
 #endif
 constexpr int NT = VH_PAIR_NT;
 constexpr int NW = NT / 64;
-// RECEIVERS PER LANE.  A wave's patch is 8 x 4 receivers (x 2 mirrored planes); with TX = 16 every lane owns the receivers at x
-// and x + 8 of a 16 x 4 patch (NS = 2 sub-patches).  Both see the same list entries, so the position words and the sender's
-// {saliency, normal} are read from LDS once for two votes (the LDS pipe is the kernel's second limiter: ~11 LDS cycles per
-// vote against ~50 issue cycles per SIMD and four SIMDs per CU), and the region a tile lists shrinks from 7.0 to 4.4 voxels
-// per receiver column.
+// RECEIVERS PER LANE (build parameter).  A wave's patch is 8 x 4 receivers (x 2 mirrored planes).  With VH_PAIR_TX = 16 every
+// lane owns the receivers at x and x + 8 of a 16 x 4 patch (NS = 2 sub-patches, one receiver pair per pass): both see the
+// same list entries, so a sender's position word and {saliency, normal} are read from LDS once for two votes and a tile
+// lists 4.4 instead of 7.0 region voxels per receiver column.  Measured at 1024^3: 400 ms against 395 ms for the 8-wide
+// tile with two receiver pairs per pass (the listing share falls from 0.09 to 0.06 of a wave's time, the sweep grows by as
+// much: 1.78 instead of 1.44 tests per vote step) -- kept as a parameter, not the default (profiles/r03_tv_design.txt).
 #ifndef VH_PAIR_TX
 #define VH_PAIR_TX 8
 #endif
@@ -196,12 +197,18 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
     const int lrow = (l5 < 8) ? 0 : (l5 < 16) ? 1 : (l5 < 24) ? 2 : 3;
     const int lcol = (l5 & 3) + (((0xc33cu >> (l5 >> 1)) & 1u) ? 4 : 0);   // lane pairs 2-5, 8-9, 14-15 (lanes 4-11, 16-19, 28-31): the right block
     const int lx = lcol, ly = wave * 4 + lrow;
-    const int rx = x0 + lx, ry = y0 + ly;
-    const bool r_in = rx < p.nx && ry < p.ny;
+    const int rx = x0 + lx, ry = y0 + ly;             // (sub-patch s: column rx + 8 s)
+    bool r_in[NS];
     // distance test as one dot product (tv_tiled.hip):  |r'-e'|^2 - h^2 - 1 = (-2r'x, -2r'y, -128, 1).(e'x, e'y, -q, m) + (|r'|^2 - h^2 - 1)
-    const int rpx = lx - TX / 2, rpy = ly - TY / 2;
-    const unsigned recv4 = (unsigned)((-2 * rpx) & 0xff) | ((unsigned)((-2 * rpy) & 0xff) << 8) | (0x80u << 16) | (1u << 24);
-    const int recv_c = rpx * rpx + rpy * rpy - h * h - 1;
+    unsigned recv4[NS];
+    int recv_c[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+      r_in[s] = rx + 8 * s < p.nx && ry < p.ny;
+      const int rpx = lx + 8 * s - TX / 2, rpy = ly - TY / 2;
+      recv4[s] = (unsigned)((-2 * rpx) & 0xff) | ((unsigned)((-2 * rpy) & 0xff) << 8) | (0x80u << 16) | (1u << 24);
+      recv_c[s] = rpx * rpx + rpy * rpy - h * h - 1;
+    }
     constexpr unsigned NEVER_HIT = 0x009c0000u;
     const unsigned r16_0 = lds_addr(slices) + (unsigned)(16 * ((ly + 2 * h) * SP + lx + 2 * h));   // table entry of j = 0.. in slot 0
     const unsigned ent_base = lds_addr(l_ent);
@@ -383,70 +390,93 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
       if (tid == 0) plane_cnt[slot] = total;
     };
 
-    float TT[NP][6];
+    float TT[NP][NS][6];
 #ifdef VH_TV_COUNT
     unsigned cnt_tested = 0, cnt_voted = 0, cnt_lanes = 0;
 #endif
 
     // ---- the SWEEP over list entries [i0, i1) of one list (base = its first LDS entry), in list order ------------------
-    // r16: this lane's table base in its slice slot; rcl: its accumulator operand of the distance test (large: never hit)
-    auto sweep = [&](auto ZN, float (&T)[6], int base, int i0, int i1, unsigned r16, int rcl) {
+    // r16: this lane's table base in its slice slot (sub-patch s: 128 bytes further); rcl[s]: its accumulator operand of the
+    // distance test (large: never hit)
+    auto sweep = [&](auto ZN, float (&T)[NS][6], int base, int i0, int i1, unsigned r16, const int (&rcl)[NS]) {
       constexpr bool ZNEG = decltype(ZN)::value;
-      auto vote_one = [&](unsigned ent, int k, int s, unsigned e16) {
-        const f4v tw = *lds_ptr<f4v>(r16 - e16);
+      auto vote_sub = [&](auto SUB, const f4v& d, int s, unsigned e16) {
+        constexpr int sub = decltype(SUB)::value;
+#if defined(VH_PAIR_ABLATE) && (VH_PAIR_ABLATE & 1)   // development: no table read (wrong results): what do the LDS reads of a vote cost?
+        const float e16f = __builtin_bit_cast(float, e16 + r16);
+        const f4v tw = {e16f, d.y, e16f, d.z};
+#else
+        const f4v tw = *lds_ptr<f4v>(r16 - e16 + 128u * sub);   // (the constant is the instruction's offset field)
+#endif
         float fv = tw.x;
         if (MASKED_SRC) fv = fv * l_mv[s];
-        const f4v d = *lds_ptr<f4v>(ent + 16u * (unsigned)k);
-        vote_fma<MODE, ZNEG>(T, d.x, fv, tw.y, tw.z, tw.w, d.y, d.z, d.w);
+        vote_fma<MODE, ZNEG>(T[sub], d.x, fv, tw.y, tw.z, tw.w, d.y, d.z, d.w);
       };
       auto batch = [&](const uint4& ca, const uint4& cb, unsigned ent, int s0) {
-        int d0, d1, d2, d3;
-        asm("v_dot4_i32_i8 %0, %4, %6, %5\n\t"
-            "v_dot4_i32_i8 %1, %4, %7, %5\n\t"
-            "v_dot4_i32_i8 %2, %4, %8, %5\n\t"
-            "v_dot4_i32_i8 %3, %4, %9, %5"
-            : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
-            : "v"(recv4), "v"(rcl), "v"(ca.x), "v"(ca.z), "v"(cb.x), "v"(cb.z));
-#ifndef VH_PAIR_PREFETCH
-#define VH_PAIR_PREFETCH 0
-#endif
-#if VH_PAIR_PREFETCH
-        // the LDS reads of a vote are requested one vote ahead, for ALL lanes (a lane the sender does not reach reads some
-        // word of LDS -- or zero beyond the allocation -- and never uses it): the round trip of a vote's two reads hides
-        // under the arithmetic of the vote before it
-        auto rd_t = [&](unsigned e16) -> f4v { return *lds_ptr<f4v>(r16 - e16); };
-        auto rd_e = [&](int k) -> f4v { return *lds_ptr<f4v>(ent + 16u * (unsigned)k); };
-        auto vote_v = [&](const f4v& tw, const f4v& d, int s) {
-          float fv = tw.x;
-          if (MASKED_SRC) fv = fv * l_mv[s];
-          vote_fma<MODE, ZNEG>(T, d.x, fv, tw.y, tw.z, tw.w, d.y, d.z, d.w);
-        };
-        f4v t0 = rd_t(ca.y), e0 = rd_e(0);
-        f4v t1 = rd_t(ca.w), e1 = rd_e(1);
-        if (__builtin_expect(d0 < 0, 1)) vote_v(t0, e0, s0);
-        t0 = rd_t(cb.y); e0 = rd_e(2);
-        if (__builtin_expect(d1 < 0, 1)) vote_v(t1, e1, s0 + 1);
-        t1 = rd_t(cb.w); e1 = rd_e(3);
-        if (__builtin_expect(d2 < 0, 1)) vote_v(t0, e0, s0 + 2);
-        if (__builtin_expect(d3 < 0, 1)) vote_v(t1, e1, s0 + 3);
+        if constexpr (NS == 1) {
+          int d0, d1, d2, d3;
+          asm("v_dot4_i32_i8 %0, %4, %6, %5\n\t"
+              "v_dot4_i32_i8 %1, %4, %7, %5\n\t"
+              "v_dot4_i32_i8 %2, %4, %8, %5\n\t"
+              "v_dot4_i32_i8 %3, %4, %9, %5\n\t"
+            "s_nop 2"
+              : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
+              : "v"(recv4[0]), "v"(rcl[0]), "v"(ca.x), "v"(ca.z), "v"(cb.x), "v"(cb.z));
+          auto vote_one = [&](int k, int s, unsigned e16) {
+#if defined(VH_PAIR_ABLATE) && (VH_PAIR_ABLATE & 2)   // development: no entry read (wrong results)
+            const float ef = __builtin_bit_cast(float, e16);
+            const f4v d = {ef, ef, ef, ef};
 #else
-        if (__builtin_expect(d0 < 0, 1)) vote_one(ent, 0, s0, ca.y);
-        if (__builtin_expect(d1 < 0, 1)) vote_one(ent, 1, s0 + 1, ca.w);
-        if (__builtin_expect(d2 < 0, 1)) vote_one(ent, 2, s0 + 2, cb.y);
-        if (__builtin_expect(d3 < 0, 1)) vote_one(ent, 3, s0 + 3, cb.w);
+            const f4v d = *lds_ptr<f4v>(ent + 16u * (unsigned)k);
 #endif
+            vote_sub(std::integral_constant<int, 0>{}, d, s, e16);
+          };
+          if (__builtin_expect(d0 < 0, 1)) vote_one(0, s0, ca.y);
+          if (__builtin_expect(d1 < 0, 1)) vote_one(1, s0 + 1, ca.w);
+          if (__builtin_expect(d2 < 0, 1)) vote_one(2, s0 + 2, cb.y);
+          if (__builtin_expect(d3 < 0, 1)) vote_one(3, s0 + 3, cb.w);
 #ifdef VH_TV_COUNT
-        {
-          const int dd[4] = {d0, d1, d2, d3};
+          {
+            const int dd[4] = {d0, d1, d2, d3};
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const unsigned long long b = __builtin_amdgcn_ballot_w64(dd[k] < 0);
-            cnt_tested += 1;
-            cnt_voted += b ? 1 : 0;
-            cnt_lanes += __builtin_popcountll(b);
+            for (int k = 0; k < 4; k++) {
+              const unsigned long long b = __builtin_amdgcn_ballot_w64(dd[k] < 0);
+              cnt_tested += 1;
+              cnt_voted += b ? 1 : 0;
+              cnt_lanes += __builtin_popcountll(b);
+            }
           }
-        }
 #endif
+        } else {
+          // two receivers per lane: both distance tests, then ONE read of the sender for the lanes either of them reaches
+          auto entry = [&](int k, int s, unsigned posw, unsigned e16) {
+            int da, db;
+            // (a dot result may be read by another kind of vector instruction three wait states later at the earliest,
+            // and the compiler does not see hazards inside an asm block: the s_nop is part of it)
+            asm("v_dot4_i32_i8 %0, %2, %6, %3\n\t"
+                "v_dot4_i32_i8 %1, %4, %6, %5\n\t"
+                "s_nop 2"
+                : "=&v"(da), "=&v"(db)
+                : "v"(recv4[0]), "v"(rcl[0]), "v"(recv4[NS - 1]), "v"(rcl[NS - 1]), "v"(posw));
+            if (__builtin_expect((da | db) < 0, 1)) {
+              const f4v d = *lds_ptr<f4v>(ent + 16u * (unsigned)k);
+              if (da < 0) vote_sub(std::integral_constant<int, 0>{}, d, s, e16);
+              if (db < 0) vote_sub(std::integral_constant<int, NS - 1>{}, d, s, e16);
+            }
+#ifdef VH_TV_COUNT
+            {
+              const unsigned long long ba = __builtin_amdgcn_ballot_w64(da < 0), bb = __builtin_amdgcn_ballot_w64(db < 0);
+              cnt_tested += 2;
+              cnt_voted += (ba ? 1 : 0) + (bb ? 1 : 0);
+              cnt_lanes += __builtin_popcountll(ba) + __builtin_popcountll(bb);
+            }
+#endif
+          };
+          entry(0, s0, ca.x, ca.y);
+          entry(1, s0 + 1, ca.z, ca.w);
+          entry(2, s0 + 2, cb.x, cb.y);
+          entry(3, s0 + 3, cb.z, cb.w);
+        }
       };
       int s0 = base + (i0 & ~1);
       const int send = base + i1;
@@ -496,16 +526,20 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
       cached_hi = sz_hi;
 
       // this lane's receivers: plane rz + 2 pp + half of pair pp
-      i64 rc[NP];
-      bool r_live[NP];
+      i64 rc[NP];                // (sub-patch s: rc + 8 s)
+      bool r_live[NP][NS];
 #pragma unroll
       for (int pp = 0; pp < NP; pp++) {
         const int rzl = rz + 2 * pp + half;
         const bool z_in = rzl < z_run1;
         rc[pp] = (i64)rzl * plane + (i64)ry * p.nx + rx;
-        r_live[pp] = r_in && z_in && !(mask_dst && mask_dst[(r_in && z_in) ? rc[pp] : 0] == 0.0f);
 #pragma unroll
-        for (int k = 0; k < 6; k++) TT[pp][k] = 0.0f;
+        for (int s = 0; s < NS; s++) {
+          const bool in = r_in[s] && z_in;
+          r_live[pp][s] = in && !(mask_dst && mask_dst[in ? rc[pp] + 8 * s : 0] == 0.0f);
+#pragma unroll
+          for (int k = 0; k < 6; k++) TT[pp][s][k] = 0.0f;
+        }
       }
       __syncthreads();   // ring entries and counts of this pass are visible
       VH_STAMP(0);
@@ -608,22 +642,29 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
             // 1-d (S_(d-1)); |r-e|^2 of the upper plane's receivers differs by 1 - 2 e'z
             if (i1[2 * pp] > i0[2 * pp]) {
               const int jl = d, ju = d - 1;
-              const bool ok = r_live[pp] && (half ? ju <= h : jl <= h);
+              const bool zok = half ? ju <= h : jl <= h;
               const unsigned r16 = r16_0 + (unsigned)(16 * nsl) * (unsigned)((half ? ju : jl) & 1);
-              sweep(std::true_type{}, TT[pp], (2 * pp) * LSTRIDE, i0[2 * pp], i1[2 * pp], r16,
-                    ok ? recv_c + d * d + (half ? 1 - 2 * d : 0) : 0x100000);
+              int rcl[NS];
+#pragma unroll
+              for (int s = 0; s < NS; s++) rcl[s] = (r_live[pp][s] && zok) ? recv_c[s] + d * d + (half ? 1 - 2 * d : 0) : 0x100000;
+              sweep(std::true_type{}, TT[pp], (2 * pp) * LSTRIDE, i0[2 * pp], i1[2 * pp], r16, rcl);
             }
             // plane B (below): jz = d-1 for the lower plane (S_(d-1)), d for the upper one (S_d)
             if (i1[2 * pp + 1] > i0[2 * pp + 1]) {
               const int jl = d - 1, ju = d;
-              const bool ok = r_live[pp] && (half ? ju <= h : jl <= h);
+              const bool zok = half ? ju <= h : jl <= h;
               const unsigned r16 = r16_0 + (unsigned)(16 * nsl) * (unsigned)((half ? ju : jl) & 1);
-              sweep(std::false_type{}, TT[pp], (2 * pp + 1) * LSTRIDE, i0[2 * pp + 1], i1[2 * pp + 1], r16,
-                    ok ? recv_c + (1 - d) * (1 - d) + (half ? 1 - 2 * (1 - d) : 0) : 0x100000);
+              int rcl[NS];
+#pragma unroll
+              for (int s = 0; s < NS; s++)
+                rcl[s] = (r_live[pp][s] && zok) ? recv_c[s] + (1 - d) * (1 - d) + (half ? 1 - 2 * (1 - d) : 0) : 0x100000;
+              sweep(std::false_type{}, TT[pp], (2 * pp + 1) * LSTRIDE, i0[2 * pp + 1], i1[2 * pp + 1], r16, rcl);
             }
           }
           VH_STAMP(3);
+#if !(defined(VH_PAIR_ABLATE) && (VH_PAIR_ABLATE & 4))   // (development: without it lists are refilled under the readers -- wrong results)
           __syncthreads();   // everyone done reading before the lists or the slices are refilled
+#endif
           VH_STAMP(4);
         }
       }
@@ -639,10 +680,12 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
 
 #pragma unroll
       for (int pp = 0; pp < NP; pp++)
-        if (r_live[pp]) {
 #pragma unroll
-          for (int k = 0; k < 6; k++) __builtin_nontemporal_store(TT[pp][k], &ten[k * nvox + rc[pp]]);   // written once, not read here
-        }
+        for (int s = 0; s < NS; s++)
+          if (r_live[pp][s]) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) __builtin_nontemporal_store(TT[pp][s][k], &ten[k * nvox + rc[pp] + 8 * s]);   // written once, not read here
+          }
     }   // next pass of the run
   }   // next unit
 #ifdef VH_TV_STAMPS

@@ -330,7 +330,8 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
         asm("v_dot4_i32_i8 %0, %4, %6, %5\n\t"
             "v_dot4_i32_i8 %1, %4, %7, %5\n\t"
             "v_dot4_i32_i8 %2, %4, %8, %5\n\t"
-            "v_dot4_i32_i8 %3, %4, %9, %5"
+            "v_dot4_i32_i8 %3, %4, %9, %5\n\t"
+            "s_nop 2"
             : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
             : "v"(recv4), "v"(recv_c_live), "v"(ca.x), "v"(ca.z), "v"(cb.x), "v"(cb.z));
         // most tested senders vote (the list is already cut to the rows the wave can reach): votes on the fall-through path
