@@ -234,8 +234,26 @@ def main():
     h_tv = int(math.floor(np.float32(sigma_tv) * np.float32(math.sqrt(2.0))))
     # world > 1: the library's own slab handle (csrc/slab.hip behind the C ABI: RCCL halos on a transfer stream, overlapped
     # interior votes, device-side histogram all-reduce); it doubles as the layout object
+    halo_transport = "none"
     if world > 1:
-        layout = slab.make_slab(ctx, rank, world, NZ * world, max(h_tv, 12))
+        # every rank must end up on the same path: agree on whether the library's communicator came up everywhere; if not,
+        # the slab stages run on visfd_amd/slab.py's orchestration (torch.distributed point-to-point on device memory)
+        try:
+            layout = slab.make_slab(ctx, rank, world, NZ * world, max(h_tv, 12))
+            up = 1
+        except Exception as e:   # noqa: BLE001
+            sys.stderr.write("bench: library-owned slab transport unavailable on rank %d (%r)\n" % (rank, e))
+            layout, up = None, 0
+        flag = torch.tensor([up], device=device if own_gpu else "cpu", dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()):
+            halo_transport = ("rccl (library-owned communicator, csrc/slab.hip)" if own_gpu
+                              else "gloo-staged callbacks (shared GPU rehearsal)")
+        else:
+            if layout is not None:
+                layout.close()
+            layout = slab.SlabLayout(NZ * world, rank, world, ghost=max(h_tv, 12))
+            halo_transport = "torch.distributed point-to-point (visfd_amd/slab.py)"
     else:
         layout = slab.SlabLayout(NZ, 0, 1, ghost=max(h_tv, 12))
     shape = (layout.nz_local, S, S)
@@ -521,8 +539,7 @@ def main():
                                     "1e-5 of the field's scale, tests/test_tolerance_modes.py); every LoG, the non-max scan and "
                                     "the radix select stay bit-exact.  exact: bit-exact kernels everywhere",
                        "per_gpu_voxels": nvox_rank, "decomposition": "z-slabs, ghost %d" % layout.ghost,
-                       "halo_transport": "none" if world == 1 else ("rccl (library-owned communicator, csrc/slab.hip)" if own_gpu
-                                                                    else "gloo-staged callbacks (shared GPU rehearsal)")},
+                       "halo_transport": halo_transport},
             "stages_ms": headline["stages_ms"],
             "results": headline["results"],
             "modes": {args.mode: headline, other_mode: other},
@@ -545,7 +562,8 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
-        layout.close()      # the slab handle (its RCCL communicator and transfer stream) before the context it points to
+        if hasattr(layout, "close"):
+            layout.close()  # the slab handle (its RCCL communicator and transfer stream) before the context it points to
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

@@ -491,6 +491,12 @@ int visfd_hip_membrane_detect_slab_dev(visfd_hip_slab*, float* src, float* sal, 
                                        int64_t nx, int64_t ny, float sigma, float truncate_ratio, int eival_order,
                                        float best_fraction, float sigma_tv, int exponent, float tv_truncate_ratio,
                                        int src_halo_ready, float* threshold_out);
+/* The same for a host whose volume lives in HOST memory (filter_mrc started once per GPU, `-slab`): src_owned / sal_owned
+ * are the rank's OWNED planes [z0, z1) only ([z1-z0][ny][nx]); tensor_owned (may be NULL) receives six interleaved floats per
+ * owned voxel, as visfd_hip_membrane_detect returns them.  Device arrays (12 slab volumes) live for the call only. */
+int visfd_hip_membrane_detect_slab(visfd_hip_slab*, const float* src_owned, int64_t nx, int64_t ny, float sigma,
+                                   float truncate_ratio, int eival_order, float best_fraction, float sigma_tv, int exponent,
+                                   float tv_truncate_ratio, float* sal_owned, float* tensor_owned, float* threshold_out);
 /* BlobDog (lib/visfd/feature.hpp:53-427) on one slab with absolute thresholds: blobs of the OWNED planes only, iz as
  * GLOBAL plane index.  The host merges the ranks' lists (and applies ratio thresholds, which need the global best). */
 int visfd_hip_blob_dog_slab_dev(visfd_hip_slab*, float* src, int64_t nx, int64_t ny, const float* blob_sigma, int n_sigma,

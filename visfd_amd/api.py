@@ -138,6 +138,8 @@ _SIGS = {
     "visfd_hip_slab_exchange_dev": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, _i64, _i64, C.c_int]),
     "visfd_hip_membrane_detect_slab_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, C.c_float, C.c_float, C.c_int,
                                                      C.c_float, C.c_float, C.c_int, C.c_float, C.c_int, _fp]),
+    "visfd_hip_membrane_detect_slab": (C.c_int, [_vp, _vp, _i64, _i64, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float,
+                                                 C.c_int, C.c_float, _vp, _vp, _fp]),
     "visfd_hip_blob_dog_slab_dev": (C.c_int, [_vp, _vp, _i64, _i64, _fp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
                                               C.c_int, _vp, _i64, C.POINTER(_i64), _vp, _i64, C.POINTER(_i64)]),
 }
@@ -882,6 +884,21 @@ class Slab:
             self._h, _dev(src), _dev(sal), _dev(dirs), _dev(tensor), _dev(scratch), nx, ny, float(sigma), float(ratio), int(order),
             float(best_fraction), float(sigma_tv), int(exponent), float(cutoff), int(bool(src_halo_ready)), C.byref(thr)))
         return float(thr.value)
+
+    def membrane_detect_host(self, src_owned, sigma, ratio, order, best_fraction, sigma_tv, exponent=4, cutoff=2.0 ** 0.5,
+                             want_tensor=False):
+        """visfd_hip_membrane_detect_slab: the slab stage on HOST arrays of the rank's owned planes (numpy float32
+        [z1-z0][ny][nx]).  Returns (saliency of the owned planes, tensor [..., 6] or None, threshold)."""
+        src_owned = np.ascontiguousarray(src_owned, np.float32)
+        nzo, ny, nx = src_owned.shape
+        assert nzo == self.z1 - self.z0
+        sal = np.empty_like(src_owned)
+        ten = np.empty(src_owned.shape + (6,), np.float32) if want_tensor else None
+        thr = C.c_float()
+        self.ctx._chk(self._L.visfd_hip_membrane_detect_slab(
+            self._h, _np(src_owned), nx, ny, float(sigma), float(ratio), int(order), float(best_fraction), float(sigma_tv),
+            int(exponent), float(cutoff), _np(sal), _np(ten), C.byref(thr)))
+        return sal, ten, float(thr.value)
 
     def blob_dog(self, src, sigmas, delta=0.02, ratio=2.5, minima_threshold=np.inf, maxima_threshold=-np.inf,
                  src_halo_ready=False, cap=1 << 22):

@@ -418,6 +418,49 @@ int visfd_hip_membrane_detect_slab_dev(visfd_hip_slab* s, float* src, float* sal
   return dev_tensor_saliency(ctx, tensor, nullptr, nvl, order, sal);
 }
 
+// The same stage for a host that keeps its volume in HOST memory (the filter_mrc program started once per GPU): the owned
+// planes go up, the slab stage runs, the owned planes of the score (and, if asked for, of the vote tensors, six interleaved
+// floats per voxel as visfd_hip_membrane_detect returns them) come back.  Device arrays live for the call only.
+int visfd_hip_membrane_detect_slab(visfd_hip_slab* s, const float* src_owned, int64_t nx, int64_t ny, float sigma, float ratio,
+                                   int order, float best_fraction, float sigma_tv, int exponent, float cutoff,
+                                   float* sal_owned, float* tensor_owned, float* thr_out) {
+  VH_REQUIRE(s && src_owned && sal_owned, "null argument");
+  visfd_hip_ctx* ctx = s->ctx;
+  VH_HIP(hipSetDevice(ctx->device));
+  const i64 nzl = s->nz_local, plane = nx * ny, nvl = plane * nzl, nown = (s->own1 - s->own0) * plane;
+  VH_TRY(check_dims(nx, ny, nzl));
+  struct Block {
+    float* p = nullptr;
+    ~Block() { if (p) (void)hipFree(p); }
+  } blk;
+  const size_t total = (size_t)nvl * 12 + (tensor_owned ? (size_t)nown * 12 : 0);
+  if (hipMalloc(&blk.p, total * sizeof(float)) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(VISFD_HIP_ENOMEM, "membrane_detect_slab: device allocation of 12 slab volumes failed");
+  }
+  float* src = blk.p;
+  float* sal = src + nvl;
+  float* dirs = sal + nvl;
+  float* ten = dirs + 3 * nvl;
+  float* scratch = ten + 6 * nvl;
+  VH_HIP(hipMemsetAsync(src, 0, sizeof(float) * (size_t)nvl, ctx->stream));     // ghost planes: filled by the exchange
+  VH_HIP(hipMemcpyAsync(src + s->own0 * plane, src_owned, sizeof(float) * (size_t)nown, hipMemcpyHostToDevice, ctx->stream));
+  VH_TRY(visfd_hip_membrane_detect_slab_dev(s, src, sal, dirs, ten, scratch, nx, ny, sigma, ratio, order, best_fraction, sigma_tv,
+                                            exponent, cutoff, 0, thr_out));
+  VH_HIP(hipMemcpyAsync(sal_owned, sal + s->own0 * plane, sizeof(float) * (size_t)nown, hipMemcpyDeviceToHost, ctx->stream));
+  if (tensor_owned) {
+    float* packed = scratch + nvl;          // [6][nown] planar, then [nown][6]
+    float* aos = packed + 6 * nown;
+    for (int c = 0; c < 6; c++)
+      VH_HIP(hipMemcpyAsync(packed + (size_t)c * nown, ten + (size_t)c * nvl + s->own0 * plane, sizeof(float) * (size_t)nown,
+                            hipMemcpyDeviceToDevice, ctx->stream));
+    VH_TRY(dev_planar_to_interleaved(ctx, packed, aos, nown, 6, nullptr));
+    VH_HIP(hipMemcpyAsync(tensor_owned, aos, sizeof(float) * 6 * (size_t)nown, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  VH_HIP(hipStreamSynchronize(ctx->stream));
+  return VISFD_HIP_OK;
+}
+
 // BlobDog (feature.hpp:53-427) on one slab: the lists hold the blobs of OWNED planes only, iz as GLOBAL plane index;
 // merging the ranks' lists (and ratio thresholds, which need the global best score) is the host's job.
 int visfd_hip_blob_dog_slab_dev(visfd_hip_slab* s, float* src, int64_t nx, int64_t ny, const float* blob_sigma, int n_sigma,

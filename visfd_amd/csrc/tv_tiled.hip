@@ -54,8 +54,17 @@ static_assert(TY <= 64, "row coordinates relative to the tile centre are packed 
 #ifndef VH_TV_CAP
 #define VH_TV_CAP 256
 #endif
-constexpr int CAP = VH_TV_CAP;       // list entries held in LDS per sweep (one per thread)
-static_assert(CAP <= NT, "the replay loads one entry per thread");
+constexpr int CAP = VH_TV_CAP;       // list entries held in LDS per sweep and list (one per thread of the list's share)
+// RECEIVER PAIRS PER PASS (round 3, as tv_pair.hip).  The sender planes the pairs (z, z+1) and (z+2, z+3) meet at step t of their
+// ascending jz are different planes, but jz -- and so the two table slices -- are the same: with NP = 2 a workgroup takes both
+// pairs through the steps together (two lists, two sweeps per barrier interval, each wave 2 x 6 sums).  Every receiver still
+// takes its votes in the reference's order; only the interleaving of DIFFERENT receivers' sums changes.
+#ifndef VH_TV_NP
+#define VH_TV_NP 2
+#endif
+constexpr int NP = (VH_TV_NP * CAP <= NT) ? VH_TV_NP : 1;
+static_assert(NP * CAP <= NT, "the replay loads one entry per thread");
+constexpr int LST = CAP + 8;         // l_pos entries per list (8 never-hit entries of slack behind each list)
 constexpr int RING_BYTES = 32;       // bytes per entry of the scratch rings
 constexpr unsigned OOB = 0x7ffffff0u;  // byte offset beyond any plane descriptor: reads give 0
 
@@ -148,13 +157,13 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
   //             slack past the list hold a never-hit operand, so the sweep runs in whole batches of four and may
   //             prefetch one batch past the end
   //   l_mv[e]   source-mask value of the entry (masked kernels)
-  __shared__ __attribute__((aligned(16))) float4 l_ent[CAP];
-  __shared__ __attribute__((aligned(16))) uint2 l_pos[CAP + 8];
-  __shared__ float l_mv[MASKED_SRC ? CAP : 1];
+  __shared__ __attribute__((aligned(16))) float4 l_ent[NP * CAP];
+  __shared__ __attribute__((aligned(16))) uint2 l_pos[NP * LST];
+  __shared__ float l_mv[MASKED_SRC ? NP * CAP : 1];
   __shared__ int wave_tot[2][NW];
-  __shared__ int cull[CAP / 64][2 * NW];     // per wave holding entries: entries above / not below the rows each wave can reach
+  __shared__ int cull[NP][CAP / 64][2 * NW]; // per list and wave holding entries: entries above / not below the rows each wave can reach
   __shared__ unsigned claimed_tile;
-  __shared__ int plane_cnt[84];              // entries per ring slot, [2h+2] (h <= 40)
+  __shared__ int plane_cnt[88];              // entries per ring slot, [2h + 2 NP] (h <= 40)
   // dynamic LDS: two table slices (jz and jz + 1 of the current sender plane), [2][(2h+1)^2] float4
   extern __shared__ __attribute__((aligned(16))) unsigned char slices[];
 
@@ -172,7 +181,7 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
   const i64 nvox = plane * p.nz;
   const int plane_bytes = (int)(plane * 4);
   const size_t plane_stride = (size_t)R * RING_BYTES;
-  const int P = S + 1;           // sender planes a pair of receiver planes reaches = slots of the ring
+  const int P = S + 2 * NP - 1;  // sender planes the receiver planes of a pass reach = slots of the ring
   unsigned char* const ring = scratch + (size_t)blockIdx.x * plane_stride * P;
   int npar = 0;                  // parity of the wave-total buffers
 
@@ -303,17 +312,17 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
       if (tid == 0) plane_cnt[slot] = total;
     };
 
-    float T[6];
-    int recv_c_live = 0x100000;   // receivers that take no votes never hit: their accumulator operand is large and positive
+    float TT[NP][6];
 
-    // ---- the SWEEP over list entries [i0, i1), in vote order -------------------------------------------------
-    auto sweep = [&](int i0, int i1) {
+    // ---- the SWEEP over entries [i0, i1) of list li, in vote order, into the sums T --------------------------
+    // recv_c_live: this lane's accumulator operand of the distance test (receivers that take no votes never hit: large, positive)
+    auto sweep = [&](float (&T)[6], int li, int i0, int i1, int recv_c_live) {
       // the table entry is requested together with the sender's own data: its address needs only E, which came with
       // the batch; ent = LDS address of the batch's first entry (a vector register: DS addresses cannot be scalar)
       auto vote_one = [&](unsigned ent, int k, int s, unsigned e16) {
         const f4v tw = *lds_ptr<f4v>(r16s - e16);
         float fv = tw.x;
-        if (MASKED_SRC) fv = fv * l_mv[s];    // fv = w * mask value first (feature.hpp:2262-2275), then sal * fv
+        if (MASKED_SRC) fv = fv * l_mv[li * CAP + s];    // fv = w * mask value first (feature.hpp:2262-2275), then sal * fv
         if (MODE == 3) {
           acc(T[0], fv);                      // "denominator += filter_val" (feature.hpp:2376-2377)
         } else {
@@ -343,8 +352,8 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
       // batches of four senders, two per trip: the next batch is in flight while this one is tested and voted, and the
       // two register sets swap roles without copies
       int s0 = i0 & ~1;                      // l_pos is read two entries at a time
-      const uint4* pq = reinterpret_cast<const uint4*>(l_pos) + (s0 >> 1);
-      unsigned ent = ent_base + 16u * (unsigned)s0;
+      const uint4* pq = reinterpret_cast<const uint4*>(l_pos + li * LST) + (s0 >> 1);
+      unsigned ent = ent_base + 16u * (unsigned)(li * CAP + s0);
       asm volatile("" : "+v"(ent));
       uint4 a0 = pq[0], a1 = pq[1];
       while (s0 < i1) {   // uniform
@@ -366,35 +375,50 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
     // 64 receivers are 8 x 4 x 2 instead of 8 x 8 x 1, which a sender's ball covers better (fewer, fuller vote steps), and
     // every list is brought into LDS once per two receiver planes.  The table slices of jz and jz + 1 sit in two LDS slots
     // chosen by the parity of jz, so a step of the sender plane needs ONE new slice.
-    int cached_lo = 1, cached_hi = 0;     // sender planes whose lists are in the ring (slot of plane sz: sz mod (2h+2))
+    int cached_lo = 1, cached_hi = 0;     // sender planes whose lists are in the ring (slot of plane sz: sz mod P)
     int slot_a = 1 << 20, slot_b = 1 << 20;   // which table slice LDS slot 0 / 1 holds (uniform)
     float4* const sl4 = reinterpret_cast<float4*>(slices);
-    for (int rz = z_run0; rz < z_run1; rz += 2) {
-      // sender planes that reach the LIVE receivers of this pair: a run of odd length ends with half a pair, and nothing above
-      // rz + h is needed then -- in a slab run that plane may not even be complete yet (visfd_amd/slab.py votes the interior
-      // band while the halo planes above it are still in flight)
-      const int sz_hi = min(min(rz + 1, z_run1 - 1) + h, p.nz - 1), sz_lo = max(rz - h, 0);
-      // the window holds at most 2h+2 planes, so a plane that enters it takes the slot of one that has left
+    for (int rz = z_run0; rz < z_run1; rz += 2 * NP) {
+      // sender planes that reach the LIVE receivers of this pass: a run may end inside a pass, and nothing above the last live
+      // receiver + h is needed then -- in a slab run that plane may not even be complete yet (visfd_amd/slab.py votes the
+      // interior band while the halo planes above it are still in flight)
+      const int sz_hi = min(min(rz + 2 * NP - 1, z_run1 - 1) + h, p.nz - 1), sz_lo = max(rz - h, 0);
+      // the window holds at most P planes, so a plane that enters it takes the slot of one that has left
       for (int sz = sz_hi; sz >= sz_lo; sz--)   // uniform
         if (p.relist || sz < cached_lo || sz > cached_hi) list_plane(sz);
       cached_lo = sz_lo;
       cached_hi = sz_hi;
 
-      const int rzl = rz + half;                               // this lane's receiver plane
-      const bool z_in = rzl < z_run1;                          // (a run of odd length ends with half a pair)
-      const i64 rc = (i64)rzl * plane + (i64)ry * p.nx + rx;
-      const bool r_live = r_in && z_in && !(mask_dst && mask_dst[(r_in && z_in) ? rc : 0] == 0.0f);
+      i64 rc[NP];                                                // this lane's receiver of pair pp (plane rz + 2 pp + half)
+      bool r_live[NP];
 #pragma unroll
-      for (int k = 0; k < 6; k++) T[k] = 0.0f;
-      __syncthreads();   // ring entries and counts of this pair of receiver planes are visible
+      for (int pp = 0; pp < NP; pp++) {
+        const int rzl = rz + 2 * pp + half;
+        const bool z_in = rzl < z_run1;                          // (a run may end with half a pair, or without the second pair)
+        rc[pp] = (i64)rzl * plane + (i64)ry * p.nx + rx;
+        r_live[pp] = r_in && z_in && !(mask_dst && mask_dst[(r_in && z_in) ? rc[pp] : 0] == 0.0f);
+#pragma unroll
+        for (int k = 0; k < 6; k++) TT[pp][k] = 0.0f;
+      }
+      __syncthreads();   // ring entries and counts of this pass are visible
 
-      for (int sz = sz_hi; sz >= sz_lo; sz--) {               // jz = rz - sz ascending
-        const int slot = sz % P;
-        const int cnt = __builtin_amdgcn_readfirstlane(plane_cnt[slot]);
-        if (cnt == 0) continue;   // uniform
-        const int jz0 = rz - sz, jz1 = jz0 + 1;               // for the lower / upper receiver plane; one of them may be
-        const bool v0 = jz0 >= -h && jz0 <= h, v1 = jz1 >= -h && jz1 <= h;   // outside the window (never hit then)
-        const unsigned char* ring_plane = ring + (size_t)slot * plane_stride;
+      // step t = 0 .. 2h+1: pair pp meets sender plane (rz + 2 pp) + 1 + h - t, i.e. jz = t - h - 1 for its lower receiver plane
+      // and jz + 1 for its upper one -- ascending, as the reference visits them, and the same for every pair
+      for (int t = 0; t <= 2 * h + 1; t++) {
+        const int jz0 = t - h - 1, jz1 = jz0 + 1;              // one of them may be outside the window (never hit then)
+        const bool v0 = jz0 >= -h, v1 = jz1 <= h;
+        int lsz[NP], lcnt[NP];
+        int cmax = 0;
+#pragma unroll
+        for (int pp = 0; pp < NP; pp++) {
+          const int z = rz + 2 * pp;
+          lsz[pp] = z - jz0;
+          // (planes above the last live receiver of the pair + h are not needed, and in a slab run not there yet)
+          const bool have = z < z_run1 && lsz[pp] >= sz_lo && lsz[pp] <= min(min(z + 1, z_run1 - 1) + h, p.nz - 1);
+          lcnt[pp] = have ? __builtin_amdgcn_readfirstlane(plane_cnt[lsz[pp] % P]) : 0;
+          cmax = max(cmax, lcnt[pp]);
+        }
+        if (cmax == 0) continue;   // uniform
         // list and slices are free: every sweep ends with a barrier.  Slot of slice jz: (jz + h + 1) & 1.
         {
           const int s0 = (jz0 + h + 1) & 1, s1 = s0 ^ 1;
@@ -410,64 +434,77 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
           }
           r16s = r16_0 + (unsigned)(16 * nsl) * (unsigned)(half ? s1 : s0);
         }
-        const int epz = sz - rz;                               // sender plane relative to the LOWER receiver plane
+        const int epz = -jz0;                                  // sender plane relative to the LOWER receiver plane
         const int epz2 = epz * epz;
-        // the upper plane's receivers see the sender one plane further down: |r - e|^2 grows by 1 - 2 epz
-        recv_c_live = r_live ? recv_c + (half ? 1 - 2 * epz : 0) : 0x100000;
         // rows a wave can reach on this plane: |r'y - e'y| <= rho = floor(sqrt(h^2 - jz^2)) for the nearer of its two
         // receiver planes, r'y in [4w-16, 4w-13]
         const int jn = min(v0 ? jz0 * jz0 : (1 << 20), v1 ? jz1 * jz1 : (1 << 20));
         int rho = (int)__builtin_sqrtf((float)(h * h - jn));
         while (rho * rho > h * h - jn) rho--;
         while ((rho + 1) * (rho + 1) <= h * h - jn) rho++;
-        for (int done = 0; done < cnt; done += CAP) {          // uniform
-          const int take = min(CAP, cnt - done);
+        const int li = min(tid / CAP, NP - 1);                 // (uniform per wave) the list this thread brings entries of
+        const int ltid = tid - li * CAP;
+        const bool bringer = tid < NP * CAP;
+        int my_sz = lsz[0], my_cnt = lcnt[0];
+#pragma unroll
+        for (int k = 1; k < NP; k++)
+          if (li == k) { my_sz = lsz[k]; my_cnt = lcnt[k]; }
+        const unsigned char* ring_plane = ring + (size_t)(((my_sz % P) + P) % P) * plane_stride;
+        for (int done = 0; done < cmax; done += CAP) {          // uniform
+          const int take = bringer ? min(CAP, max(my_cnt - done, 0)) : 0;
           int epy = -128;                                      // threads without an entry: below every range
-          if (tid < take) {
-            const unsigned char* src_e = ring_plane + (size_t)(done + tid) * RING_BYTES;
+          if (ltid < take) {
+            const unsigned char* src_e = ring_plane + (size_t)(done + ltid) * RING_BYTES;
             const float4 a = *reinterpret_cast<const float4*>(src_e);
             const uint4 m = *reinterpret_cast<const uint4*>(src_e + 16);
-            l_ent[tid] = a;
+            l_ent[li * CAP + ltid] = a;
             const int e2 = (int)m.y + epz2;
-            l_pos[tid] = make_uint2(m.x | ((unsigned)((-(e2 >> 7)) & 0xff) << 16) | ((unsigned)(e2 & 127) << 24), m.z);
-            if (MASKED_SRC) l_mv[tid] = __uint_as_float(m.w);
+            l_pos[li * LST + ltid] = make_uint2(m.x | ((unsigned)((-(e2 >> 7)) & 0xff) << 16) | ((unsigned)(e2 & 127) << 24), m.z);
+            if (MASKED_SRC) l_mv[li * CAP + ltid] = __uint_as_float(m.w);
             epy = (int)(signed char)(m.x >> 8);
           }
-          if (tid < 8) l_pos[take + tid] = make_uint2(NEVER_HIT, 0u);
+          if (bringer && ltid < 8) l_pos[li * LST + take + ltid] = make_uint2(NEVER_HIT, 0u);
           // entries are in descending row order: wave w needs those from the first one at or below row 4w-13+rho to
           // the last one at or above row 4w-16-rho; the waves that hold entries count both kinds for all waves
-          if (wave < CAP / 64) {
+          if (bringer) {
 #pragma unroll
             for (int w = 0; w < NW; w++) {
               const int above = __builtin_popcountll(__builtin_amdgcn_ballot_w64(epy > 4 * w - (TY / 2 - 3) + rho));
               const int upto = __builtin_popcountll(__builtin_amdgcn_ballot_w64(epy >= 4 * w - TY / 2 - rho));
-              if (lane == 0) { cull[wave][2 * w] = above; cull[wave][2 * w + 1] = upto; }
+              if (lane == 0) { cull[li][ltid >> 6][2 * w] = above; cull[li][ltid >> 6][2 * w + 1] = upto; }
             }
           }
-          __syncthreads();   // list (and slices) complete
-          int i0 = 0, i1 = 0;
+          __syncthreads();   // lists (and slices) complete
 #pragma unroll
-          for (int w = 0; w < CAP / 64; w++) { i0 += cull[w][2 * wave]; i1 += cull[w][2 * wave + 1]; }
-          i0 = __builtin_amdgcn_readfirstlane(i0);
-          i1 = __builtin_amdgcn_readfirstlane(i1);
+          for (int pp = 0; pp < NP; pp++) {
+            int i0 = 0, i1 = 0;
+#pragma unroll
+            for (int w = 0; w < CAP / 64; w++) { i0 += cull[pp][w][2 * wave]; i1 += cull[pp][w][2 * wave + 1]; }
+            i0 = __builtin_amdgcn_readfirstlane(i0);
+            i1 = __builtin_amdgcn_readfirstlane(i1);
+            // the upper plane's receivers see the sender one plane further down: |r - e|^2 grows by 1 - 2 epz
+            const int rcl = r_live[pp] ? recv_c + (half ? 1 - 2 * epz : 0) : 0x100000;
 #if defined(VH_TV_EXP) && VH_TV_EXP == 2   // ablation (wrong results): everything but the sweeps
-          if (i0 > (1 << 20)) sweep(i0, i1);
+            if (i0 > (1 << 20)) sweep(TT[pp], pp, i0, i1, rcl);
 #else
-          sweep(i0, i1);
+            if (i1 > i0) sweep(TT[pp], pp, i0, i1, rcl);      // uniform
 #endif
-          __syncthreads();   // everyone done reading before the list or the slices are refilled
+          }
+          __syncthreads();   // everyone done reading before the lists or the slices are refilled
         }
       }
 
-      if (r_live) {
-        if (MODE == 3) {
-          ten[rc] = T[0];
-        } else {
 #pragma unroll
-          for (int k = 0; k < 6; k++) __builtin_nontemporal_store(T[k], &ten[k * nvox + rc]);   // written once, not read here
+      for (int pp = 0; pp < NP; pp++)
+        if (r_live[pp]) {
+          if (MODE == 3) {
+            ten[rc[pp]] = TT[pp][0];
+          } else {
+#pragma unroll
+            for (int k = 0; k < 6; k++) __builtin_nontemporal_store(TT[pp][k], &ten[k * nvox + rc[pp]]);   // written once, not read here
+          }
         }
-      }
-    }   // next pair of receiver planes of the run
+    }   // next pass of the run
   }   // next unit
 }
 
@@ -512,7 +549,7 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
   if (nblk > 0x7fffffffLL) return fail(VISFD_HIP_EINVAL, "volume too large for one launch");
   if (nblk <= 0) { *handled = true; return VISFD_HIP_OK; }
   const size_t lds = 2 * slice_bytes;   // dynamic part: the slices of jz and jz + 1
-  const size_t lds_static = sizeof(float4) * CAP + sizeof(uint2) * (CAP + 8) + sizeof(float) * (mask_src ? CAP : 1) + 2048;
+  const size_t lds_static = (sizeof(float4) * CAP + sizeof(uint2) * LST + sizeof(float) * (mask_src ? CAP : 0)) * NP + 2560;
   if (lds + lds_static > 150 * 1024) return VISFD_HIP_OK;   // window too wide for the LDS slice: baseline kernel
   const int mode = weights_only ? 3 : (curves ? 1 : (exponent == 4 ? 0 : (exponent == 2 ? 2 : 1)));
   // persistent workgroups (see the kernel): as many as the chip holds at once -- LDS allows 160 KB / (static +
@@ -531,7 +568,7 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
   // wide windows are capped at 16 GB (fewer workgroups: their LDS slices allow only one or two per CU anyway); if the
   // allocation fails the grid is halved, and without any ring the caller's baseline kernel takes over.
   unsigned char* scratch = nullptr;
-  const size_t per_wg = (size_t)(n + 1) * R * RING_BYTES;
+  const size_t per_wg = (size_t)(n + 2 * NP - 1) * R * RING_BYTES;
   if ((size_t)ngrid * per_wg > ((size_t)16 << 30)) ngrid = (i64)(((size_t)16 << 30) / per_wg);
   for (; ngrid >= 1; ngrid /= 2) {
     if (ws(ctx, WS_TVSCRATCH, per_wg * (size_t)ngrid, &scratch) == VISFD_HIP_OK) break;
