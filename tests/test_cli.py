@@ -490,3 +490,51 @@ def test_cli_normals_file_reference_scenario(cli, ref_cli, tmp_path):
     assert_bits_equal(a, b, "cluster labels")
     assert "element vertex 58" in pb
     assert pa == pb
+
+
+# ---- Z-slab mode of the program (one filter_mrc per GPU; no reference counterpart) ----------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("id_file", ["-", "id"])
+def test_cli_membrane_slab_mode_one_rank_equals_plain_run(cli, tmp_path, id_file):
+    """`-slab 0 1 IDFILE`: the slab stage of csrc/slab.hip through the program's host-memory entry point -- with IDFILE "-"
+    without a communicator, with a file through a one-rank RCCL communicator made from the id the program publishes there
+    (what a one-GPU box can run of the multi-process path).  The output file equals the plain run's byte for byte."""
+    inp = os.path.join(GOLDEN, "test_image_membrane.rec")
+    flags = ("-w", 19.2, "-in", inp, "-membrane", "minima", 55, "-tv", 4, "-tv-angle-exponent", 4, "-bin", 1, "-tv-best", 0.1)
+    plain, slab = tmp_path / "plain.rec", tmp_path / "slab.rec"
+    r = run(cli, *flags, "-out", plain)
+    assert r.returncode == 0, r.stderr
+    idf = "-" if id_file == "-" else str(tmp_path / "rccl.id")
+    r = run(cli, *flags, "-out", slab, "-slab", 0, 1, idf)
+    assert r.returncode == 0, r.stderr
+    assert "slab 0 of 1" in r.stderr
+    assert open(plain, "rb").read() == open(slab, "rb").read()
+    if id_file != "-":
+        assert os.path.getsize(idf) == 128
+
+
+def test_cli_slab_mode_argument_checks(cli, tmp_path):
+    inp = os.path.join(GOLDEN, "test_image_membrane.rec")
+    r = run(cli, "-in", inp, "-out", tmp_path / "o.rec", "-membrane", "minima", 55, "-tv", 4, "-slab", 2, 2, "x")
+    assert r.returncode == 1 and "RANK < WORLD" in r.stderr
+    r = run(cli, "-in", inp, "-out", tmp_path / "o.rec", "-membrane", "minima", 55, "-tv", 4, "-slab", 0)
+    assert r.returncode == 1
+
+
+def test_join_slabs_tool(tmp_path):
+    """tools/join_slabs.py stacks the per-rank files of a slab run (CPU only)."""
+    import subprocess
+    import sys
+    rng = np.random.default_rng(5)
+    vol = rng.standard_normal((9, 5, 7)).astype(np.float32)
+    names = []
+    for k, (a, b) in enumerate(((0, 4), (4, 9))):
+        p = tmp_path / ("s%d.rec" % k)
+        volgen.write_mrc(str(p), vol[a:b])                  # voxel width 1: cell z = number of planes
+        names.append(str(p))
+    out = tmp_path / "joined.rec"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "join_slabs.py"), str(out)] + names, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert_bits_equal(volgen.read_mrc(str(out)), vol, "joined slabs")
+    hdr = np.frombuffer(open(out, "rb").read()[:1024], np.float32)
+    assert hdr[12] == np.float32(9.0) and hdr[19] == vol.min() and hdr[20] == vol.max()

@@ -30,6 +30,8 @@
 #include <iostream>
 #include <sstream>
 #include <string>
+#include <thread>
+#include <chrono>
 #include <vector>
 
 #include "../../include/visfd_hip.hpp"
@@ -185,6 +187,10 @@ struct Settings {
   float tv_sigma = 0.0f;
   int tv_exponent = 4;                                        // settings.cpp:154
   float tv_truncate = std::sqrt(2.0);                         // settings.cpp:155
+  // Z-slab run across the GPUs of a node (no reference counterpart: the reference is single-process).  One filter_mrc per GPU:
+  //   VISFD_HIP_DEVICE=r filter_mrc ... -slab r WORLD IDFILE -out out_r.rec
+  int slab_rank = -1, slab_world = 0;
+  string slab_id_file;
 };
 
 bool read_must_link_file(const string& path, Settings& s);
@@ -323,6 +329,13 @@ Settings parse(int argc, char** argv) {
       i += 2;
     }
     else if (f == "-detection-threshold") { need(1); s.hessian_thr = num(v, i + 1, f); s.hessian_thr_is_fraction = false; i += 2; }
+    else if (f == "-slab") {
+      need(3);
+      s.slab_rank = (int)num(v, i + 1, f); s.slab_world = (int)num(v, i + 2, f); s.slab_id_file = v[i + 3];
+      if (s.slab_world < 1 || s.slab_rank < 0 || s.slab_rank >= s.slab_world)
+        throw VisfdErr("Error: -slab RANK WORLD IDFILE needs 0 <= RANK < WORLD.\n");
+      i += 4;
+    }
     else if (f == "-save-progress") { need(1); s.save_base = v[i + 1]; i += 2; }
     else if (f == "-load-progress") { need(1); s.load_base = v[i + 1]; i += 2; }
     // (-connect-dark differs from -connect only in clusters_begin_at_maxima, settings.cpp:3057-3060, a flag that nothing on
@@ -573,6 +586,58 @@ float ratio_of(const Settings& s) {
 
 }  // namespace
 
+// -membrane ... -tv ... -slab RANK WORLD IDFILE: this process owns planes [z0, z1) of the volume (WORLD processes, one GPU
+// each).  Rank 0 makes the RCCL id and publishes it as IDFILE (written under a temporary name, then renamed); the other ranks
+// wait for the file.  IDFILE "-" with WORLD 1 runs without a communicator.  Every rank reads the whole input, computes its
+// owned planes (halos, the global top-fraction threshold and the overlapped votes are csrc/slab.hip's business) and returns
+// them in `out` (nz = z1 - z0), which main() writes to this rank's own -out file; tools/join_slabs.py stacks the files.
+void handle_membrane_slab(const Settings& s, Mrc& tomo_in, Mrc& out, float ratio, int order, int64_t* z0_out) {
+  if (!(s.tv_sigma > 0)) throw VisfdErr("Error: -slab needs -tv (tensor voting).\n");
+  if (!s.hessian_thr_is_fraction) throw VisfdErr("Error: -slab needs the fractional threshold (-tv-best), not -detection-threshold.\n");
+  if (!s.mask.empty() || !s.load_base.empty() || !s.save_base.empty() || s.cluster_connected_voxels)
+    throw VisfdErr("Error: -slab runs the plain -membrane ... -tv stage only (no -mask, -save/-load-progress, -connect).\n");
+  visfd_hip_ctx* ctx = hip_detail::context();
+  unsigned char id[128];
+  const bool with_id = !(s.slab_id_file == "-" && s.slab_world == 1);
+  if (s.slab_id_file == "-" && s.slab_world > 1) throw VisfdErr("Error: -slab with more than one rank needs an id file.\n");
+  if (with_id) {
+    if (s.slab_rank == 0) {
+      hip_detail::check(visfd_hip_slab_unique_id(id));
+      const string tmp = s.slab_id_file + ".tmp";
+      { std::ofstream f(tmp.c_str(), std::ios::binary); f.write(reinterpret_cast<const char*>(id), 128);
+        if (!f) throw VisfdErr("Error: unable to write \"" + tmp + "\".\n"); }
+      if (std::rename(tmp.c_str(), s.slab_id_file.c_str()) != 0) throw VisfdErr("Error: unable to create \"" + s.slab_id_file + "\".\n");
+    } else {
+      bool got = false;
+      for (int tries = 0; tries < 12000 && !got; tries++) {   // up to 10 minutes
+        std::ifstream f(s.slab_id_file.c_str(), std::ios::binary);
+        if (f && f.read(reinterpret_cast<char*>(id), 128) && f.gcount() == 128) got = true;
+        else std::this_thread::sleep_for(std::chrono::milliseconds(50));
+      }
+      if (!got) throw VisfdErr("Error: the id file \"" + s.slab_id_file + "\" did not appear (is rank 0 running?).\n");
+    }
+  }
+  int h_tv = 0;
+  hip_detail::check(visfd_hip_tv_tables(s.tv_sigma, s.tv_truncate, &h_tv, nullptr, nullptr));
+  const int ghost = std::max(h_tv, (int)std::floor(s.width_a[0] * ratio) + 1);
+  visfd_hip_slab* slab = nullptr;
+  hip_detail::check(visfd_hip_slab_create_rccl(ctx, with_id ? id : nullptr, s.slab_rank, s.slab_world, tomo_in.nz, ghost, &slab));
+  int64_t lay[7];
+  hip_detail::check(visfd_hip_slab_layout(slab, lay));
+  const int64_t z0 = lay[0], z1 = lay[1];
+  cerr << "slab " << s.slab_rank << " of " << s.slab_world << ": planes [" << z0 << ", " << z1 << "), ghost depth " << ghost << "\n";
+  out.alloc(tomo_in.nx, tomo_in.ny, (int)(z1 - z0));
+  float thr = 0;
+  const size_t plane = (size_t)tomo_in.nx * tomo_in.ny;
+  const int rc = visfd_hip_membrane_detect_slab(slab, tomo_in.data() + (size_t)z0 * plane, tomo_in.nx, tomo_in.ny, s.width_a[0], ratio,
+                                                order, s.hessian_thr, s.tv_sigma, s.tv_exponent, s.tv_truncate, out.data(), nullptr,
+                                                &thr);
+  visfd_hip_slab_destroy(slab);
+  hip_detail::check(rc);
+  cerr << "  (saliency threshold = " << thr << ")\n";
+  *z0_out = z0;
+}
+
 int main(int argc, char** argv) {
   try {
     cerr << "filter_mrc (visfd-mi355x, hot path on libvisfd_hip ABI " << visfd_hip_abi_version() << ")\n";
@@ -687,6 +752,26 @@ int main(int argc, char** argv) {
       const bool want_tensor = s.tv_sigma > 0 && (!s.save_base.empty() || s.cluster_connected_voxels || !s.load_base.empty());
       vector<float> tensor(want_tensor ? 6 * n : 0);
       const float* mptr = mask.loaded ? mask.data() : nullptr;
+      if (s.slab_world > 0) {
+        if (bin > 1) throw VisfdErr("Error: -slab does not combine with binning (use -bin 1).\n");
+        Mrc part;
+        int64_t z0 = 0;
+        handle_membrane_slab(s, tomo_in, part, ratio, order, &z0);
+        // this rank's planes as an MRC file of their own: the input's header with nz, the cell's z extent and the z origin
+        // of the slab
+        std::memcpy(part.raw_header, tomo_in.raw_header, 1024);
+        float fw[256];
+        std::memcpy(fw, part.raw_header, 1024);
+        const float dz = tomo_in.cella[2] / (float)tomo_in.nz;
+        part.cella[0] = tomo_in.cella[0]; part.cella[1] = tomo_in.cella[1]; part.cella[2] = dz * (float)part.nz;
+        fw[51] += dz * (float)z0;                                // MRC2014 origin z (word 52)
+        std::memcpy(part.raw_header, fw, 1024);
+        if (!s.out.empty()) {
+          cerr << "writing this slab's planes (in 32-bit float mode)\n";
+          part.write(s.out, part);
+        }
+        return 0;
+      }
       if (s.load_base.empty()) {
         float thr = 0;
         hip_detail::check(visfd_hip_membrane_detect(
