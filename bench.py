@@ -472,12 +472,26 @@ def main():
         ts_ms = timed(lambda: ctx.tensor_saliency_dev(ten, sal, order), 3)
         # FP64 work of the eigen kernels, counted from the compiled code (tools/count_fp64.py): vector FP64 instructions per
         # voxel on the common path x 2 flop for FMA forms; peak 78.6 TFLOP/s FP64 vector (MI355X_MICROARCH.md)
+        FP64_PEAK = 78.6
+
+        def fp64(o, flop_per_voxel, voxels, ms):
+            tf = flop_per_voxel * voxels / (ms * 1e-3) / 1e12
+            o.update(fp64_flop_per_voxel=flop_per_voxel, fp64_voxels=int(voxels), achieved_fp64_tflops=round(tf, 2),
+                     frac_fp64=round(tf / FP64_PEAK, 4))
+            return o
+        n_sal = int(round(nv * MEMBRANE["best_fraction"]))
         roofline_ridge = {
-            "bound": "fp64 valu", "peak_tflops_fp64_vector": 78.6,
-            "ridge_score_kernel": hbm_obj("Gaussian-smoothed Hessian -> eigenvalues -> planar score, every voxel", rs_ms, nv, 8.0),
-            "ridge_directions_kernel": hbm_obj("eigenvectors of the voxels above the threshold (5 %)", rd_ms, nv, 16.0),
-            "tensor_saliency_kernel": hbm_obj("eigenvalues of the vote tensor -> lambda0 - lambda1", ts_ms, nv, 28.0),
-            "note": "ms_per_launch of ridge_score_kernel includes the smoothing Gaussian (sigma 1.73, h=4) in front of it"}
+            "bound": "fp64 valu", "peak_tflops_fp64_vector": FP64_PEAK,
+            "ridge_score_kernel": fp64(hbm_obj("Gaussian-smoothed Hessian -> eigenvalues -> planar score, every voxel", rs_ms, nv, 8.0),
+                                       153, nv, rs_ms),
+            "ridge_directions_kernel": fp64(hbm_obj("eigenvectors of the voxels above the threshold (5 %)", rd_ms, nv, 16.0),
+                                            987, n_sal, rd_ms),
+            "tensor_saliency_kernel": fp64(hbm_obj("eigenvalues of the vote tensor -> lambda0 - lambda1", ts_ms, nv, 28.0),
+                                           146, nv, ts_ms),
+            "note": "fp64_flop_per_voxel: FP64 vector instructions of the compiled kernel per voxel it works on, FMA = 2 (tools/"
+                    "count_fp64.py); the kernels issue 2-3 other vector instructions per FP64 one (fp32 Hessian stencil, the angle "
+                    "in single precision, selects), so frac_fp64 is what the FP64 pipe sees, not the kernels' issue load; "
+                    "ms_per_launch of ridge_score_kernel includes the smoothing Gaussian (sigma 1.73, h=4) in front of it"}
 
     # ---- the north-star target case: the separable Gaussian on a 2048^3 volume (2^33 voxels, 32 GiB) -------
     roofline_2048 = None

@@ -45,6 +45,10 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0
     assert set(out["roofline_tv"]) == {"exact", "tolerance"} and out["roofline_tv"]["exact"]["bound"] == "valu"
     assert out["roofline_pass"]["bound"] == "hbm" and "ridge_score_kernel" in out["roofline_ridge"]
+    rr = out["roofline_ridge"]   # the eigen kernels against the FP64 vector peak
+    for k in ("ridge_score_kernel", "ridge_directions_kernel", "tensor_saliency_kernel"):
+        assert rr[k]["fp64_flop_per_voxel"] > 0 and 0 < rr[k]["frac_fp64"] < 1
+        assert abs(rr[k]["frac_fp64"] - rr[k]["achieved_fp64_tflops"] / rr["peak_tflops_fp64_vector"]) < 2e-3
     rp = out["roofline_pipeline"]   # the BASELINE metric's own "% HBM roofline"
     assert rp["algorithmic_bytes_per_voxel"] == 336.0 and set(rp["stages"]) == {"gauss", "blob_dog", "membrane_tv"}
     assert abs(rp["frac"] - rp["achieved"] / rp["peak"]) < 1e-3

@@ -65,6 +65,10 @@ constexpr int CAP = VH_TV_CAP;       // list entries held in LDS per sweep and l
 constexpr int NP = (VH_TV_NP * CAP <= NT) ? VH_TV_NP : 1;
 static_assert(NP * CAP <= NT, "the replay loads one entry per thread");
 constexpr int LST = CAP + 8;         // l_pos entries per list (8 never-hit entries of slack behind each list)
+#ifndef VH_TV_LIST2
+#define VH_TV_LIST2 1
+#endif
+constexpr int NCH_MAX = NT >= 512 ? 4 : 5;   // chunks of the region per wave the two-plane lister handles
 constexpr int RING_BYTES = 32;       // bytes per entry of the scratch rings
 constexpr unsigned OOB = 0x7ffffff0u;  // byte offset beyond any plane descriptor: reads give 0
 
@@ -160,7 +164,7 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
   __shared__ __attribute__((aligned(16))) float4 l_ent[NP * CAP];
   __shared__ __attribute__((aligned(16))) uint2 l_pos[NP * LST];
   __shared__ float l_mv[MASKED_SRC ? NP * CAP : 1];
-  __shared__ int wave_tot[2][NW];
+  __shared__ int wave_tot[2][2][NW];
   __shared__ int cull[NP][CAP / 64][2 * NW]; // per list and wave holding entries: entries above / not below the rows each wave can reach
   __shared__ unsigned claimed_tile;
   __shared__ int plane_cnt[88];              // entries per ring slot, [2h + 2 NP] (h <= 40)
@@ -264,12 +268,12 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
         cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(s != 0.0f));
       }
       const int par = (npar++) & 1;
-      if (lane == 0) wave_tot[par][wave] = cnt;
+      if (lane == 0) wave_tot[par][0][wave] = cnt;
       __syncthreads();
       int running = 0, total = 0;   // entries at higher positions than this wave's; entries of the plane
 #pragma unroll
       for (int w = 0; w < NW; w++) {
-        const int t = wave_tot[par][w];
+        const int t = wave_tot[par][0][w];
         running += (w > wave) ? t : 0;
         total += t;
       }
@@ -310,6 +314,105 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
         }
       }
       if (tid == 0) plane_cnt[slot] = total;
+    };
+
+    // ---- LISTING, two planes at a time (tv_pair.hip, round 3; window regions of <= 4 chunks per wave: h <= 12).  Every load
+    // of a phase is in flight at once -- the saliencies of both planes (kept in registers across the barrier: one read per
+    // voxel), then the normals of a plane's salient voxels -- and both planes share one barrier.  The entries and their order
+    // are list_plane's.  A plane index < 0 means "no plane" (zero-length descriptors: nothing is salient).
+    auto list_two = [&](int sz0, int sz1) {
+      constexpr int NCH = NCH_MAX;
+      const int q0 = wave * p.nchunk * 64 + lane;
+      unsigned off[NCH];
+#pragma unroll
+      for (int j = 0; j < NCH; j++) {
+        const int q = q0 + 64 * j;
+        const int ey = (int)(((unsigned)q * (unsigned)p.rw_magic) >> 20);
+        const int ex = q - ey * p.rw;
+        const int sx = x0 - h + ex, sy = y0 - h + ey;
+        const bool ok = j < p.nchunk && q < R && sx >= 0 && sx < p.nx && sy >= 0 && sy < p.ny;
+        off[j] = ok ? (unsigned)(sy * p.nx + sx) * 4u : OOB;
+      }
+      float sv[2][NCH];
+      int cnt[2] = {0, 0};
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const int sz = k ? sz1 : sz0;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(sal + (i64)(sz < 0 ? 0 : sz) * plane), 0,
+                                                                            sz < 0 ? 0 : plane_bytes, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NCH; j++) sv[k][j] = buf_load(rs, off[j]);
+        if (MASKED_SRC) {
+          const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)(mask_src + (i64)(sz < 0 ? 0 : sz) * plane), 0,
+                                                                              sz < 0 ? 0 : plane_bytes, 0x00020000);
+#pragma unroll
+          for (int j = 0; j < NCH; j++)
+            if (buf_load(rm, off[j]) == 0.0f) sv[k][j] = 0.0f;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int j = 0; j < NCH; j++) cnt[k] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(sv[k][j] != 0.0f));
+      const int par = (npar++) & 1;
+      if (lane == 0) { wave_tot[par][0][wave] = cnt[0]; wave_tot[par][1][wave] = cnt[1]; }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const int sz = k ? sz1 : sz0;
+        if (sz < 0) continue;   // uniform
+        int running = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+          const int t = wave_tot[par][k][w];
+          running += (w > wave) ? t : 0;
+          total += t;
+        }
+        running = __builtin_amdgcn_readfirstlane(running);
+        const int slot = sz % P;
+        unsigned char* const ring_plane = ring + (size_t)slot * plane_stride;
+        if (tid == 0) plane_cnt[slot] = total;
+        if (cnt[k] == 0) continue;   // uniform
+        const __amdgpu_buffer_rsrc_t rd0 =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(dir + (i64)sz * plane), 0, plane_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rd1 =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(dir + nvox + (i64)sz * plane), 0, plane_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rd2 =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(dir + 2 * nvox + (i64)sz * plane), 0, plane_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((MASKED_SRC ? mask_src : sal) + (i64)sz * plane), 0, plane_bytes, 0x00020000);
+        float n0[NCH], n1[NCH], n2[NCH];
+        unsigned mvv[NCH];
+#pragma unroll
+        for (int j = 0; j < NCH; j++) {   // the normals of the salient voxels only, all chunks requested before the first use
+          n0[j] = n1[j] = n2[j] = 0.0f;
+          mvv[j] = 0u;
+          if (sv[k][j] != 0.0f) {
+            if (MODE != 3) { n0[j] = buf_load(rd0, off[j]); n1[j] = buf_load(rd1, off[j]); n2[j] = buf_load(rd2, off[j]); }
+            if (MASKED_SRC) mvv[j] = __float_as_uint(buf_load(rm, off[j]));
+          }
+        }
+#pragma unroll
+        for (int j = NCH - 1; j >= 0; j--) {   // descending region position = vote order
+          const bool f = sv[k][j] != 0.0f;
+          const unsigned long long bal = __builtin_amdgcn_ballot_w64(f);
+          const int tb = __builtin_popcountll(bal);
+          const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+          if (f) {
+            const int idx = running + (tb - below - 1);
+            const int q = q0 + 64 * j;
+            const int ey = (int)(((unsigned)q * (unsigned)p.rw_magic) >> 20);
+            const int ex = q - ey * p.rw;
+            const int epx = ex - h - TX / 2, epy = ey - h - TY / 2;
+            unsigned char* dst_e = ring_plane + (size_t)idx * RING_BYTES;
+            *reinterpret_cast<float4*>(dst_e) = make_float4(sv[k][j], n0[j], n1[j], n2[j]);
+            *reinterpret_cast<uint4*>(dst_e + 16) =
+                make_uint4((unsigned)(epx & 0xff) | ((unsigned)(epy & 0xff) << 8), (unsigned)(epx * epx + epy * epy),
+                           (unsigned)(16 * (ey * SP + ex)), mvv[j]);
+          }
+          running += tb;
+        }
+      }
     };
 
     float TT[NP][6];
@@ -384,8 +487,19 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
       // interior band while the halo planes above it are still in flight)
       const int sz_hi = min(min(rz + 2 * NP - 1, z_run1 - 1) + h, p.nz - 1), sz_lo = max(rz - h, 0);
       // the window holds at most P planes, so a plane that enters it takes the slot of one that has left
-      for (int sz = sz_hi; sz >= sz_lo; sz--)   // uniform
-        if (p.relist || sz < cached_lo || sz > cached_hi) list_plane(sz);
+      if (VH_TV_LIST2 && p.nchunk <= NCH_MAX) {
+        int pend = -1;
+        for (int sz = sz_hi; sz >= sz_lo; sz--) {   // uniform
+          if (!(p.relist || sz < cached_lo || sz > cached_hi)) continue;
+          if (pend < 0) { pend = sz; continue; }
+          list_two(pend, sz);
+          pend = -1;
+        }
+        if (pend >= 0) list_two(pend, -1);
+      } else {
+        for (int sz = sz_hi; sz >= sz_lo; sz--)   // uniform
+          if (p.relist || sz < cached_lo || sz > cached_hi) list_plane(sz);
+      }
       cached_lo = sz_lo;
       cached_hi = sz_hi;
 
