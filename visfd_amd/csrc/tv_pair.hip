@@ -53,6 +53,9 @@ static_assert(TX == 8 || TX == 16, "one or two 8-column sub-patches per wave");
 // planes, but they need the SAME two table slices S_(d-1), S_d: with NP = 2 a workgroup takes both pairs through the
 // steps together -- four lists and four sweeps per barrier interval (each wave: 2 x 6 sums), the same two slices, half as
 // many intervals, fills and barriers per vote.  LDS is unchanged: 4 lists of 128 entries instead of 2 of 256.
+#ifndef VH_PAIR_REMAT
+#define VH_PAIR_REMAT 1
+#endif
 #ifndef VH_PAIR_NP
 #define VH_PAIR_NP (VH_PAIR_TX == 8 ? 2 : 1)
 #endif
@@ -150,7 +153,7 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
   extern __shared__ __attribute__((aligned(16))) unsigned char slices[];   // two table slices: S_j (jz = +j) in slot j & 1
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = p.h;
   const int S = 2 * h + 1;
   // LDS rows of a table slice are SP float4 apart, SP = S rounded up to 4 mod 8, and the lanes of a half wave are dealt to
@@ -190,27 +193,43 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
     const int z_run1 = min(z_run0 + p.zrun, p.z_out1);
     const int x0 = tile_x * TX, y0 = tile_y * TY;
 
-    const int half = lane >> 5;                       // 0: receiver plane rz, 1: plane rz + 1
     // lane -> receiver inside the wave's 8 x 4 patch (see SP above): lanes 0-3, 12-15, 20-23, 24-27 are columns 0-3 of rows
-    // 0, 1, 2, 3; lanes 4-7, 8-11, 16-19, 28-31 columns 4-7 of rows 0, 1, 2, 3
-    const int l5 = lane & 31;
-    const int lrow = (l5 < 8) ? 0 : (l5 < 16) ? 1 : (l5 < 24) ? 2 : 3;
-    const int lcol = (l5 & 3) + (((0xc33cu >> (l5 >> 1)) & 1u) ? 4 : 0);   // lane pairs 2-5, 8-9, 14-15 (lanes 4-11, 16-19, 28-31): the right block
-    const int lx = lcol, ly = wave * 4 + lrow;
-    const int rx = x0 + lx, ry = y0 + ly;             // (sub-patch s: column rx + 8 s)
-    bool r_in[NS];
+    // 0, 1, 2, 3; lanes 4-7, 8-11, 16-19, 28-31 columns 4-7 of rows 0, 1, 2, 3.  half: 0 = receiver plane rz, 1 = plane rz + 1.
     // distance test as one dot product (tv_tiled.hip):  |r'-e'|^2 - h^2 - 1 = (-2r'x, -2r'y, -128, 1).(e'x, e'y, -q, m) + (|r'|^2 - h^2 - 1)
-    unsigned recv4[NS];
-    int recv_c[NS];
+    struct LaneConst {
+      int half, lx, ly;
+      unsigned recv4[NS];
+      int recv_c[NS];
+      unsigned r16_0;     // LDS address of this lane's table entry of j = 0 in slice slot 0
+    };
+    auto lane_consts = [&](unsigned ln) -> LaneConst {
+      LaneConst c;
+      c.half = (int)(ln >> 5);
+      const int l5 = (int)(ln & 31);
+      const int lrow = l5 >> 3;
+      const int lcol = (l5 & 3) + (((0xc33cu >> (l5 >> 1)) & 1u) ? 4 : 0);   // lane pairs 2-5, 8-9, 14-15 (lanes 4-11, 16-19, 28-31): the right block
+      c.lx = lcol;
+      c.ly = wave * 4 + lrow;
 #pragma unroll
-    for (int s = 0; s < NS; s++) {
-      r_in[s] = rx + 8 * s < p.nx && ry < p.ny;
-      const int rpx = lx + 8 * s - TX / 2, rpy = ly - TY / 2;
-      recv4[s] = (unsigned)((-2 * rpx) & 0xff) | ((unsigned)((-2 * rpy) & 0xff) << 8) | (0x80u << 16) | (1u << 24);
-      recv_c[s] = rpx * rpx + rpy * rpy - h * h - 1;
-    }
+      for (int s = 0; s < NS; s++) {
+        const int rpx = c.lx + 8 * s - TX / 2, rpy = c.ly - TY / 2;
+        c.recv4[s] = (unsigned)((-2 * rpx) & 0xff) | ((unsigned)((-2 * rpy) & 0xff) << 8) | (0x80u << 16) | (1u << 24);
+        c.recv_c[s] = rpx * rpx + rpy * rpy - h * h - 1;
+      }
+      c.r16_0 = lds_addr(slices) + (unsigned)(16 * ((c.ly + 2 * h) * SP + c.lx + 2 * h));
+      return c;
+    };
+    // The constants are RECOMPUTED from the lane number wherever a phase needs them (pass start, every step): kept live
+    // across the sweeps they are spilled, and a step would begin with their reloads from scratch memory in front of its ring
+    // loads.  (The empty asm hides the lane number's origin, so that the compiler cannot share one computation.)
+    auto fresh_lane = [&]() -> unsigned {
+      unsigned ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+#if VH_PAIR_REMAT
+      asm volatile("" : "+v"(ln));
+#endif
+      return ln;
+    };
     constexpr unsigned NEVER_HIT = 0x009c0000u;
-    const unsigned r16_0 = lds_addr(slices) + (unsigned)(16 * ((ly + 2 * h) * SP + lx + 2 * h));   // table entry of j = 0.. in slot 0
     const unsigned ent_base = lds_addr(l_ent);
 
     // position word of a list entry = the sender's operand of the distance test: signed bytes (e'x, e'y, -q, m) with
@@ -398,7 +417,8 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
     // ---- the SWEEP over list entries [i0, i1) of one list (base = its first LDS entry), in list order ------------------
     // r16: this lane's table base in its slice slot (sub-patch s: 128 bytes further); rcl[s]: its accumulator operand of the
     // distance test (large: never hit)
-    auto sweep = [&](auto ZN, float (&T)[NS][6], int base, int i0, int i1, unsigned r16, const int (&rcl)[NS]) {
+    auto sweep = [&](auto ZN, float (&T)[NS][6], int base, int i0, int i1, unsigned r16, const int (&rcl)[NS],
+                     const unsigned (&recv4)[NS]) {
       constexpr bool ZNEG = decltype(ZN)::value;
       auto vote_sub = [&](auto SUB, const f4v& d, int s, unsigned e16) {
         constexpr int sub = decltype(SUB)::value;
@@ -528,14 +548,16 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
       // this lane's receivers: plane rz + 2 pp + half of pair pp
       i64 rc[NP];                // (sub-patch s: rc + 8 s)
       bool r_live[NP][NS];
+      const LaneConst pc = lane_consts(fresh_lane());
+      const int rx = x0 + pc.lx, ry = y0 + pc.ly;             // (sub-patch s: column rx + 8 s)
 #pragma unroll
       for (int pp = 0; pp < NP; pp++) {
-        const int rzl = rz + 2 * pp + half;
+        const int rzl = rz + 2 * pp + pc.half;
         const bool z_in = rzl < z_run1;
         rc[pp] = (i64)rzl * plane + (i64)ry * p.nx + rx;
 #pragma unroll
         for (int s = 0; s < NS; s++) {
-          const bool in = r_in[s] && z_in;
+          const bool in = rx + 8 * s < p.nx && ry < p.ny && z_in;
           r_live[pp][s] = in && !(mask_dst && mask_dst[in ? rc[pp] + 8 * s : 0] == 0.0f);
 #pragma unroll
           for (int k = 0; k < 6; k++) TT[pp][s][k] = 0.0f;
@@ -583,7 +605,10 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
         for (int k = 1; k < NLIST; k++)
           if (li == k) { my_sz = lsz[k]; my_cnt = lcnt[k]; }
         const unsigned char* ring_plane = ring + (size_t)(((my_sz % P) + P) % P) * plane_stride;
-        const int ltid = tid & (CAPH - 1);
+        const LaneConst lc = lane_consts(fresh_lane());
+        const int half = lc.half;
+        const unsigned r16_0 = lc.r16_0;
+        const int ltid = VH_PAIR_REMAT ? (wave % WPL) * 64 + (int)(fresh_lane()) : (tid & (CAPH - 1));
         const int lbase = li * LSTRIDE;
         for (int done = 0; done < cmax; done += CAPH) {   // uniform
           const int take = min(CAPH, max(my_cnt - done, 0));
@@ -646,8 +671,8 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
               const unsigned r16 = r16_0 + (unsigned)(16 * nsl) * (unsigned)((half ? ju : jl) & 1);
               int rcl[NS];
 #pragma unroll
-              for (int s = 0; s < NS; s++) rcl[s] = (r_live[pp][s] && zok) ? recv_c[s] + d * d + (half ? 1 - 2 * d : 0) : 0x100000;
-              sweep(std::true_type{}, TT[pp], (2 * pp) * LSTRIDE, i0[2 * pp], i1[2 * pp], r16, rcl);
+              for (int s = 0; s < NS; s++) rcl[s] = (r_live[pp][s] && zok) ? lc.recv_c[s] + d * d + (half ? 1 - 2 * d : 0) : 0x100000;
+              sweep(std::true_type{}, TT[pp], (2 * pp) * LSTRIDE, i0[2 * pp], i1[2 * pp], r16, rcl, lc.recv4);
             }
             // plane B (below): jz = d-1 for the lower plane (S_(d-1)), d for the upper one (S_d)
             if (i1[2 * pp + 1] > i0[2 * pp + 1]) {
@@ -657,8 +682,8 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
               int rcl[NS];
 #pragma unroll
               for (int s = 0; s < NS; s++)
-                rcl[s] = (r_live[pp][s] && zok) ? recv_c[s] + (1 - d) * (1 - d) + (half ? 1 - 2 * (1 - d) : 0) : 0x100000;
-              sweep(std::false_type{}, TT[pp], (2 * pp + 1) * LSTRIDE, i0[2 * pp + 1], i1[2 * pp + 1], r16, rcl);
+                rcl[s] = (r_live[pp][s] && zok) ? lc.recv_c[s] + (1 - d) * (1 - d) + (half ? 1 - 2 * (1 - d) : 0) : 0x100000;
+              sweep(std::false_type{}, TT[pp], (2 * pp + 1) * LSTRIDE, i0[2 * pp + 1], i1[2 * pp + 1], r16, rcl, lc.recv4);
             }
           }
           VH_STAMP(3);
