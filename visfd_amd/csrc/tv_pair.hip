@@ -703,14 +703,23 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
       cnt_tested = cnt_voted = cnt_lanes = 0;
 #endif
 
+      {
+        const LaneConst sc = lane_consts(fresh_lane());         // (the receiver index again, rather than a value live since the pass began)
 #pragma unroll
-      for (int pp = 0; pp < NP; pp++)
+        for (int pp = 0; pp < NP; pp++) {
+#if VH_PAIR_REMAT
+          const i64 rcs = (i64)(rz + 2 * pp + sc.half) * plane + (i64)(y0 + sc.ly) * p.nx + (x0 + sc.lx);
+#else
+          const i64 rcs = rc[pp];
+#endif
 #pragma unroll
-        for (int s = 0; s < NS; s++)
-          if (r_live[pp][s]) {
+          for (int s = 0; s < NS; s++)
+            if (r_live[pp][s]) {
 #pragma unroll
-            for (int k = 0; k < 6; k++) __builtin_nontemporal_store(TT[pp][s][k], &ten[k * nvox + rc[pp] + 8 * s]);   // written once, not read here
-          }
+              for (int k = 0; k < 6; k++) __builtin_nontemporal_store(TT[pp][s][k], &ten[k * nvox + rcs + 8 * s]);   // written once, not read here
+            }
+        }
+      }
     }   // next pass of the run
   }   // next unit
 #ifdef VH_TV_STAMPS
