@@ -51,6 +51,9 @@
 #ifndef VH_FUSED_STAGGER
 #define VH_FUSED_STAGGER 0
 #endif
+#ifndef VH_FUSED_SCALAR_WAVE
+#define VH_FUSED_SCALAR_WAVE 1
+#endif
 
 namespace vh {
 
@@ -230,7 +233,7 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
     col_off[c] = inside ? (unsigned)(gy * nx + gx) * 4u : OOB;
   }
   const int lds_base = 4 * tid;   // BYTE offset of column c in sZ: lds_base + 4 * NT * c
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = VH_FUSED_SCALAR_WAVE ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
   constexpr int NYR = C::YBLOCK ? C::YB_ROUNDS : C::YROUNDS;
   int y_off[NYR];    // LDS BYTE offset of (row y, column pair xp); -1: idle lane
   if constexpr (C::YBLOCK) {
