@@ -67,13 +67,27 @@ def main():
             print("SLAB-MISMATCH: a context on its own stream was accepted", flush=True)
             sys.exit(1)
     thr = slab.membrane_detect_slab(ctx, L, src, sal, dirs, ten, sigma, tv_ratio, 4, fraction)
+    host_bad = []
+    if isinstance(L, api.Slab):
+        # the host-memory face of the same stage (what filter_mrc -slab calls): owned planes in, owned planes out
+        import math
+        sal_h, ten_h, thr_h = L.membrane_detect_host(
+            full[L.z0:L.z1].numpy(), sigma, api.ratio_from_threshold(0.03), api.DECREASING_EIVALS, fraction,
+            float(np.float32(tv_ratio) * np.float32(sigma)), 4, math.sqrt(2.0), want_tensor=True)
+        ctx.synchronize()
+        if np.float32(thr_h) != np.float32(thr):
+            host_bad.append("host-face threshold differs on rank %d" % rank)
+        if not np.array_equal(sal_h.view(np.uint32), L.owned(sal).cpu().numpy().view(np.uint32)):
+            host_bad.append("host-face saliency differs on rank %d" % rank)
+        if not np.array_equal(ten_h.view(np.uint32), np.moveaxis(L.owned(ten).cpu().numpy(), 0, -1).view(np.uint32)):
+            host_bad.append("host-face tensor differs on rank %d" % rank)
     src2 = torch.full(lshape, float("nan"), device=dev)
     L.owned(src2).copy_(full[L.z0:L.z1])
     mins, maxs = slab.blob_detect_slab(ctx, L, src2, blob_sigmas, 0.03, 0.02, -5.0, 5.0, False)
     ctx.synchronize()
 
     part = dict(z0=L.z0, z1=L.z1, thr=np.float32(thr), sal=L.owned(sal).cpu().numpy(),
-                ten=L.owned(ten).cpu().numpy(), mins=mins, maxs=maxs)
+                ten=L.owned(ten).cpu().numpy(), mins=mins, maxs=maxs, host_bad=host_bad)
     parts = [None] * world
     dist.all_gather_object(parts, part)
 
@@ -90,6 +104,7 @@ def main():
         if not np.abs(ften).max() > 0:
             bad.append("vote tensor is all zero")
         for p in parts:
+            bad.extend(p["host_bad"])
             z0, z1 = p["z0"], p["z1"]
             if np.float32(p["thr"]) != np.float32(fthr):
                 bad.append("threshold differs on planes %d..%d" % (z0, z1))
