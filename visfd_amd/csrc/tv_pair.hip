@@ -12,8 +12,9 @@
 //     is symmetric under jz -> -jz up to the sign of rhat_z, and the sender planes z + d and z + 1 - d (d = 1..h+1) see the
 //     receiver pair at jz = (-d, 1-d) and (d-1, d): the SAME two slices |jz| = d-1 and d, with the halves of the wave
 //     swapped and rhat_z negated.  So one interval serves both planes: h+1 intervals instead of 2h+2, every thread brings
-//     one list entry (threads 0-255 the plane above, 256-511 the plane below), one new slice per interval, and because the
-//     direction of d may alternate from one receiver pair to the next, never a slice reload at a turn.
+//     one list entry, one new slice per interval, and because the direction of d may alternate from one pass to the next,
+//     never a slice reload at a turn.  Two receiver pairs go through the steps together (NP below): four lists of 128
+//     entries per interval.
 //
 // Everything else follows tv_tiled.hip: persistent workgroups claiming units (an 8 x 32 tile of receivers over a run of
 // receiver planes) from a global counter; sender planes LISTED once per unit into a per-workgroup ring in global memory
@@ -139,15 +140,15 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
                const float4* __restrict__ table /* [(2h+1)^3] : w, sqrt(2) rhat at j */,
                PairParams p, unsigned* __restrict__ tile_counter, unsigned ntiles,
                unsigned char* __restrict__ scratch /* per-workgroup rings of compacted sender planes */) {
-  // l_ent[e]  float4 {sal (scaled), n0, n1, n2} of list entry e; list A (the sender plane ABOVE the receiver pair) in
-  //           [0, CAPH), list B (the plane below) in [LSTRIDE, LSTRIDE + CAPH)
+  // l_ent[e]  float4 {sal (scaled), n0, n1, n2} of list entry e; list 2 pp (the sender plane ABOVE receiver pair pp) in
+  //           [2 pp LSTRIDE, 2 pp LSTRIDE + CAPH), list 2 pp + 1 (the plane below it) one LSTRIDE further
   // l_pos[e]  {distance-test operand, table offset E}: packed signed bytes (e'x, e'y, -(|e'|^2 >> 7), |e'|^2 & 127) with e' =
   //           sender position relative to the tile centre and the LOWER receiver plane; 8 never-hit entries behind each list
   __shared__ __attribute__((aligned(16))) float4 l_ent[NLIST * LSTRIDE];
   __shared__ __attribute__((aligned(16))) uint2 l_pos[NLIST * LSTRIDE];
   __shared__ float l_mv[MASKED_SRC ? NLIST * LSTRIDE : 1];
   __shared__ int wave_tot[2][2][NW];
-  __shared__ int cull[NW][2 * NW];           // per wave holding entries (0-3: list A, 4-7: list B): entries above / not below each wave's rows
+  __shared__ int cull[NW][2 * NW];           // per wave holding entries (waves WPL k .. WPL k + WPL - 1: list k): entries above / not below each wave's rows
   __shared__ unsigned claimed_tile;
   __shared__ int plane_cnt[88];              // entries per ring slot, [2h + 2 NP] (h <= 40)
   extern __shared__ __attribute__((aligned(16))) unsigned char slices[];   // two table slices: S_j (jz = +j) in slot j & 1
@@ -525,9 +526,6 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
       const int sz_hi = min(min(rz + 2 * NP - 1, z_run1 - 1) + h, p.nz - 1), sz_lo = max(rz - h, 0);
 #ifndef VH_PAIR_LIST2
 #define VH_PAIR_LIST2 1
-#endif
-#ifndef VH_PAIR_FILL_FIRST
-#define VH_PAIR_FILL_FIRST 0
 #endif
       if (VH_PAIR_LIST2 && p.nchunk <= NCH_MAX) {
         int pend = -1;
