@@ -67,6 +67,14 @@ constexpr int WPL = NW / NLIST;        // waves that bring (and count the row ra
 static_assert(CAPH % 64 == 0 && WPL >= 1, "a list is brought by whole waves");
 constexpr int NCH_MAX = (NT >= 512 && TX == 8) ? 4 : 5;   // chunks of the region per wave the two-plane lister handles
 constexpr int LSTRIDE = CAPH + 8;      // LDS entries per list (8 never-hit entries of slack behind each list)
+// PACKED LISTS.  The lists of a step share the NT entry slots of LDS: their entries are dealt to the threads as ONE sequence
+// (list 0, then list 1, ...), each list's share of an interval lands contiguously (an even start, 8 never-hit entries of slack
+// behind it), and an interval ends when NT entries are in -- not when the longest list has had CAPH.  At 1024^3 a step brings
+// 349 entries on average but its longest list often more than 128: 1.34 intervals per step with fixed quarters, 1.0x packed.
+#ifndef VH_PAIR_PACK
+#define VH_PAIR_PACK 1
+#endif
+constexpr int LSLOTS = VH_PAIR_PACK ? NT + 12 * NLIST : NLIST * LSTRIDE;   // LDS entry slots
 constexpr unsigned OOB = 0x7ffffff0u;  // byte offset beyond any plane descriptor: reads give 0
 
 __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
@@ -91,7 +99,7 @@ __device__ unsigned long long g_pair_stamps[8];
 #endif
 
 #ifdef VH_TV_COUNT   // development build: how many senders the waves test, how many of those vote, how many lanes they reach
-__device__ unsigned long long g_pair_counts[4];
+__device__ unsigned long long g_pair_counts[8];   // tested, voted, lanes, -, steps with senders, barrier intervals, list entries, -
 #endif
 
 struct PairParams {
@@ -144,11 +152,13 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
   //           [2 pp LSTRIDE, 2 pp LSTRIDE + CAPH), list 2 pp + 1 (the plane below it) one LSTRIDE further
   // l_pos[e]  {distance-test operand, table offset E}: packed signed bytes (e'x, e'y, -(|e'|^2 >> 7), |e'|^2 & 127) with e' =
   //           sender position relative to the tile centre and the LOWER receiver plane; 8 never-hit entries behind each list
-  __shared__ __attribute__((aligned(16))) float4 l_ent[NLIST * LSTRIDE];
-  __shared__ __attribute__((aligned(16))) uint2 l_pos[NLIST * LSTRIDE];
-  __shared__ float l_mv[MASKED_SRC ? NLIST * LSTRIDE : 1];
+  __shared__ __attribute__((aligned(16))) float4 l_ent[LSLOTS];
+  __shared__ __attribute__((aligned(16))) uint2 l_pos[LSLOTS];
+  __shared__ float l_mv[MASKED_SRC ? LSLOTS : 1];
   __shared__ int wave_tot[2][2][NW];
+#if !VH_PAIR_PACK
   __shared__ int cull[NW][2 * NW];           // per wave holding entries (waves WPL k .. WPL k + WPL - 1: list k): entries above / not below each wave's rows
+#endif
   __shared__ unsigned claimed_tile;
   __shared__ int plane_cnt[88];              // entries per ring slot, [2h + 2 NP] (h <= 40)
   extern __shared__ __attribute__((aligned(16))) unsigned char slices[];   // two table slices: S_j (jz = +j) in slot j & 1
@@ -597,6 +607,133 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
         int rho = (int)__builtin_sqrtf((float)(h * h - jn));
         while (rho * rho > h * h - jn) rho--;
         while ((rho + 1) * (rho + 1) <= h * h - jn) rho++;
+#if VH_PAIR_PACK
+        const LaneConst lc = lane_consts(fresh_lane());
+        const int half = lc.half;
+        const unsigned r16_0 = lc.r16_0;
+        const int t512 = wave * 64 + (int)fresh_lane();        // this thread's place in the interval's entry sequence
+        int pre[NLIST + 1];                                    // (uniform) first position of list k in the step's sequence
+        pre[0] = 0;
+#pragma unroll
+        for (int k = 0; k < NLIST; k++) pre[k + 1] = pre[k] + lcnt[k];
+        const int total = pre[NLIST];
+        int pl[NLIST];                                         // (uniform) ring slot of list k's plane
+#pragma unroll
+        for (int k = 0; k < NLIST; k++) pl[k] = __builtin_amdgcn_readfirstlane(((lsz[k] % P) + P) % P);
+#ifdef VH_TV_COUNT
+        if (tid == 0) {
+          atomicAdd(&g_pair_counts[4], 1ull);
+          atomicAdd(&g_pair_counts[5], (unsigned long long)((total + NT - 1) / NT));
+          atomicAdd(&g_pair_counts[6], (unsigned long long)total);
+        }
+#endif
+        for (int done = 0; done < total; done += NT) {   // uniform
+          // list k's share of this interval: sequence positions [c[k], c[k] + len[k]) of the NT, LDS slots from S[k]
+          int c[NLIST], len[NLIST], S[NLIST];
+#pragma unroll
+          for (int k = 0; k < NLIST; k++) {
+            const int lo = min(max(pre[k], done), done + NT), hi = min(pre[k + 1], done + NT);
+            c[k] = lo - done;
+            len[k] = max(hi - lo, 0);
+            S[k] = ((c[k] + 1) & ~1) + 10 * k;
+          }
+          const int g = done + t512;
+          int k_me = 0;
+#pragma unroll
+          for (int k = 1; k < NLIST; k++) k_me += (g >= pre[k]) ? 1 : 0;
+          const bool have = g < total;
+          int idx = g, slot = t512, pl_me = pl[0];
+#pragma unroll
+          for (int k = 0; k < NLIST; k++)
+            if (k_me == k) { idx = g - pre[k]; slot = S[k] + (t512 - c[k]); pl_me = pl[k]; }
+          const unsigned char* ring_plane = ring + (size_t)pl_me * plane_stride;
+          int epy = -128;                                      // threads without an entry: below every range
+          float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          unsigned m = 0u;
+          float mvv = 0.0f;
+          if (have) {
+            a = reinterpret_cast<const float4*>(ring_plane)[idx];
+            m = reinterpret_cast<const unsigned*>(ring_plane + (size_t)R * 16)[idx];
+            if (MASKED_SRC) mvv = reinterpret_cast<const float*>(ring_plane + (size_t)R * 20)[idx];
+          }
+          if (done == 0) {
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+              if (need[k] < 0) continue;   // uniform
+              const int j = need[k];
+              const float4* src4 = table + (i64)(j + h) * nsl;
+              float4* dst4 = sl4 + (j & 1) * nsl;
+              for (int i = tid; i < nsl; i += NT) dst4[i] = src4[i];
+            }
+          }
+          if (have) {
+            l_ent[slot] = a;
+            const int epx = (int)(signed char)(m & 0xff);
+            epy = (int)(signed char)((m >> 8) & 0xff);
+            const unsigned e16 = (unsigned)(16 * ((epy + h + TY / 2) * SP + (epx + h + TX / 2)));
+            l_pos[slot] = make_uint2(m, e16);
+            if (MASKED_SRC) l_mv[slot] = mvv;
+          }
+          if (t512 < 8 * NLIST) {                               // 8 never-hit entries behind every (non-empty) list's share
+            int sk = S[0] + len[0], lk = len[0];
+#pragma unroll
+            for (int k = 1; k < NLIST; k++)
+              if ((t512 >> 3) == k) { sk = S[k] + len[k]; lk = len[k]; }
+            if (lk > 0) l_pos[sk + (t512 & 7)] = make_uint2(NEVER_HIT, 0u);
+          }
+          VH_STAMP(1);
+          __syncthreads();   // lists (and slices) complete
+          VH_STAMP(2);
+          // entries are in descending row order: of list k, this wave needs those from the first one at or below row
+          // 4w-13+rho to the last one at or above row 4w-16-rho.  Every wave counts both kinds itself, from the row bytes of
+          // the position words in LDS, 64 entries at a time.
+          int i0[NLIST], i1[NLIST];
+          {
+            const int hi_row = 4 * wave - (TY / 2 - 3) + rho, lo_row = 4 * wave - TY / 2 - rho;
+            const int ln = (int)fresh_lane();
+#pragma unroll
+            for (int k = 0; k < NLIST; k++) {
+              int above = 0, upto = 0;
+              for (int j = 0; j < len[k]; j += 64) {   // uniform
+                int ey = -128;
+                if (j + ln < len[k]) ey = (int)(signed char)((l_pos[S[k] + j + ln].x >> 8) & 0xff);
+                above += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ey > hi_row));
+                upto += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ey >= lo_row));
+              }
+              i0[k] = above;
+              i1[k] = upto;
+            }
+          }
+#pragma unroll
+          for (int pp = 0; pp < NP; pp++) {
+            // plane A (above): the lower receiver plane sees it at jz = -d (slice S_d, rhat_z negated), the upper one at
+            // 1-d (S_(d-1)); |r-e|^2 of the upper plane's receivers differs by 1 - 2 e'z
+            if (i1[2 * pp] > i0[2 * pp]) {
+              const int jl = d, ju = d - 1;
+              const bool zok = half ? ju <= h : jl <= h;
+              const unsigned r16 = r16_0 + (unsigned)(16 * nsl) * (unsigned)((half ? ju : jl) & 1);
+              int rcl[NS];
+#pragma unroll
+              for (int s = 0; s < NS; s++) rcl[s] = (r_live[pp][s] && zok) ? lc.recv_c[s] + d * d + (half ? 1 - 2 * d : 0) : 0x100000;
+              sweep(std::true_type{}, TT[pp], S[2 * pp], i0[2 * pp], i1[2 * pp], r16, rcl, lc.recv4);
+            }
+            // plane B (below): jz = d-1 for the lower plane (S_(d-1)), d for the upper one (S_d)
+            if (i1[2 * pp + 1] > i0[2 * pp + 1]) {
+              const int jl = d - 1, ju = d;
+              const bool zok = half ? ju <= h : jl <= h;
+              const unsigned r16 = r16_0 + (unsigned)(16 * nsl) * (unsigned)((half ? ju : jl) & 1);
+              int rcl[NS];
+#pragma unroll
+              for (int s = 0; s < NS; s++)
+                rcl[s] = (r_live[pp][s] && zok) ? lc.recv_c[s] + (1 - d) * (1 - d) + (half ? 1 - 2 * (1 - d) : 0) : 0x100000;
+              sweep(std::false_type{}, TT[pp], S[2 * pp + 1], i0[2 * pp + 1], i1[2 * pp + 1], r16, rcl, lc.recv4);
+            }
+          }
+          VH_STAMP(3);
+          __syncthreads();   // everyone done reading before the lists or the slices are refilled
+          VH_STAMP(4);
+        }
+#else
         const int li = wave / WPL;                             // (uniform) the list this thread brings entries of
         int my_sz = lsz[0], my_cnt = lcnt[0];
 #pragma unroll
@@ -608,6 +745,15 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
         const unsigned r16_0 = lc.r16_0;
         const int ltid = VH_PAIR_REMAT ? (wave % WPL) * 64 + (int)(fresh_lane()) : (tid & (CAPH - 1));
         const int lbase = li * LSTRIDE;
+#ifdef VH_TV_COUNT
+        if (tid == 0) {
+          atomicAdd(&g_pair_counts[4], 1ull);
+          atomicAdd(&g_pair_counts[5], (unsigned long long)((cmax + CAPH - 1) / CAPH));
+          unsigned long long tot = 0;
+          for (int k = 0; k < NLIST; k++) tot += (unsigned long long)lcnt[k];
+          atomicAdd(&g_pair_counts[6], tot);
+        }
+#endif
         for (int done = 0; done < cmax; done += CAPH) {   // uniform
           const int take = min(CAPH, max(my_cnt - done, 0));
           int epy = -128;                                      // threads without an entry: below every range
@@ -690,6 +836,7 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
 #endif
           VH_STAMP(4);
         }
+#endif
       }
       up = !up;
 #ifdef VH_TV_COUNT
@@ -768,7 +915,7 @@ int dev_tv_pair(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* t
   if (nblk > 0x7fffffffLL) return fail(VISFD_HIP_EINVAL, "volume too large for one launch");
   if (nblk <= 0) { *handled = true; return VISFD_HIP_OK; }
   const size_t lds = 2 * slice_bytes;
-  const size_t lds_static = (sizeof(float4) + sizeof(uint2) + (mask_src ? sizeof(float) : 0)) * NLIST * LSTRIDE + 2048;
+  const size_t lds_static = (sizeof(float4) + sizeof(uint2) + (mask_src ? sizeof(float) : 0)) * LSLOTS + 2560;
   if (lds + lds_static > 150 * 1024) return VISFD_HIP_OK;   // window too wide: the caller falls back
   unsigned* counter = nullptr;
   VH_TRY(ws(ctx, WS_COUNTER, 16, &counter));
@@ -803,11 +950,13 @@ int dev_tv_pair(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* t
   VH_HIP(hipGetLastError());
 #ifdef VH_TV_COUNT
   {
-    unsigned long long c4[4], z4[4] = {};
+    unsigned long long c4[8], z4[8] = {};
     VH_HIP(hipStreamSynchronize(st));
     VH_HIP(hipMemcpyFromSymbol(c4, HIP_SYMBOL(g_pair_counts), sizeof(c4)));
     fprintf(stderr, "[tv_pair counts] tested (incl. batch padding) %.4g  voted wave-steps %.4g  votes (lane hits) %.4g  -> lane use of a vote step %.3f, "
             "tested / voted %.3f\n", (double)c4[0], (double)c4[1], (double)c4[2], (double)c4[2] / (64.0 * (double)c4[1]), (double)c4[0] / (double)c4[1]);
+    fprintf(stderr, "[tv_pair counts] steps with senders %.4g  barrier intervals %.4g (%.3f per step)  list entries per step %.1f (capacity %d)\n",
+            (double)c4[4], (double)c4[5], (double)c4[5] / (double)c4[4], (double)c4[6] / (double)c4[4], NLIST * CAPH);
     VH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_pair_counts), z4, sizeof(z4)));
   }
 #endif
