@@ -65,6 +65,14 @@ constexpr int CAP = VH_TV_CAP;       // list entries held in LDS per sweep and l
 constexpr int NP = (VH_TV_NP * CAP <= NT) ? VH_TV_NP : 1;
 static_assert(NP * CAP <= NT, "the replay loads one entry per thread");
 constexpr int LST = CAP + 8;         // l_pos entries per list (8 never-hit entries of slack behind each list)
+// PACKED LISTS (round 3, as tv_pair.hip): the lists of a step share the NT entry slots of LDS -- their entries are dealt to the
+// threads as ONE sequence, each list's share of an interval lands contiguously (an even start, 8 never-hit entries of slack
+// behind it), and an interval ends when NT entries are in, not when the longest list has had CAP.  Every list is still swept
+// in its own order, interval after interval, so every receiver takes its votes in the reference's order.
+#ifndef VH_TV_PACK
+#define VH_TV_PACK 1
+#endif
+constexpr int LSLOTS = VH_TV_PACK ? NT + 12 * NP : NP * LST;   // l_pos / l_ent entry slots
 #ifndef VH_TV_LIST2
 #define VH_TV_LIST2 1
 #endif
@@ -161,11 +169,13 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
   //             slack past the list hold a never-hit operand, so the sweep runs in whole batches of four and may
   //             prefetch one batch past the end
   //   l_mv[e]   source-mask value of the entry (masked kernels)
-  __shared__ __attribute__((aligned(16))) float4 l_ent[NP * CAP];
-  __shared__ __attribute__((aligned(16))) uint2 l_pos[NP * LST];
-  __shared__ float l_mv[MASKED_SRC ? NP * CAP : 1];
+  __shared__ __attribute__((aligned(16))) float4 l_ent[VH_TV_PACK ? LSLOTS : NP * CAP];
+  __shared__ __attribute__((aligned(16))) uint2 l_pos[LSLOTS];
+  __shared__ float l_mv[MASKED_SRC ? (VH_TV_PACK ? LSLOTS : NP * CAP) : 1];
   __shared__ int wave_tot[2][2][NW];
+#if !VH_TV_PACK
   __shared__ int cull[NP][CAP / 64][2 * NW]; // per list and wave holding entries: entries above / not below the rows each wave can reach
+#endif
   __shared__ unsigned claimed_tile;
   __shared__ int plane_cnt[88];              // entries per ring slot, [2h + 2 NP] (h <= 40)
   // dynamic LDS: two table slices (jz and jz + 1 of the current sender plane), [2][(2h+1)^2] float4
@@ -425,7 +435,7 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
       auto vote_one = [&](unsigned ent, int k, int s, unsigned e16) {
         const f4v tw = *lds_ptr<f4v>(r16s - e16);
         float fv = tw.x;
-        if (MASKED_SRC) fv = fv * l_mv[li * CAP + s];    // fv = w * mask value first (feature.hpp:2262-2275), then sal * fv
+        if (MASKED_SRC) fv = fv * l_mv[(VH_TV_PACK ? li : li * CAP) + s];    // fv = w * mask value first (feature.hpp:2262-2275), then sal * fv
         if (MODE == 3) {
           acc(T[0], fv);                      // "denominator += filter_val" (feature.hpp:2376-2377)
         } else {
@@ -455,8 +465,9 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
       // batches of four senders, two per trip: the next batch is in flight while this one is tested and voted, and the
       // two register sets swap roles without copies
       int s0 = i0 & ~1;                      // l_pos is read two entries at a time
-      const uint4* pq = reinterpret_cast<const uint4*>(l_pos + li * LST) + (s0 >> 1);
-      unsigned ent = ent_base + 16u * (unsigned)(li * CAP + s0);
+      // (li: the list's first LDS slot -- packed lists -- or its number)
+      const uint4* pq = reinterpret_cast<const uint4*>(l_pos + (VH_TV_PACK ? li : li * LST)) + (s0 >> 1);
+      unsigned ent = ent_base + 16u * (unsigned)((VH_TV_PACK ? li : li * CAP) + s0);
       asm volatile("" : "+v"(ent));
       uint4 a0 = pq[0], a1 = pq[1];
       while (s0 < i1) {   // uniform
@@ -556,6 +567,71 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
         int rho = (int)__builtin_sqrtf((float)(h * h - jn));
         while (rho * rho > h * h - jn) rho--;
         while ((rho + 1) * (rho + 1) <= h * h - jn) rho++;
+#if VH_TV_PACK
+        const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        const int t512 = wave * 64 + ln;                       // this thread's place in the interval's entry sequence
+        int pre[NP + 1], pl[NP];                               // (uniform) first position of list k in the step's sequence; its ring slot
+        pre[0] = 0;
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+          pre[k + 1] = pre[k] + lcnt[k];
+          pl[k] = __builtin_amdgcn_readfirstlane(((lsz[k] % P) + P) % P);
+        }
+        const int total = pre[NP];
+        for (int done = 0; done < total; done += NT) {          // uniform
+          int c[NP], len[NP], S[NP];                            // list k's share: sequence positions [c, c + len) of the NT, LDS slots from S
+#pragma unroll
+          for (int k = 0; k < NP; k++) {
+            const int lo = min(max(pre[k], done), done + NT), hi = min(pre[k + 1], done + NT);
+            c[k] = lo - done;
+            len[k] = max(hi - lo, 0);
+            S[k] = ((c[k] + 1) & ~1) + 10 * k;
+          }
+          const int g = done + t512;
+          int k_me = 0;
+#pragma unroll
+          for (int k = 1; k < NP; k++) k_me += (g >= pre[k]) ? 1 : 0;
+          int idx = g, slot = t512, pl_me = pl[0];
+#pragma unroll
+          for (int k = 0; k < NP; k++)
+            if (k_me == k) { idx = g - pre[k]; slot = S[k] + (t512 - c[k]); pl_me = pl[k]; }
+          if (g < total) {
+            const unsigned char* src_e = ring + (size_t)pl_me * plane_stride + (size_t)idx * RING_BYTES;
+            const float4 a = *reinterpret_cast<const float4*>(src_e);
+            const uint4 m = *reinterpret_cast<const uint4*>(src_e + 16);
+            l_ent[slot] = a;
+            const int e2 = (int)m.y + epz2;
+            l_pos[slot] = make_uint2(m.x | ((unsigned)((-(e2 >> 7)) & 0xff) << 16) | ((unsigned)(e2 & 127) << 24), m.z);
+            if (MASKED_SRC) l_mv[slot] = __uint_as_float(m.w);
+          }
+          if (t512 < 8 * NP) {                                  // 8 never-hit entries behind every (non-empty) list's share
+            int sk = S[0] + len[0], lk = len[0];
+#pragma unroll
+            for (int k = 1; k < NP; k++)
+              if ((t512 >> 3) == k) { sk = S[k] + len[k]; lk = len[k]; }
+            if (lk > 0) l_pos[sk + (t512 & 7)] = make_uint2(NEVER_HIT, 0u);
+          }
+          __syncthreads();   // lists (and slices) complete
+          // entries are in descending row order: of list k, this wave needs those from the first one at or below row
+          // 4w-13+rho to the last one at or above row 4w-16-rho; every wave counts both kinds itself, from the row bytes of the
+          // position words in LDS, 64 entries at a time
+          const int hi_row = 4 * wave - (TY / 2 - 3) + rho, lo_row = 4 * wave - TY / 2 - rho;
+#pragma unroll
+          for (int pp = 0; pp < NP; pp++) {
+            int i0 = 0, i1 = 0;
+            for (int j = 0; j < len[pp]; j += 64) {   // uniform
+              int ey = -128;
+              if (j + ln < len[pp]) ey = (int)(signed char)((l_pos[S[pp] + j + ln].x >> 8) & 0xff);
+              i0 += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ey > hi_row));
+              i1 += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ey >= lo_row));
+            }
+            // the upper plane's receivers see the sender one plane further down: |r - e|^2 grows by 1 - 2 epz
+            const int rcl = r_live[pp] ? recv_c + (half ? 1 - 2 * epz : 0) : 0x100000;
+            if (i1 > i0) sweep(TT[pp], S[pp], i0, i1, rcl);      // uniform
+          }
+          __syncthreads();   // everyone done reading before the lists or the slices are refilled
+        }
+#else
         const int li = min(tid / CAP, NP - 1);                 // (uniform per wave) the list this thread brings entries of
         const int ltid = tid - li * CAP;
         const bool bringer = tid < NP * CAP;
@@ -606,6 +682,7 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
           }
           __syncthreads();   // everyone done reading before the lists or the slices are refilled
         }
+#endif
       }
 
 #pragma unroll
@@ -663,7 +740,7 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
   if (nblk > 0x7fffffffLL) return fail(VISFD_HIP_EINVAL, "volume too large for one launch");
   if (nblk <= 0) { *handled = true; return VISFD_HIP_OK; }
   const size_t lds = 2 * slice_bytes;   // dynamic part: the slices of jz and jz + 1
-  const size_t lds_static = (sizeof(float4) * CAP + sizeof(uint2) * LST + sizeof(float) * (mask_src ? CAP : 0)) * NP + 2560;
+  const size_t lds_static = (sizeof(float4) + sizeof(uint2) + sizeof(float) * (mask_src ? 1 : 0)) * (size_t)(NT + 12 * NP + 16) + 2560;
   if (lds + lds_static > 150 * 1024) return VISFD_HIP_OK;   // window too wide for the LDS slice: baseline kernel
   const int mode = weights_only ? 3 : (curves ? 1 : (exponent == 4 ? 0 : (exponent == 2 ? 2 : 1)));
   // persistent workgroups (see the kernel): as many as the chip holds at once -- LDS allows 160 KB / (static +
