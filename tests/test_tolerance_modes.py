@@ -226,3 +226,24 @@ def test_tv_fma_receiver_plane_ranges(ctx, oracle):
                 assert np.max(np.abs(got[a:b] - want[a:b])) <= TOL * scale, "planes %d..%d" % (a, b)
             assert np.all(got[~covered] == 7.5), "planes outside the requested ranges were written"
         c2.close()
+
+
+def test_tv_fma_negative_saliencies(ctx, oracle):
+    """Senders with a NEGATIVE saliency (never so on the membrane path -- the score is a sum of squares -- but the entry point
+    takes any field): mixed signs, all negative, and a single negative sender."""
+    shape = (14, 40, 37)
+    sal, dirs = _sparse_field(shape, seed=77, frac=0.08)
+    rng = np.random.default_rng(5)
+    mixed = sal * np.where(rng.random(shape) < 0.4, -1.0, 1.0).astype(np.float32)
+    one = sal.copy()
+    zz, yy, xx = np.nonzero(one)
+    one[zz[3], yy[3], xx[3]] *= -1.0
+    for field, what in ((mixed, "mixed signs"), (-sal, "all negative"), (one, "one negative sender")):
+        for ex in (4, 2):
+            ref = oracle.tv_dense_stick(field, dirs, 3.0, ex, 2.0 ** 0.5)
+            with ctx.options(tv_fma=1):
+                got = ctx.tv_dense_stick(field, dirs, 3.0, ex, 2.0 ** 0.5)
+            assert_close_rel(got, ref, TOL, "fma tensor, %s, exponent %d" % (what, ex))
+            with ctx.options(tv_fma=1, tv_max_wg=2, tv_zrun=3):
+                got = ctx.tv_dense_stick(field, dirs, 3.0, ex, 2.0 ** 0.5)
+            assert_close_rel(got, ref, TOL, "fma tensor, %s, exponent %d, few workgroups" % (what, ex))
