@@ -98,6 +98,10 @@ __device__ unsigned long long g_pair_stamps[8];
 #define VH_STAMP(i) do {} while (0)
 #endif
 
+#ifdef VH_TV_IMBAL   // development build: the slowest wave's sweep time against the mean, per barrier interval
+__device__ unsigned long long g_pair_imbal[4];
+#endif
+
 #ifdef VH_TV_COUNT   // development build: how many senders the waves test, how many of those vote, how many lanes they reach
 __device__ unsigned long long g_pair_counts[8];   // tested, voted, lanes, -, steps with senders, barrier intervals, list entries, -
 #endif
@@ -160,6 +164,9 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
   __shared__ int cull[NW][2 * NW];           // per wave holding entries (waves WPL k .. WPL k + WPL - 1: list k): entries above / not below each wave's rows
 #endif
   __shared__ unsigned claimed_tile;
+#ifdef VH_TV_IMBAL
+  __shared__ unsigned imb_max, imb_sum;
+#endif
   __shared__ int plane_cnt[88];              // entries per ring slot, [2h + 2 NP] (h <= 40)
   extern __shared__ __attribute__((aligned(16))) unsigned char slices[];   // two table slices: S_j (jz = +j) in slot j & 1
 
@@ -684,6 +691,10 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
           VH_STAMP(1);
           __syncthreads();   // lists (and slices) complete
           VH_STAMP(2);
+#ifdef VH_TV_IMBAL
+          const unsigned long long imb_t0 = __builtin_amdgcn_s_memtime();
+          if (tid == 0) { imb_max = 0u; imb_sum = 0u; }
+#endif
           // entries are in descending row order: of list k, this wave needs those from the first one at or below row
           // 4w-13+rho to the last one at or above row 4w-16-rho.  Every wave counts both kinds itself, from the row bytes of
           // the position words in LDS, 64 entries at a time.
@@ -730,7 +741,17 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
             }
           }
           VH_STAMP(3);
+#ifdef VH_TV_IMBAL
+          if (lane == 0) {
+            const unsigned dt = (unsigned)(__builtin_amdgcn_s_memtime() - imb_t0);
+            atomicMax(&imb_max, dt);
+            atomicAdd(&imb_sum, dt);
+          }
+#endif
           __syncthreads();   // everyone done reading before the lists or the slices are refilled
+#ifdef VH_TV_IMBAL
+          if (tid == 0) { atomicAdd(&g_pair_imbal[0], (unsigned long long)imb_max); atomicAdd(&g_pair_imbal[1], (unsigned long long)imb_sum); atomicAdd(&g_pair_imbal[2], 1ull); }
+#endif
           VH_STAMP(4);
         }
 #else
@@ -958,6 +979,16 @@ int dev_tv_pair(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* t
     fprintf(stderr, "[tv_pair counts] steps with senders %.4g  barrier intervals %.4g (%.3f per step)  list entries per step %.1f (capacity %d)\n",
             (double)c4[4], (double)c4[5], (double)c4[5] / (double)c4[4], (double)c4[6] / (double)c4[4], NLIST * CAPH);
     VH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_pair_counts), z4, sizeof(z4)));
+  }
+#endif
+#ifdef VH_TV_IMBAL
+  {
+    unsigned long long c4[4], z4[4] = {};
+    VH_HIP(hipStreamSynchronize(st));
+    VH_HIP(hipMemcpyFromSymbol(c4, HIP_SYMBOL(g_pair_imbal), sizeof(c4)));
+    fprintf(stderr, "[tv_pair imbalance] intervals %.4g: slowest wave's sweep %.0f ticks on average, mean wave %.0f  -> max / mean %.3f\n",
+            (double)c4[2], (double)c4[0] / (double)c4[2], (double)c4[1] / (8.0 * (double)c4[2]), 8.0 * (double)c4[0] / (double)c4[1]);
+    VH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_pair_imbal), z4, sizeof(z4)));
   }
 #endif
 #ifdef VH_TV_STAMPS
