@@ -57,6 +57,9 @@ static_assert(TX == 8 || TX == 16, "one or two 8-column sub-patches per wave");
 #ifndef VH_PAIR_REMAT
 #define VH_PAIR_REMAT 1
 #endif
+#ifndef VH_PAIR_MIRROR
+#define VH_PAIR_MIRROR (VH_PAIR_PACK ? 1 : 0)
+#endif
 #ifndef VH_PAIR_NP
 #define VH_PAIR_NP (VH_PAIR_TX == 8 ? 2 : 1)
 #endif
@@ -220,14 +223,24 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
       int recv_c[NS];
       unsigned r16_0;     // LDS address of this lane's table entry of j = 0 in slice slot 0
     };
-    auto lane_consts = [&](unsigned ln) -> LaneConst {
+    // MIRRORED ROW BLOCKS.  A wave's receivers of pair pp are the four rows of block wv(pp): its own number for the first pair,
+    // NW - 1 - (its number) for the second (VH_PAIR_MIRROR = 2: half a tile further, cyclically -- the same effect).  The
+    // sweep of an interval lasts as long as its slowest wave (measured: 1.36 x the mean wave), and which rows are heavy -- those
+    // near a membrane -- is much the same for the two pairs of a pass: a wave that is heavy for one pair is lighter for the
+    // other.  Measured: max / mean 1.36 -> 1.31, 381 -> 376 ms; what remains is the scatter of eight waves' vote counts.
+    auto row_block = [&](int pp) -> int {
+      if (VH_PAIR_MIRROR == 1 && (pp & 1)) return NW - 1 - wave;
+      if (VH_PAIR_MIRROR == 2 && (pp & 1)) return (wave + NW / 2) % NW;
+      return wave;
+    };
+    auto lane_consts = [&](unsigned ln, int wv) -> LaneConst {
       LaneConst c;
       c.half = (int)(ln >> 5);
       const int l5 = (int)(ln & 31);
       const int lrow = l5 >> 3;
       const int lcol = (l5 & 3) + (((0xc33cu >> (l5 >> 1)) & 1u) ? 4 : 0);   // lane pairs 2-5, 8-9, 14-15 (lanes 4-11, 16-19, 28-31): the right block
       c.lx = lcol;
-      c.ly = wave * 4 + lrow;
+      c.ly = wv * 4 + lrow;
 #pragma unroll
       for (int s = 0; s < NS; s++) {
         const int rpx = c.lx + 8 * s - TX / 2, rpy = c.ly - TY / 2;
@@ -563,10 +576,10 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
       // this lane's receivers: plane rz + 2 pp + half of pair pp
       i64 rc[NP];                // (sub-patch s: rc + 8 s)
       bool r_live[NP][NS];
-      const LaneConst pc = lane_consts(fresh_lane());
-      const int rx = x0 + pc.lx, ry = y0 + pc.ly;             // (sub-patch s: column rx + 8 s)
 #pragma unroll
       for (int pp = 0; pp < NP; pp++) {
+        const LaneConst pc = lane_consts(fresh_lane(), row_block(pp));
+        const int rx = x0 + pc.lx, ry = y0 + pc.ly;             // (sub-patch s: column rx + 8 s)
         const int rzl = rz + 2 * pp + pc.half;
         const bool z_in = rzl < z_run1;
         rc[pp] = (i64)rzl * plane + (i64)ry * p.nx + rx;
@@ -615,9 +628,7 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
         while (rho * rho > h * h - jn) rho--;
         while ((rho + 1) * (rho + 1) <= h * h - jn) rho++;
 #if VH_PAIR_PACK
-        const LaneConst lc = lane_consts(fresh_lane());
-        const int half = lc.half;
-        const unsigned r16_0 = lc.r16_0;
+        const int half = (int)(fresh_lane() >> 5);
         const int t512 = wave * 64 + (int)fresh_lane();        // this thread's place in the interval's entry sequence
         int pre[NLIST + 1];                                    // (uniform) first position of list k in the step's sequence
         pre[0] = 0;
@@ -700,10 +711,11 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
           // the position words in LDS, 64 entries at a time.
           int i0[NLIST], i1[NLIST];
           {
-            const int hi_row = 4 * wave - (TY / 2 - 3) + rho, lo_row = 4 * wave - TY / 2 - rho;
             const int ln = (int)fresh_lane();
 #pragma unroll
             for (int k = 0; k < NLIST; k++) {
+              const int wv = row_block(k >> 1);
+              const int hi_row = 4 * wv - (TY / 2 - 3) + rho, lo_row = 4 * wv - TY / 2 - rho;
               int above = 0, upto = 0;
               for (int j = 0; j < len[k]; j += 64) {   // uniform
                 int ey = -128;
@@ -717,6 +729,9 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
           }
 #pragma unroll
           for (int pp = 0; pp < NP; pp++) {
+            if (i1[2 * pp] <= i0[2 * pp] && i1[2 * pp + 1] <= i0[2 * pp + 1]) continue;   // uniform
+            const LaneConst lc = lane_consts(fresh_lane(), row_block(pp));
+            const unsigned r16_0 = lc.r16_0;
             // plane A (above): the lower receiver plane sees it at jz = -d (slice S_d, rhat_z negated), the upper one at
             // 1-d (S_(d-1)); |r-e|^2 of the upper plane's receivers differs by 1 - 2 e'z
             if (i1[2 * pp] > i0[2 * pp]) {
@@ -761,7 +776,7 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
         for (int k = 1; k < NLIST; k++)
           if (li == k) { my_sz = lsz[k]; my_cnt = lcnt[k]; }
         const unsigned char* ring_plane = ring + (size_t)(((my_sz % P) + P) % P) * plane_stride;
-        const LaneConst lc = lane_consts(fresh_lane());
+        const LaneConst lc = lane_consts(fresh_lane(), wave);
         const int half = lc.half;
         const unsigned r16_0 = lc.r16_0;
         const int ltid = VH_PAIR_REMAT ? (wave % WPL) * 64 + (int)(fresh_lane()) : (tid & (CAPH - 1));
@@ -870,9 +885,9 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
 #endif
 
       {
-        const LaneConst sc = lane_consts(fresh_lane());         // (the receiver index again, rather than a value live since the pass began)
 #pragma unroll
         for (int pp = 0; pp < NP; pp++) {
+          const LaneConst sc = lane_consts(fresh_lane(), row_block(pp));   // (the receiver index again, rather than a value live since the pass began)
 #if VH_PAIR_REMAT
           const i64 rcs = (i64)(rz + 2 * pp + sc.half) * plane + (i64)(y0 + sc.ly) * p.nx + (x0 + sc.lx);
 #else
