@@ -59,7 +59,7 @@ void* visfd_hip_get_stream(visfd_hip_ctx* ctx);
 /* release the cached workspace (it otherwise persists between calls) */
 int visfd_hip_trim(visfd_hip_ctx* ctx);
 const char* visfd_hip_last_error(void);
-int visfd_hip_abi_version(void);   /* 6: entry points only get added between versions */
+int visfd_hip_abi_version(void);   /* 7: entry points only get added between versions */
 /* Tuning and test switches of a context (integers; unknown names are VISFD_HIP_EINVAL).  A new context starts from the
  * environment (VISFD_HIP_<NAME>, read once in visfd_hip_create); nothing reads the environment afterwards.
  *   gauss_3pass      1: the separable filter always takes its three single-axis passes

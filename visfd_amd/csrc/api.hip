@@ -286,7 +286,7 @@ void options_from_environment(visfd_hip_options* o) {
 }
 }  // namespace
 
-int visfd_hip_abi_version(void) { return 6; }   // 6: + visfd_hip_get_option, tolerance modes (tv_fma, gauss_fma); 5: + visfd_hip_set_option, CompactMultiChannelImage3D/TVDenseStick normalisation in the shim; 2: + blob post-processing, binning, LabelConnected and its host helpers; 3: + host DiagonalizeFlatSym3 / ConvertFlatSym2Evects3; 4: + LocalFluctuations, two-step ridge (scores / directions)
+int visfd_hip_abi_version(void) { return 7; }   // 7: + visfd_hip_membrane_detect_slab (host-memory face of the slab stage); 6: + visfd_hip_get_option, tolerance modes (tv_fma, gauss_fma), slab entry points; 5: + visfd_hip_set_option, CompactMultiChannelImage3D/TVDenseStick normalisation in the shim; 2: + blob post-processing, binning, LabelConnected and its host helpers; 3: + host DiagonalizeFlatSym3 / ConvertFlatSym2Evects3; 4: + LocalFluctuations, two-step ridge (scores / directions)
 const char* visfd_hip_last_error(void) { return g_last_error.c_str(); }
 
 int visfd_hip_create(int device, void* stream, visfd_hip_ctx** out) {
