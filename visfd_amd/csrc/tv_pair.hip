@@ -47,9 +47,15 @@ constexpr int NW = NT / 64;
 #ifndef VH_PAIR_TX
 #define VH_PAIR_TX 8
 #endif
-constexpr int TX = VH_PAIR_TX, TY = 4 * NW;
-constexpr int NS = TX / 8;             // receivers per lane and plane pair
-static_assert(TX == 8 || TX == 16, "one or two 8-column sub-patches per wave");
+// WAVES SIDE BY SIDE (build parameter VH_PAIR_WX = 2): a 16 x 16 tile, the waves' 8 x 4 patches in two columns.  The waves'
+// reach windows overlap more than in the 8 x 32 tile (their vote counts scatter less), at the price of more failed tests.
+#ifndef VH_PAIR_WX
+#define VH_PAIR_WX 1
+#endif
+constexpr int WX = VH_PAIR_WX;
+constexpr int NS = (WX == 1) ? VH_PAIR_TX / 8 : 1;   // receivers per lane and plane pair
+constexpr int TX = 8 * NS * WX, TY = 4 * NW / WX;
+static_assert((TX == 8 || TX == 16) && (WX == 1 || WX == 2), "one or two 8-column sub-patches per wave, or two waves side by side");
 // RECEIVER PAIRS PER PASS.  The sender planes of the receiver pairs (z, z+1) and (z+2, z+3) at step d are four different
 // planes, but they need the SAME two table slices S_(d-1), S_d: with NP = 2 a workgroup takes both pairs through the
 // steps together -- four lists and four sweeps per barrier interval (each wave: 2 x 6 sums), the same two slices, half as
@@ -68,7 +74,7 @@ constexpr int NLIST = 2 * NP;          // lists per interval: (A, B) of pair 0, 
 constexpr int CAPH = NT / NLIST;       // list entries per sender plane held in LDS per sweep: one per thread of its share of the workgroup
 constexpr int WPL = NW / NLIST;        // waves that bring (and count the row ranges of) one list
 static_assert(CAPH % 64 == 0 && WPL >= 1, "a list is brought by whole waves");
-constexpr int NCH_MAX = (NT >= 512 && TX == 8) ? 4 : 5;   // chunks of the region per wave the two-plane lister handles
+constexpr int NCH_MAX = (NT >= 512 && (TX == 8 || WX == 2)) ? 4 : 5;   // chunks of the region per wave the two-plane lister handles
 constexpr int LSTRIDE = CAPH + 8;      // LDS entries per list (8 never-hit entries of slack behind each list)
 // PACKED LISTS.  The lists of a step share the NT entry slots of LDS: their entries are dealt to the threads as ONE sequence
 // (list 0, then list 1, ...), each list's share of an interval lands contiguously (an even start, 8 never-hit entries of slack
@@ -239,8 +245,8 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
       const int l5 = (int)(ln & 31);
       const int lrow = l5 >> 3;
       const int lcol = (l5 & 3) + (((0xc33cu >> (l5 >> 1)) & 1u) ? 4 : 0);   // lane pairs 2-5, 8-9, 14-15 (lanes 4-11, 16-19, 28-31): the right block
-      c.lx = lcol;
-      c.ly = wv * 4 + lrow;
+      c.lx = (wv % WX) * 8 + lcol;
+      c.ly = (wv / WX) * 4 + lrow;
 #pragma unroll
       for (int s = 0; s < NS; s++) {
         const int rpx = c.lx + 8 * s - TX / 2, rpy = c.ly - TY / 2;
@@ -714,7 +720,7 @@ tv_pair_kernel(const float* __restrict__ sal, const float* __restrict__ dir, flo
             const int ln = (int)fresh_lane();
 #pragma unroll
             for (int k = 0; k < NLIST; k++) {
-              const int wv = row_block(k >> 1);
+              const int wv = row_block(k >> 1) / WX;
               const int hi_row = 4 * wv - (TY / 2 - 3) + rho, lo_row = 4 * wv - TY / 2 - rho;
               int above = 0, upto = 0;
               for (int j = 0; j < len[k]; j += 64) {   // uniform
