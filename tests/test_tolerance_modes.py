@@ -42,7 +42,7 @@ def test_tv_fma_seeded_goldens(ctx, tag):
     m = volgen.block_mask(volgen.MEM_SHAPE, seed=302) if tag == "mask" else None
     sal, dirs = g[tag + "_salthr"], g[tag + "_dir"]
     for opts in ({}, {"tv_max_wg": 3}, {"tv_max_wg": 1, "tv_zrun": 3}, {"tv_no_replay": 1}):
-        with ctx.options(tv_fma=1, **opts):
+        with ctx.options(tv_fma=1, tv_poison=1, **opts):
             for ex in (4, 2):
                 ten = ctx.tv_dense_stick(sal, dirs, volgen.MEM_TV_SIGMA, ex, 2.0 ** 0.5, m, m)
                 want = g["%s_tensor_e%d" % (tag, ex)]
@@ -53,7 +53,7 @@ def test_tv_fma_seeded_goldens(ctx, tag):
             ten = ctx.tv_dense_stick(sal, dirs, volgen.MEM_TV_SIGMA, 4, 2.0 ** 0.5, m, m, curves=True)
             assert_bits_equal(ten, g[tag + "_tensor_curves"], "curve-mode tensor under tv_fma")
     # the post-vote score from the tolerance-mode tensor
-    with ctx.options(tv_fma=1):
+    with ctx.options(tv_fma=1, tv_poison=1):
         ten = ctx.tv_dense_stick(sal, dirs, volgen.MEM_TV_SIGMA, 4, 2.0 ** 0.5, m, m)
     s2 = sal.copy()
     ctx.tensor_saliency(ten, po.ORDER_DECREASING, s2, m)
@@ -69,7 +69,7 @@ def test_tv_fma_windows(ctx, oracle, sigma_tv, shape):
     ref2 = oracle.tv_dense_stick(sal, dirs, sigma_tv, 2, 2.0 ** 0.5)
     for opts in ({}, {"tv_max_wg": 3}, {"tv_max_wg": 1}, {"tv_max_wg": 2, "tv_zrun": 4}, {"tv_max_wg": 2, "tv_no_replay": 1},
                  {"tv_zrun": 1}, {"tv_zrun": 5}):
-        with ctx.options(tv_fma=1, **opts):
+        with ctx.options(tv_fma=1, tv_poison=1, **opts):
             assert_close_rel(ctx.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5), ref, TOL, "fma tensor %g %s" % (sigma_tv, opts))
             assert_close_rel(ctx.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5, mask, mask), ref_m, TOL,
                              "fma masked tensor %g %s" % (sigma_tv, opts))
@@ -84,7 +84,7 @@ def test_tv_fma_dense_saliency_and_empty(ctx, oracle):
     sal = (rng.random(shape, dtype=np.float32) + 0.1).astype(np.float32)
     d = rng.standard_normal(shape + (3,)).astype(np.float32)
     d /= np.linalg.norm(d, axis=-1, keepdims=True).astype(np.float32)
-    with ctx.options(tv_fma=1):
+    with ctx.options(tv_fma=1, tv_poison=1):
         for ex in (2, 4):
             assert_close_rel(ctx.tv_dense_stick(sal, d, 3.0, ex, 2.0 ** 0.5), oracle.tv_dense_stick(sal, d, 3.0, ex, 2.0 ** 0.5), TOL,
                              "dense-saliency tensor e%d" % ex)
@@ -104,7 +104,7 @@ def test_tv_fma_large_magnitudes(ctx, oracle):
     sal, dirs = _sparse_field((18, 30, 40), seed=77)
     for scale in (1e-12, 1.0, 1e12):
         s = (sal * np.float32(scale)).astype(np.float32)
-        with ctx.options(tv_fma=1):
+        with ctx.options(tv_fma=1, tv_poison=1):
             assert_close_rel(ctx.tv_dense_stick(s, dirs, 3.0, 4, 2.0 ** 0.5), oracle.tv_dense_stick(s, dirs, 3.0, 4, 2.0 ** 0.5), TOL,
                              "saliency scale %g" % scale)
 
@@ -193,7 +193,7 @@ def test_tv_fma_very_wide_windows(ctx, oracle, sigma_tv, h):
     sal, dirs = _sparse_field(shape, seed=h, frac=0.02)
     ref = oracle.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5)
     for opts in ({}, {"tv_max_wg": 2, "tv_zrun": 3}):
-        with ctx.options(tv_fma=1, **opts):
+        with ctx.options(tv_fma=1, tv_poison=1, **opts):
             assert_close_rel(ctx.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5), ref, TOL, "fma tensor h=%d %s" % (h, opts))
 
 
@@ -241,7 +241,7 @@ def test_tv_fma_negative_saliencies(ctx, oracle):
     for field, what in ((mixed, "mixed signs"), (-sal, "all negative"), (one, "one negative sender")):
         for ex in (4, 2):
             ref = oracle.tv_dense_stick(field, dirs, 3.0, ex, 2.0 ** 0.5)
-            with ctx.options(tv_fma=1):
+            with ctx.options(tv_fma=1, tv_poison=1):
                 got = ctx.tv_dense_stick(field, dirs, 3.0, ex, 2.0 ** 0.5)
             assert_close_rel(got, ref, TOL, "fma tensor, %s, exponent %d" % (what, ex))
             with ctx.options(tv_fma=1, tv_max_wg=2, tv_zrun=3):

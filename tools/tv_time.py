@@ -27,7 +27,7 @@ ctx.threshold_fraction_dev(sal, 0.05)
 del src
 ten = torch.empty((6, n, n, n), device=dev)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-for mode in (0, 1):
+for mode in [int(m) for m in os.environ.get('TV_MODES', '0,1').split(',')]:
     ctx.set_option("tv_fma", mode)
     ts = []
     for _ in range(reps + 1):

@@ -22,6 +22,7 @@ SOURCES = ["host_math.cpp", "blob_post.cpp", "connect.cpp", "api.hip", "gauss.hi
 # (source, object stem, extra flags): the fused Gaussian is compiled once per window half-width
 # the vote loop is faster without the SLP vectoriser's packed-f32 shuffles (profiles/r01 notes)
 TV_VARIANT = [("tv_tiled.hip", "tv_tiled", ["-fno-slp-vectorize"]), ("tv_pair.hip", "tv_pair", ["-fno-slp-vectorize"]),
+              ("tv_box.hip", "tv_box", ["-fno-slp-vectorize"]),
               # the device eigen solver takes its one angle (atan2, sin, cos) in single precision: eigenvalues move by ~1e-7 of the
               # matrix's scale, the order of the difference between the device's and glibc's double-precision libm (csrc/eigen3.hpp)
               ("ridge.hip", "ridge", ["-DVH_EIG_F32_TRIG"])]

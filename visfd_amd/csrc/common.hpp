@@ -67,6 +67,7 @@ struct visfd_hip_options {
   int gauss_fma = 0;        // 1: TOLERANCE MODE of the single-sweep Gaussian (plain ApplyGauss only; DoG/LoG stay exact)
   int tv_zrun = 0;          // receiver planes per unit of work (0: default)
   int tv_no_replay = 0;     // 1: list every sender plane again for every receiver plane (nothing reused from the rings)
+  int tv_poison = 0;        // tests: NaN bit patterns in LDS, ring memory and the output before tensor voting runs (tv_box.hip)
   int tv_max_wg = 0;        // cap on the persistent grid (0: fill the chip); tests use it to make workgroups claim many units
   int64_t blob_test_cap = 0;   // pretend the pipelined blob scan's buffers hold this many entries (0: off)
   int debug = 0;
@@ -116,6 +117,17 @@ inline int tv_padded_row(int h) {
   while ((sp & 7) != 4) sp++;
   return sp;
 }
+
+// tolerance-mode vote table of tv_box.hip: a slice has 3 zero rows above and below its 2h+1 rows and rows of
+// tv_box_row(h) entries -- at least 3 zero entries behind the 2h+1 of a row, 4 modulo 8 (LDS banks) -- behind 4 guard
+// entries: entry (jy, jx) of slice jz at 4 + (jy + h + 3) * row + (jx + h); everything else is zero, so that the receivers
+// of a 4 x 4 sub-patch a sender does not reach read a zero weight
+inline int tv_box_row(int h) {
+  int sp = 2 * h + 1 + 3;
+  while ((sp & 7) != 4) sp++;
+  return sp;
+}
+inline int tv_box_slice(int h) { return (2 * h + 1 + 6) * tv_box_row(h) + 8; }
 
 // host-side arithmetic (taps.cpp)
 void host_gauss_taps(float sigma, int h, float* t);

@@ -126,6 +126,11 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
                  const float* mask_src, const float* mask_dst, i64 nx, i64 ny, i64 nz, i64 z_out0,
                  i64 z_out1, int h, const float4* dtab, int exponent, bool curves, bool weights_only, bool* handled);
 
+// declared in tv_box.hip
+int dev_tv_box(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* ten, const float* mask_src,
+               const float* mask_dst, i64 nx, i64 ny, i64 nz, i64 z_out0, i64 z_out1, int h, const float4* dtab_box,
+               int exponent, bool* handled);
+
 // declared in tv_pair.hip
 int dev_tv_pair(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* ten, const float* mask_src,
                 const float* mask_dst, i64 nx, i64 ny, i64 nz, i64 z_out0, i64 z_out1, int h, const float4* dtab_fma,
@@ -148,17 +153,20 @@ static int tv_table_device(visfd_hip_ctx* ctx, float sigma_tv, float cutoff, int
   // tv_padded_row(h) entries (tiled kernel: LDS banks); then the tolerance mode's {w, sqrt(2) rhat}, padded as well
   // (tv_pair.hip: vote_fma).  Pad entries are never read.
   const size_t sp = (size_t)tv_padded_row(h), m2 = n * n * sp;
-  std::vector<float4> tab(m + 2 * m2, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+  // and the same {w, sqrt(2) rhat} in the slice layout of tv_box.hip (zero rows and zero row tails: common.hpp)
+  const size_t spb = (size_t)tv_box_row(h), nslb = (size_t)tv_box_slice(h), m3 = n * nslb;
+  std::vector<float4> tab(m + 2 * m2 + m3, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
   const float rt2 = 1.41421356237309504880f;
   for (size_t k = 0; k < m; k++) {
     tab[k] = make_float4(w[k], rh[3 * k], rh[3 * k + 1], rh[3 * k + 2]);
     tab[m + (k / n) * sp + (k % n)] = tab[k];
     tab[m + m2 + (k / n) * sp + (k % n)] = make_float4(w[k], rt2 * rh[3 * k], rt2 * rh[3 * k + 1], rt2 * rh[3 * k + 2]);
+    tab[m + 2 * m2 + (k / (n * n)) * nslb + 4 + ((k / n) % n + 3) * spb + (k % n)] = tab[m + m2 + (k / n) * sp + (k % n)];
   }
   float4* dtab = nullptr;
   ctx->tv_table_dev = nullptr;
-  VH_TRY(ws(ctx, WS_TVTAB, m + 2 * m2, &dtab));
-  VH_HIP(hipMemcpyAsync(dtab, tab.data(), sizeof(float4) * (m + 2 * m2), hipMemcpyHostToDevice, ctx->stream));
+  VH_TRY(ws(ctx, WS_TVTAB, m + 2 * m2 + m3, &dtab));
+  VH_HIP(hipMemcpyAsync(dtab, tab.data(), sizeof(float4) * (m + 2 * m2 + m3), hipMemcpyHostToDevice, ctx->stream));
   VH_HIP(hipStreamSynchronize(ctx->stream));
   ctx->tv_table_dev = reinterpret_cast<float*>(dtab);
   ctx->tv_table_h = h;
@@ -186,7 +194,10 @@ int dev_tv_dense_stick(visfd_hip_ctx* ctx, const float* sal, const float* dir, f
   bool handled = false;
   // tolerance mode (option tv_fma): fused multiply-adds and mirror-paired sender planes (tv_pair.hip); windows and vote
   // forms it does not take fall through to the exact kernels
-  if (!ctx->opt.tv_dense && ctx->opt.tv_fma && !curves)
+  if (!ctx->opt.tv_dense && ctx->opt.tv_fma == 1 && !curves)
+    VH_TRY(dev_tv_box(ctx, sal, dir, ten, mask_src, mask_dst, nx, ny, nz, z_out0, z_out1, h,
+                      dtab + m_packed + 2 * m_padded, exponent, &handled));
+  if (!handled && !ctx->opt.tv_dense && ctx->opt.tv_fma && !curves)
     VH_TRY(dev_tv_pair(ctx, sal, dir, ten, mask_src, mask_dst, nx, ny, nz, z_out0, z_out1, h,
                        dtab + m_packed + m_padded, exponent, &handled));
   if (handled) return VISFD_HIP_OK;
