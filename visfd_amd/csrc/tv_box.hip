@@ -60,6 +60,7 @@ __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rs, unsigned by
 
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
@@ -123,8 +124,11 @@ __device__ __forceinline__ void vote_fma(float (&T)[6], const f4v& snd /* sal, n
 // (volatile: the reads of the vote loop stay in program order -- requested a step ahead of their use -- and are neither
 // paired into ds_read2 forms nor sunk behind the loop's exits)
 __device__ __forceinline__ f4v lds_f4(unsigned a) { return *(const volatile __attribute__((address_space(3))) f4v*)(uintptr_t)a; }
+__device__ __forceinline__ void lds_store_u2(unsigned a, unsigned x, unsigned y) {
+  u2v v = {x, y};
+  *(__attribute__((address_space(3))) u2v*)(uintptr_t)a = v;
+}
 __device__ __forceinline__ uint2 lds_u2(unsigned a) {
-  typedef unsigned u2v __attribute__((ext_vector_type(2)));
   const u2v v = *(const volatile __attribute__((address_space(3))) u2v*)(uintptr_t)a;
   return make_uint2(v.x, v.y);
 }
@@ -134,8 +138,9 @@ __device__ __forceinline__ uint2 lds_u2(unsigned a) {
 // lane's table entry for a sender at E = 0.  Software pipeline over two register sets: a step's entry is requested three
 // steps ahead, its sender and table reads one step ahead of its vote.  Entries behind a stream's last one are stale or
 // null, never invalid addresses: the reads run ahead of the votes.
-template <int MODE, bool ZNEG>
+template <int MODE, bool ZNEG, int OFF>
 __device__ __forceinline__ void vote_hits(float (&T)[6], unsigned hp, int nst, unsigned r16) {
+  hp += (unsigned)OFF;
   uint2 ea = lds_u2(hp), eb = lds_u2(hp + 8u);
   f4v sa = lds_f4(ea.x), ta = lds_f4(r16 - ea.y);
   ea = lds_u2(hp + 16u);
@@ -172,6 +177,7 @@ tv_box_kernel(const float* __restrict__ sal, const float* __restrict__ dir, floa
   __shared__ int wave_tot[2][2][NW];
   __shared__ unsigned claimed_tile;
   __shared__ int plane_cnt[88];              // entries per ring slot, [2h + 2 NP] (h <= 40)
+  __shared__ int rho_tab[44];                // floor(sqrt(h^2 - j^2)), j = 0..h: the radius of slice j
   extern __shared__ __attribute__((aligned(16))) unsigned char slices[];   // two table slices: S_j (jz = +j) in slot j & 1
 
   const int tid = threadIdx.x;
@@ -214,6 +220,13 @@ tv_box_kernel(const float* __restrict__ sal, const float* __restrict__ dir, floa
 
   // every stale hit entry must be a valid pair of LDS addresses: the vote loop reads ahead of its hits
   if (tid == 0) l_ent[LSLOTS] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (tid <= h) {
+    const int r2 = h * h - tid * tid;
+    int rho = (int)__builtin_sqrtf((float)r2);
+    while (rho * rho > r2) rho--;
+    while ((rho + 1) * (rho + 1) <= r2) rho++;
+    rho_tab[tid] = rho;
+  }
   for (int i = tid; i < NW * NSUB * 2 * HCAP; i += NT) (&l_hit[0][0][0][0])[i] = make_uint2(null_ent, 0u);
 
   for (;;) {
@@ -233,6 +246,13 @@ tv_box_kernel(const float* __restrict__ sal, const float* __restrict__ dir, floa
     // the second: the sweep of an interval lasts as long as its slowest wave, and which rows are heavy -- those near a
     // membrane -- is much the same for the two pairs of a pass.
     auto row_block = [&](int pp) -> int { return (pp & 1) ? NW - 1 - wave : wave; };
+    // The per-lane constants of a phase are RECOMPUTED from the lane number where the phase starts (the empty asm hides the
+    // number's origin from the compiler): hoisted out of the step loop they stay live across the vote loops and are spilled.
+    auto fresh_lane = [&]() -> unsigned {
+      unsigned ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+      asm volatile("" : "+v"(ln));
+      return ln;
+    };
 
     // ---- LISTING, two planes at a time (window regions of <= 4 chunks per wave: h <= 12).  Every load of a phase is in
     // flight at once -- the saliencies of both planes (kept in registers across the barrier: one read per voxel), then the
@@ -414,8 +434,11 @@ tv_box_kernel(const float* __restrict__ sal, const float* __restrict__ dir, floa
       constexpr bool ZNEG = decltype(ZN)::value;
       constexpr int pp = decltype(PP)::value;
       const float cx0 = (float)h + 1.5f;
+      // this wave's hit entries: sub-patch s, stream t at hb + (2 s + t) * HCAP * 8 (the constants are offset fields)
+      const unsigned hb = lds_addr(&l_hit[wave][0][0][0]);
       for (int c = i0; c < i1; c += 64) {   // uniform
-        const int e = c + lane;
+        const int ln = (int)fresh_lane();
+        const int e = c + ln;
         uint2 pw = make_uint2(0xffffffffu, 0u);           // lanes without an entry: far from every box
         if (e < i1) pw = l_pos[base + e];
         const float exf = (float)(pw.x & 0xffu), eyf = (float)((pw.x >> 8) & 0xffu);
@@ -429,11 +452,13 @@ tv_box_kernel(const float* __restrict__ sal, const float* __restrict__ dir, floa
           const bool hit = __builtin_fmaf(dx, dx, dy2) <= rr;
           const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
           nh[s] = __builtin_popcountll(bal);
-          const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-          if (hit) l_hit[wave][s][rank & 1][rank >> 1] = make_uint2(ent, pw.y);
+          const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+          // (sub-patch 1's table entries are 4 columns = 64 bytes further: taken off the sender's offset here, so that the
+          // vote loop has one table base for both sub-patches)
+          if (hit) lds_store_u2(hb + (unsigned)(2 * s * HCAP * 8) + (rank & 1u) * (unsigned)(HCAP * 8) + (rank >> 1) * 8u, ent, pw.y - 64u * (unsigned)s);
           // the second stream's last step when the count is odd: the null sender (zero saliency, zero normal), placed on the
           // sub-patch's first receiver so that every lane reads a table entry of the slice (finite; times 0)
-          if (lane == 0) l_hit[wave][s][1][nh[s] >> 1] = make_uint2(null_ent, null_e16 + 64u * (unsigned)s);
+          if (ln == 0) lds_store_u2(hb + (unsigned)((2 * s + 1) * HCAP * 8) + (unsigned)(nh[s] >> 1) * 8u, null_ent, null_e16);
         }
 #ifdef VH_TV_COUNT
         cnt_tested += (unsigned)min(64, i1 - c);
@@ -442,12 +467,9 @@ tv_box_kernel(const float* __restrict__ sal, const float* __restrict__ dir, floa
 #endif
         __builtin_amdgcn_wave_barrier();
         asm volatile("" ::: "memory");
-#pragma unroll
-        for (int s = 0; s < NSUB; s++) {
-          if (nh[s] == 0) continue;   // uniform
-          const unsigned hp = lds_addr(&l_hit[wave][s][0][0]) + (unsigned)(strm * HCAP * 8);
-          vote_hits<MODE, ZNEG>(TT[pp][s], hp, (nh[s] + 1) >> 1, r16 + 64u * (unsigned)s);
-        }
+        const unsigned hp = hb + (fresh_lane() >> 5) * (unsigned)(HCAP * 8);
+        if (nh[0] > 0) vote_hits<MODE, ZNEG, 0>(TT[pp][0], hp, (nh[0] + 1) >> 1, r16);              // (uniform)
+        if (nh[1] > 0) vote_hits<MODE, ZNEG, 2 * HCAP * 8>(TT[pp][1], hp, (nh[1] + 1) >> 1, r16);
         asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
       }
@@ -487,6 +509,12 @@ tv_box_kernel(const float* __restrict__ sal, const float* __restrict__ dir, floa
       // lower receiver plane, 1-d for the upper one) and B = z + 1 - d (below: jz = d-1 and d).  All of them need the slices
       // S_(d-1) and S_d; the direction of d alternates from pass to pass, so that every step -- the first of a pass
       // included -- finds one of its two slices in LDS already.
+      const int rzs = rz % P;            // ring slot of plane rz; the planes of a pass are within (-P, 2P) of it
+      auto ring_slot = [&](int sz) -> int {
+        int sl = rzs + (sz - rz);
+        sl = sl < 0 ? sl + P : sl;
+        return sl >= P ? sl - P : sl;
+      };
       for (int step = 0; step <= h; step++) {
         const int d = up ? step + 1 : h + 1 - step;
         int lsz[NLIST], lcnt[NLIST];     // list 2 pp: plane A of pair pp; list 2 pp + 1: its plane B
@@ -497,8 +525,8 @@ tv_box_kernel(const float* __restrict__ sal, const float* __restrict__ dir, floa
           const bool pair_live = z < z_run1;                   // (uniform) a pair beyond the end of the run takes no votes
           lsz[2 * pp] = z + d;
           lsz[2 * pp + 1] = z + 1 - d;
-          lcnt[2 * pp] = (pair_live && lsz[2 * pp] <= sz_hi) ? __builtin_amdgcn_readfirstlane(plane_cnt[lsz[2 * pp] % P]) : 0;
-          lcnt[2 * pp + 1] = (pair_live && lsz[2 * pp + 1] >= sz_lo) ? __builtin_amdgcn_readfirstlane(plane_cnt[lsz[2 * pp + 1] % P]) : 0;
+          lcnt[2 * pp] = (pair_live && lsz[2 * pp] <= sz_hi) ? __builtin_amdgcn_readfirstlane(plane_cnt[ring_slot(lsz[2 * pp])]) : 0;
+          lcnt[2 * pp + 1] = (pair_live && lsz[2 * pp + 1] >= sz_lo) ? __builtin_amdgcn_readfirstlane(plane_cnt[ring_slot(lsz[2 * pp + 1])]) : 0;
           cmax = max(cmax, max(lcnt[2 * pp], lcnt[2 * pp + 1]));
         }
         if (cmax == 0) continue;   // uniform
@@ -512,11 +540,8 @@ tv_box_kernel(const float* __restrict__ sal, const float* __restrict__ dir, floa
           if (need[k] >= 0) slot_has[j & 1] = j;
         }
         // rows a wave can reach: the nearer of its two receiver planes is |jz| = d-1 away from either sender plane
-        const int jn = (d - 1) * (d - 1);
-        int rho = (int)__builtin_sqrtf((float)(h * h - jn));
-        while (rho * rho > h * h - jn) rho--;
-        while ((rho + 1) * (rho + 1) <= h * h - jn) rho++;
-        const float rr = (float)(h * h - jn);
+        const int rho = __builtin_amdgcn_readfirstlane(rho_tab[d - 1]);
+        const float rr = (float)(h * h - (d - 1) * (d - 1));
         int pre[NLIST + 1];                                    // (uniform) first position of list k in the step's sequence
         pre[0] = 0;
 #pragma unroll
@@ -524,7 +549,7 @@ tv_box_kernel(const float* __restrict__ sal, const float* __restrict__ dir, floa
         const int total = pre[NLIST];
         int pl[NLIST];                                         // (uniform) ring slot of list k's plane
 #pragma unroll
-        for (int k = 0; k < NLIST; k++) pl[k] = __builtin_amdgcn_readfirstlane(((lsz[k] % P) + P) % P);
+        for (int k = 0; k < NLIST; k++) pl[k] = ring_slot(lsz[k]);
         for (int done = 0; done < total; done += NT) {   // uniform
           // PACKED LISTS: the lists of a step are dealt to the threads as ONE sequence; list k's share of this interval:
           // sequence positions = LDS slots [c[k], c[k] + len[k])
@@ -592,20 +617,22 @@ tv_box_kernel(const float* __restrict__ sal, const float* __restrict__ dir, floa
             if (i1[2 * pp] <= i0[2 * pp] && i1[2 * pp + 1] <= i0[2 * pp + 1]) return;   // uniform
             const int rb = row_block(pp);
             const float cy = (float)(4 * rb + h) + 1.5f;
+            const unsigned ln = fresh_lane();
+            const int fq = (int)((ln & 31u) >> 2);
+            const int fcol = (int)(ln & 3u), frow = fq >> 1, fpl = (0x96 >> fq) & 1;
             // this lane's table entry of a sender at region position (0, 0), sub-patch 0, in slice slot 0:
-            // 4 guard entries, then row (jy + h + YPAD), column (jx + h) with jy = 4 rb + lrow + h - ey, jx = lcol + h - ex
-            const unsigned r16_0 = lds_addr(slices) + 16u * (unsigned)(4 + (4 * rb + lrow + 2 * h + YPAD) * SP + lcol + 2 * h);
+            // 4 guard entries, then row (jy + h + YPAD), column (jx + h) with jy = 4 rb + frow + h - ey, jx = fcol + h - ex
+            const unsigned r16_0 = lds_addr(slices) + 16u * (unsigned)(4 + (4 * rb + frow + 2 * h + YPAD) * SP + fcol + 2 * h);
+            const unsigned null_e16 = 16u * (unsigned)((4 * rb + h) * SP + h);
             // plane A (above): the lower receiver plane sees it at jz = -d (slice S_d, rhat_z negated), the upper one at 1-d
             if (i1[2 * pp] > i0[2 * pp]) {
-              const int js = lpl ? d - 1 : d;
-              test_vote(std::true_type{}, PP, c[2 * pp], i0[2 * pp], i1[2 * pp], r16_0 + (unsigned)(16 * nsl) * (unsigned)(js & 1), cy, rr,
-                        16u * (unsigned)((4 * rb + h) * SP + h));
+              const int js = fpl ? d - 1 : d;
+              test_vote(std::true_type{}, PP, c[2 * pp], i0[2 * pp], i1[2 * pp], r16_0 + (unsigned)(16 * nsl) * (unsigned)(js & 1), cy, rr, null_e16);
             }
             // plane B (below): jz = d-1 for the lower plane (S_(d-1)), d for the upper one (S_d)
             if (i1[2 * pp + 1] > i0[2 * pp + 1]) {
-              const int js = lpl ? d : d - 1;
-              test_vote(std::false_type{}, PP, c[2 * pp + 1], i0[2 * pp + 1], i1[2 * pp + 1], r16_0 + (unsigned)(16 * nsl) * (unsigned)(js & 1), cy, rr,
-                        16u * (unsigned)((4 * rb + h) * SP + h));
+              const int js = fpl ? d : d - 1;
+              test_vote(std::false_type{}, PP, c[2 * pp + 1], i0[2 * pp + 1], i1[2 * pp + 1], r16_0 + (unsigned)(16 * nsl) * (unsigned)(js & 1), cy, rr, null_e16);
             }
           };
           pair_votes(std::integral_constant<int, 0>{});
