@@ -135,27 +135,36 @@ __device__ __forceinline__ uint2 lds_u2(unsigned a) {
 
 // The votes of one hit list: nst steps, each serving one hit per stream.  hp: LDS address of this lane's stream's entries
 // {LDS address of the sender's {saliency, normal}, byte offset E of the sender in a table slice}; r16: LDS address of this
-// lane's table entry for a sender at E = 0.  Software pipeline over two register sets: a step's entry is requested three
-// steps ahead, its sender and table reads one step ahead of its vote.  Entries behind a stream's last one are stale or
-// null, never invalid addresses: the reads run ahead of the votes.
+// lane's table entry for a sender at E = 0.  Software pipeline over two register sets, four steps per trip: two entries
+// come with one ds_read_b128, requested two to four steps ahead; a step's sender and table reads are requested one step
+// ahead of its vote.  Entries behind a stream's last one are stale or null, never invalid addresses: the reads run ahead
+// of the votes.
+__device__ __forceinline__ u4v lds_u4(unsigned a) { return *(const volatile __attribute__((address_space(3))) u4v*)(uintptr_t)a; }
+
 template <int MODE, bool ZNEG, int OFF>
 __device__ __forceinline__ void vote_hits(float (&T)[6], unsigned hp, int nst, unsigned r16) {
-  hp += (unsigned)OFF;
-  uint2 ea = lds_u2(hp), eb = lds_u2(hp + 8u);
-  f4v sa = lds_f4(ea.x), ta = lds_f4(r16 - ea.y);
-  ea = lds_u2(hp + 16u);
+  u4v h0 = lds_u4(hp + (unsigned)OFF), h1 = lds_u4(hp + (unsigned)(OFF + 16));
+  f4v sa = lds_f4(h0.x), ta = lds_f4(r16 - h0.y);
   f4v sb, tb;
   int k = 0;
   for (;;) {   // uniform
-    sb = lds_f4(eb.x);
-    tb = lds_f4(r16 - eb.y);
-    eb = lds_u2(hp + 24u);
+    sb = lds_f4(h0.z);
+    tb = lds_f4(r16 - h0.w);
     vote_fma<MODE, ZNEG>(T, sa, ta);
     if (++k >= nst) break;
-    sa = lds_f4(ea.x);
-    ta = lds_f4(r16 - ea.y);
-    hp += 16u;
-    ea = lds_u2(hp + 16u);
+    sa = lds_f4(h1.x);
+    ta = lds_f4(r16 - h1.y);
+    h0 = lds_u4(hp + (unsigned)(OFF + 32));
+    vote_fma<MODE, ZNEG>(T, sb, tb);
+    if (++k >= nst) break;
+    sb = lds_f4(h1.z);
+    tb = lds_f4(r16 - h1.w);
+    vote_fma<MODE, ZNEG>(T, sa, ta);
+    if (++k >= nst) break;
+    sa = lds_f4(h0.x);
+    ta = lds_f4(r16 - h0.y);
+    h1 = lds_u4(hp + (unsigned)(OFF + 48));
+    hp += 32u;
     vote_fma<MODE, ZNEG>(T, sb, tb);
     if (++k >= nst) break;
   }
