@@ -477,8 +477,10 @@ tv_box_kernel(const float* __restrict__ sal, const float* __restrict__ dir, floa
         __builtin_amdgcn_wave_barrier();
         asm volatile("" ::: "memory");
         const unsigned hp = hb + (fresh_lane() >> 5) * (unsigned)(HCAP * 8);
+        __builtin_amdgcn_s_setprio(1);   // a voting wave is on its workgroup's critical path; waves that list or fill are not (337 -> 333 ms)
         if (nh[0] > 0) vote_hits<MODE, ZNEG, 0>(TT[pp][0], hp, (nh[0] + 1) >> 1, r16);              // (uniform)
         if (nh[1] > 0) vote_hits<MODE, ZNEG, 2 * HCAP * 8>(TT[pp][1], hp, (nh[1] + 1) >> 1, r16);
+        __builtin_amdgcn_s_setprio(0);
         asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
       }
