@@ -269,7 +269,7 @@ def main():
     ten = torch.empty((6,) + shape, device=device, dtype=torch.float32)
     torch.cuda.synchronize()
 
-    MODE_OPTS = {"tolerance": dict(tv_fma=1, gauss_fma=1), "exact": dict(tv_fma=0, gauss_fma=0)}
+    MODE_OPTS = {"tolerance": dict(tv_fma=1, gauss_fma=1, eig_f32=1), "exact": dict(tv_fma=0, gauss_fma=0, eig_f32=0)}
     ratio = api.ratio_from_threshold(0.03)
     # ONE source-halo exchange per step, at the deepest depth any stage needs (the widest LoG window + the 3x3x3 scan;
     # the Gaussian and the ridge stage need less): the stage functions are told the ghost planes are current

@@ -59,7 +59,7 @@ void* visfd_hip_get_stream(visfd_hip_ctx* ctx);
 /* release the cached workspace (it otherwise persists between calls) */
 int visfd_hip_trim(visfd_hip_ctx* ctx);
 const char* visfd_hip_last_error(void);
-int visfd_hip_abi_version(void);   /* 7: entry points only get added between versions */
+int visfd_hip_abi_version(void);   /* 8: entry points only get added between versions */
 /* Tuning and test switches of a context (integers; unknown names are VISFD_HIP_EINVAL).  A new context starts from the
  * environment (VISFD_HIP_<NAME>, read once in visfd_hip_create); nothing reads the environment afterwards.
  *   gauss_3pass      1: the separable filter always takes its three single-axis passes
@@ -71,6 +71,10 @@ int visfd_hip_abi_version(void);   /* 7: entry points only get added between ver
  *   gauss_fma        1: TOLERANCE MODE of the plain separable Gaussian (ApplyGauss / ApplySeparable, symmetric taps,
  *                    no mask): fused multiply-adds and a reciprocal normaliser, same 1e-5 bar.  DoG / LoG / BlobDog feed
  *                    index comparisons and ignore it (always the reference's bits); default 0 = exact
+ *   eig_f32          1: TOLERANCE MODE of the device eigen solver (ridge scores and directions, post-vote score, the
+ *                    diagonalise batch): its one angle -- atan2, sin, cos -- in single precision; eigenvalues move by about
+ *                    one float ulp.  default 0 = the reference's double-precision angle (eigen3_simple.hpp:74-81)
+ *   tv_poison        tests: NaN bit patterns in LDS, ring memory and the output before tolerance-mode tensor voting runs
  *   tv_zrun          receiver planes per unit of work (default 32)
  *   tv_no_replay     1: every sender plane is listed again for every receiver plane (no reuse within a run)
  *   tv_max_wg        cap on the number of persistent workgroups (tests: forces many units of work per workgroup)
@@ -348,6 +352,16 @@ int visfd_hip_ridge_scores_dev(visfd_hip_ctx*, const float* src, const float* ma
                                float* smoothed);
 int visfd_hip_ridge_directions_dev(visfd_hip_ctx*, const float* smoothed, int64_t nx, int64_t ny, int64_t nz,
                                    float sigma, int eival_order, const float* saliency, float* direction);
+/* The optional PEAK-HEIGHT factor of the two score loops (`-membrane-background SIGMA_B`, alias `-detection-background`;
+ * bin/filter_mrc/settings.cpp:2802-2825): background = ApplyGauss(image, SIGMA_B, floor(SIGMA_B * ratio), mask, normalize)
+ * (handlers.cpp:1577-1592), and every score is multiplied by (image - background) in float (handlers.cpp:1698-1702).
+ * visfd_hip_peak_background_dev computes the background volume; visfd_hip_ridge_scores_bg_dev is
+ * visfd_hip_ridge_scores_dev with the factor applied to every score (background == NULL: no factor). */
+int visfd_hip_peak_background_dev(visfd_hip_ctx*, const float* image, const float* mask, int64_t nx, int64_t ny, int64_t nz,
+                                  float sigma_background, float truncate_ratio, int normalize, float* background);
+int visfd_hip_ridge_scores_bg_dev(visfd_hip_ctx*, const float* src, const float* mask, int64_t nx, int64_t ny,
+                                  int64_t nz, float sigma, float truncate_ratio, int eival_order, const float* background,
+                                  float* saliency, float* smoothed);
 
 /* ---- a12 (second half): global top-fraction threshold, handlers.cpp:1751-1797 -------------------- */
 /* threshold = (floor(n_unmasked*fraction))-th largest unmasked saliency; every voxel with
@@ -410,9 +424,13 @@ int visfd_hip_tensor_saliency(visfd_hip_ctx*, const float* tensor, const float* 
                               int eival_order, float* saliency_inout);
 int visfd_hip_tensor_saliency_dev(visfd_hip_ctx*, const float* tensor, const float* mask,
                                   int64_t nvox, int eival_order, float* saliency_inout);
+/* with the peak-height factor (handlers.cpp:1883-1887): score *= image - background (both NULL: no factor) */
+int visfd_hip_tensor_saliency_bg_dev(visfd_hip_ctx*, const float* tensor, const float* mask, int64_t nvox, int eival_order,
+                                     const float* image, const float* background, float* saliency_inout);
 
 /* ---- a9+a10+a11+a12+a14+a15 in one call: the compute section of HandleTV ------------------------- */
-/* bin/filter_mrc/handlers.cpp:1618-1892 for SURFACE_RIDGE without background subtraction:
+/* bin/filter_mrc/handlers.cpp:1618-1892 for SURFACE_RIDGE (the _bg forms add the optional peak-height factor of
+ * handlers.cpp:1577-1605,1698-1702,1883-1887: sigma_background > 0 multiplies both scores by image - background):
  * CalcHessian (feature.hpp:1203) -> per-voxel eigen/score/direction loop (handlers.cpp:1645-1746) ->
  * saliency threshold (handlers.cpp:1751-1797: top `best_fraction` of unmasked voxels when
  * best_fraction >= 0, else the absolute value `threshold_abs`) -> TV3D::TVDenseStick when sigma_tv > 0
@@ -432,6 +450,17 @@ int visfd_hip_membrane_detect_dev(visfd_hip_ctx*, const float* src, const float*
                                   float sigma_tv, int tv_exponent, float tv_cutoff_ratio,
                                   float* saliency_out, float* tensor_out, float* direction_out,
                                   float* threshold_out);
+int visfd_hip_membrane_detect_bg(visfd_hip_ctx*, const float* src, const float* mask,
+                                 int64_t nx, int64_t ny, int64_t nz, float sigma, float truncate_ratio,
+                                 int eival_order, float best_fraction, float threshold_abs, float sigma_tv,
+                                 int tv_exponent, float tv_cutoff_ratio, float sigma_background, int normalize_background,
+                                 float* saliency_out, float* tensor_out, float* direction_out, float* threshold_out);
+int visfd_hip_membrane_detect_bg_dev(visfd_hip_ctx*, const float* src, const float* mask,
+                                     int64_t nx, int64_t ny, int64_t nz, float sigma, float truncate_ratio,
+                                     int eival_order, float best_fraction, float threshold_abs,
+                                     float sigma_tv, int tv_exponent, float tv_cutoff_ratio, float sigma_background,
+                                     int normalize_background, float* saliency_out, float* tensor_out, float* direction_out,
+                                     float* threshold_out);
 
 /* ---- Z-slab helpers for the separable filter (multi-GPU) -------------------------- */
 /* Same as apply_gauss_dev on a slab: arrays hold planes [z_lo, z_lo+nz_local) of a volume of height
@@ -497,6 +526,17 @@ int visfd_hip_membrane_detect_slab_dev(visfd_hip_slab*, float* src, float* sal, 
 int visfd_hip_membrane_detect_slab(visfd_hip_slab*, const float* src_owned, int64_t nx, int64_t ny, float sigma,
                                    float truncate_ratio, int eival_order, float best_fraction, float sigma_tv, int exponent,
                                    float tv_truncate_ratio, float* sal_owned, float* tensor_owned, float* threshold_out);
+/* The slab forms with the peak-height factor (sigma_background > 0; `background`: one more slab volume on the device face).
+ * The ghost depth must cover floor(sigma_background * truncate_ratio) as well. */
+int visfd_hip_membrane_detect_slab_bg_dev(visfd_hip_slab*, float* src, float* sal, float* dirs, float* tensor, float* scratch,
+                                          float* background, int64_t nx, int64_t ny, float sigma, float truncate_ratio,
+                                          int eival_order, float best_fraction, float sigma_tv, int exponent,
+                                          float tv_truncate_ratio, float sigma_background, int normalize_background,
+                                          int src_halo_ready, float* threshold_out);
+int visfd_hip_membrane_detect_slab_bg(visfd_hip_slab*, const float* src_owned, int64_t nx, int64_t ny, float sigma,
+                                      float truncate_ratio, int eival_order, float best_fraction, float sigma_tv, int exponent,
+                                      float tv_truncate_ratio, float sigma_background, int normalize_background,
+                                      float* sal_owned, float* tensor_owned, float* threshold_out);
 /* BlobDog (lib/visfd/feature.hpp:53-427) on one slab with absolute thresholds: blobs of the OWNED planes only, iz as
  * GLOBAL plane index.  The host merges the ranks' lists (and applies ratio thresholds, which need the global best). */
 int visfd_hip_blob_dog_slab_dev(visfd_hip_slab*, float* src, int64_t nx, int64_t ny, const float* blob_sigma, int n_sigma,

@@ -318,6 +318,11 @@ def test_cli_membrane_scenario_equals_reference_program(cli, ref_cli, tmp_path):
     (["-membrane", "minima", 55, "-tv", 4, "-bin", 1, "-detection-threshold", 2000.0], False),
     (["-membrane", "minima", 90, "-tv", 3], False),                                    # sigma > 1.8 voxels: automatic binning + un-binning
     (["-membrane", "minima", 55, "-tv", 4, "-bin", 1, "-truncate", 2.0, "-tv-truncate-ratio", 1.2], False),
+    # the peak-height factor of both score loops (handlers.cpp:1577-1605,1698-1702,1883-1887; settings.cpp:2802-2825)
+    (["-membrane", "minima", 55, "-tv", 4, "-tv-angle-exponent", 4, "-bin", 1, "-membrane-background", 120], False),
+    (["-membrane", "maxima", 55, "-tv", 4, "-bin", 1, "-detection-background", 90, "-tv-best", 0.2], False),
+    (["-membrane", "minima", 45, "-bin", 1, "-membrane-background", 100], False),     # ridge scores only
+    (["-membrane", "minima", 90, "-tv", 3, "-membrane-background", 150], False),      # with automatic binning
     (["-log-d", 60, "-dog-delta", 0.05, "-truncate-threshold", 0.01], True),
     (["-gauss", 30, "-normalize-filters", "no"], True),
 ])

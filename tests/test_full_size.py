@@ -99,7 +99,7 @@ def _check_membrane(gpu, oracle, src, crops, E, dense=0.12, ridge_crops=4, tv_fm
         got_c = np.ascontiguousarray(np.stack([_crop(ten[k], c0, c0 + E) for k in range(6)], axis=-1))
         assert np.abs(want_c).max() > 0
         if tv_fma:   # tolerance mode: 1e-5 of the crop's own scale (stricter than the field's)
-            assert_close_rel(got_c, want_c, 1e-5, "tolerance-mode vote tensor in the crop at %s" % ((z0, y0, x0),))
+            assert_close_rel(got_c, want_c, 1e-5, "tolerance-mode vote tensor in the crop at %s" % ((z0, y0, x0),), pervoxel=0.005)
             assert not np.array_equal(got_c.view(np.uint32), want_c.view(np.uint32)), "the tolerance kernel did not run"
         else:
             assert_bits_equal(got_c, want_c, "vote tensor in the crop at %s" % ((z0, y0, x0),))
@@ -231,3 +231,82 @@ def test_blob_1024_cubed_crops_equal_oracle(gpu, volume, oracle):
             total += len(b)
             assert_bits_equal(volgen.sort_blobs(a, asc), volgen.sort_blobs(b, asc), "blobs in the crop at %s" % ((z0, y0, x0),))
     assert total > 50
+
+
+def test_exact_mode_eigen_census(gpu, volume, oracle):
+    """Exact mode IS the reference's arithmetic in the ridge stage: with eig_f32 = 0 (the default) the device's float
+    eigenvalues / saliencies equal the oracle's bit for bit in (almost) every voxel -- the device's and glibc's double
+    libm differ at ~1e-16, which disappears in the float store -- whereas the single-precision angle (eig_f32 = 1, a
+    tolerance option) moves most of them by an ulp.  Counted here on tests/golden/eigen.npz and on the 1024^3 bench
+    volume: values bit-equal to the oracle with and without the option, and voxels on the other side of the top-5 % cut.
+    The census is written to gpurun_out/r4_eig_census.txt (copied to profiles/)."""
+    import bench
+    from conftest import golden
+    from visfd_amd import api
+    torch, dev, ctx = gpu
+    lines = []
+    g = golden("eigen")
+    mats = g["mats"]
+    for mode in (0, 1):
+        with ctx.options(eig_f32=mode):
+            for oname, order in (("inc", 0), ("dec", 1)):
+                d = ctx.diagonalize(mats, order)
+                ref = g["diag_" + oname]
+                eq = d[:, :3].view(np.uint32) == ref[:, :3].view(np.uint32)
+                lines.append("golden eigen.npz  eig_f32=%d order=%s: %d of %d float eigenvalues bit-equal to the reference (%.4f)" % (
+                    mode, oname, int(eq.sum()), eq.size, eq.mean()))
+                if mode == 0:
+                    assert eq.mean() > 0.995, lines[-1]
+    # the bench volume: scores of the whole volume in both modes, the cut each selects, and crops against the oracle
+    P = bench.MEMBRANE
+    sigma, ratio, order = P["sigma"], api.ratio_from_threshold(0.03), api.DECREASING_EIVALS
+    sal = {}
+    thr = {}
+    for mode in (0, 1):
+        s = torch.empty_like(volume)
+        sm = torch.empty_like(volume)
+        with ctx.options(eig_f32=mode):
+            ctx.ridge_scores_dev(volume, s, sm, sigma, ratio, order)
+        ctx.synchronize()
+        del sm
+        raw = s.clone()
+        thr[mode] = ctx.threshold_fraction_dev(s, P["best_fraction"])
+        ctx.synchronize()
+        sal[mode] = (raw, s != 0)
+        del s
+    nvox = volume.numel()
+    same_bits = int((sal[0][0].view(torch.int32) == sal[1][0].view(torch.int32)).sum().item())
+    flips = int((sal[0][1] != sal[1][1]).sum().item())
+    lines.append("bench volume 1024^3: saliencies bit-equal between eig_f32=0 and =1: %d of %d (%.4f); thresholds %.9g / %.9g; "
+                 "voxels on different sides of the top-5 %% cut: %d (of %d kept)" % (
+                     same_bits, nvox, same_bits / nvox, thr[0], thr[1], flips, int(sal[0][1].sum().item())))
+    hg = int(math.floor(np.float32(sigma) * np.float32(ratio))) + 1
+    E = 48
+    dims = np.array(volume.shape)
+    tot = {0: [0, 0, 0], 1: [0, 0, 0]}
+    for (z0, y0, x0) in [(0, 0, 0), (500, 300, 700), (N - E, N - E, N - E), (int(0.35 * N) - 20, 100, 100)]:
+        c0 = np.array([z0, y0, x0])
+        lo = np.maximum(c0 - hg, 0)
+        hi = np.minimum(c0 + E + hg, dims)
+        _, hess = oracle.calc_hessian(_crop(volume, lo, hi), np.float32(sigma), ratio)
+        s_o, _ = oracle.hessian_saliency(hess, po.ORDER_DECREASING)
+        o = c0 - lo
+        inner = [slice(o[k] + (hg if lo[k] > 0 else 0), o[k] + E - (hg if hi[k] < dims[k] else 0)) for k in range(3)]
+        innerg = [slice(c0[k] + (hg if lo[k] > 0 else 0), c0[k] + E - (hg if hi[k] < dims[k] else 0)) for k in range(3)]
+        b = s_o[inner[0], inner[1], inner[2]]
+        for mode in (0, 1):
+            a = sal[mode][0][innerg[0], innerg[1], innerg[2]].cpu().numpy()
+            kept = sal[mode][1][innerg[0], innerg[1], innerg[2]].cpu().numpy()
+            tot[mode][0] += int((a.view(np.uint32) == b.view(np.uint32)).sum())
+            tot[mode][1] += a.size
+            tot[mode][2] += int((kept != (b >= np.float32(thr[0]))).sum())
+    for mode in (0, 1):
+        lines.append("bench volume, 4 crops of %d^3 against the oracle, eig_f32=%d: %d of %d saliencies bit-equal (%.5f); voxels whose side of the "
+                     "cut (threshold of the exact run) differs from the oracle's: %d" % (E, mode, tot[mode][0], tot[mode][1],
+                                                                                        tot[mode][0] / tot[mode][1], tot[mode][2]))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "r4_eig_census.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+    assert tot[0][0] / tot[0][1] > 0.995, "exact mode: device saliencies are not the oracle's bits"
+    assert tot[0][2] == 0, "exact mode: voxels on the wrong side of the cut"

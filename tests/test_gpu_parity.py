@@ -537,6 +537,54 @@ def test_membrane_reference_fixture_end_to_end(ctx, oracle):
     assert_close_rel(s2, g["tvsal_dec"], 1e-4 if diff.any() else 1e-5, "post-TV saliency")
 
 
+@pytest.mark.parametrize("masked", [False, True])
+def test_membrane_peak_height_factor_vs_oracle(ctx, oracle, masked):
+    """`-membrane-background`: both score loops multiply by (image - background), background = ApplyGauss(image, sigma_b)
+    (bin/filter_mrc/handlers.cpp:1577-1605, :1698-1702, :1883-1887).  The whole stage through the C ABI
+    (visfd_hip_membrane_detect_bg) against the oracle's stages chained the same way; a background of width 0 is the
+    plain stage."""
+    shape = volgen.MEM_SHAPE
+    src = volgen.membrane_volume(shape, seed=301)
+    m = volgen.block_mask(shape, seed=302) if masked else None
+    r = ratio(oracle)
+    sigma, sigma_b, frac, sigma_tv = volgen.MEM_SIGMA, np.float32(3.0), volgen.MEM_FRACTION, volgen.MEM_TV_SIGMA
+    hb = int(np.floor(np.float32(sigma_b) * np.float32(r)))
+    bg, _ = oracle.gauss_hw(src, (sigma_b,) * 3, (hb,) * 3, m, True)
+    peak = (src - bg).astype(np.float32)
+    _, hess = oracle.calc_hessian(src, sigma, r, m)
+    sal_o, dirs_o = oracle.hessian_saliency(hess, po.ORDER_DECREASING, m)
+    sal_o = (sal_o * peak).astype(np.float32)
+    if m is not None:
+        sal_o[m == 0] = 0.0
+    raw_o = sal_o.copy()
+    thr_o = oracle.threshold_fraction(sal_o, frac, m)
+    for sigma_tv_run in (0.0, sigma_tv):
+        sal, ten, dirs, thr = ctx.membrane_detect(src, sigma, r, po.ORDER_DECREASING, frac, 0.0, sigma_tv_run, 4, 2.0 ** 0.5, m,
+                                                  want_tensor=True, want_dir=True, sigma_background=sigma_b)
+        scale = float(np.abs(raw_o).max())
+        assert abs(thr - thr_o) <= 1e-5 * scale
+        if sigma_tv_run == 0.0:
+            kept, kept_o = sal != 0, sal_o != 0
+            diff = kept != kept_o
+            assert np.all(np.abs(raw_o[diff] - thr_o) <= 1e-5 * scale), "threshold membership differs away from the tie band"
+            both_kept = kept & kept_o
+            assert np.all(np.abs(sal[both_kept] - sal_o[both_kept]) <= 1e-5 * scale)
+            assert (raw_o < 0).any(), "the test volume should have voxels with a negative peak height (dark membranes)"
+        else:
+            ten_o = oracle.tv_dense_stick(sal_o, dirs_o, sigma_tv, 4, 2.0 ** 0.5, m, m)
+            assert_close_rel(ten, ten_o, 1e-4, "vote tensor from peak-height-weighted saliencies")
+            s2 = sal_o.copy()
+            oracle.tensor_saliency(ten_o, po.ORDER_DECREASING, s2, m)
+            want = s2.copy()
+            sel = np.ones(shape, bool) if m is None else (m != 0)
+            want[sel] = (s2[sel] * peak[sel]).astype(np.float32)
+            assert_close_rel(sal, want, 1e-4, "post-vote score times peak height")
+    # width 0: the plain stage, bit for bit the same call without the factor
+    a = ctx.membrane_detect(src, sigma, r, po.ORDER_DECREASING, frac, 0.0, sigma_tv, 4, 2.0 ** 0.5, m, sigma_background=0.0)
+    b = ctx.membrane_detect(src, sigma, r, po.ORDER_DECREASING, frac, 0.0, sigma_tv, 4, 2.0 ** 0.5, m)
+    assert_bits_equal(a[0], b[0], "no background == plain stage")
+
+
 def _sparse_field(shape, seed, fraction=0.06):
     """Random saliency (a fraction non-zero, clustered on a plane) + random unit directions."""
     rng = np.random.default_rng(seed)

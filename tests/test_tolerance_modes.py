@@ -16,6 +16,11 @@ from oracle import pyoracle as po
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-5
+# the per-voxel reading of the same tolerance (conftest.assert_close_rel): the fraction of significant voxels (|want| above
+# 1e-3 of the field's scale) allowed to differ by more than 1e-5 of THEIR OWN value.  A vote tensor is a sum of hundreds of
+# signed terms: its rounding error scales with the sum of their magnitudes, not with the result, so small results of large
+# cancellations exceed 1e-5 of themselves while staying ~1e-7 of the field's scale.  Measured: profiles/r04_tolerance_pervoxel.txt
+PV = 0.005
 
 
 @pytest.fixture(scope="module")
@@ -46,7 +51,7 @@ def test_tv_fma_seeded_goldens(ctx, tag):
             for ex in (4, 2):
                 ten = ctx.tv_dense_stick(sal, dirs, volgen.MEM_TV_SIGMA, ex, 2.0 ** 0.5, m, m)
                 want = g["%s_tensor_e%d" % (tag, ex)]
-                assert_close_rel(ten, want, TOL, "fma tensor e%d %s" % (ex, opts))
+                assert_close_rel(ten, want, TOL, "fma tensor e%d %s" % (ex, opts), pervoxel=PV)
                 assert not np.array_equal(ten.view(np.uint32), want.view(np.uint32)) or not np.any(want), \
                     "the tolerance mode did not run (bits equal the exact kernel's)"
             # exponent 3 and curve mode have no tolerance form: the option must leave them exact / as before
@@ -57,7 +62,7 @@ def test_tv_fma_seeded_goldens(ctx, tag):
         ten = ctx.tv_dense_stick(sal, dirs, volgen.MEM_TV_SIGMA, 4, 2.0 ** 0.5, m, m)
     s2 = sal.copy()
     ctx.tensor_saliency(ten, po.ORDER_DECREASING, s2, m)
-    assert_close_rel(s2, g[tag + "_tvsal"], TOL, "post-TV saliency from the tolerance-mode tensor")
+    assert_close_rel(s2, g[tag + "_tvsal"], TOL, "post-TV saliency from the tolerance-mode tensor", pervoxel=PV)
 
 
 @pytest.mark.parametrize("sigma_tv,shape", [(8.66, (20, 37, 45)), (11.0, (12, 40, 50)), (1.0, (9, 20, 33)), (3.0, (41, 33, 70))])
@@ -70,10 +75,10 @@ def test_tv_fma_windows(ctx, oracle, sigma_tv, shape):
     for opts in ({}, {"tv_max_wg": 3}, {"tv_max_wg": 1}, {"tv_max_wg": 2, "tv_zrun": 4}, {"tv_max_wg": 2, "tv_no_replay": 1},
                  {"tv_zrun": 1}, {"tv_zrun": 5}):
         with ctx.options(tv_fma=1, tv_poison=1, **opts):
-            assert_close_rel(ctx.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5), ref, TOL, "fma tensor %g %s" % (sigma_tv, opts))
+            assert_close_rel(ctx.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5), ref, TOL, "fma tensor %g %s" % (sigma_tv, opts), pervoxel=PV)
             assert_close_rel(ctx.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5, mask, mask), ref_m, TOL,
-                             "fma masked tensor %g %s" % (sigma_tv, opts))
-            assert_close_rel(ctx.tv_dense_stick(sal, dirs, sigma_tv, 2, 2.0 ** 0.5), ref2, TOL, "fma tensor e2 %g %s" % (sigma_tv, opts))
+                             "fma masked tensor %g %s" % (sigma_tv, opts), pervoxel=PV)
+            assert_close_rel(ctx.tv_dense_stick(sal, dirs, sigma_tv, 2, 2.0 ** 0.5), ref2, TOL, "fma tensor e2 %g %s" % (sigma_tv, opts), pervoxel=PV)
 
 
 def test_tv_fma_dense_saliency_and_empty(ctx, oracle):
@@ -87,7 +92,7 @@ def test_tv_fma_dense_saliency_and_empty(ctx, oracle):
     with ctx.options(tv_fma=1, tv_poison=1):
         for ex in (2, 4):
             assert_close_rel(ctx.tv_dense_stick(sal, d, 3.0, ex, 2.0 ** 0.5), oracle.tv_dense_stick(sal, d, 3.0, ex, 2.0 ** 0.5), TOL,
-                             "dense-saliency tensor e%d" % ex)
+                             "dense-saliency tensor e%d" % ex, pervoxel=PV)
         zero = np.zeros((9, 10, 11), np.float32)
         dz = np.zeros((9, 10, 11, 3), np.float32)
         assert not np.any(ctx.tv_dense_stick(zero, dz, 3.0, 4, 2.0 ** 0.5))
@@ -95,7 +100,7 @@ def test_tv_fma_dense_saliency_and_empty(ctx, oracle):
         one[4, 5, 6] = 2.5
         dz[4, 5, 6] = (0.6, 0.0, 0.8)
         assert_close_rel(ctx.tv_dense_stick(one, dz, 3.0, 4, 2.0 ** 0.5), oracle.tv_dense_stick(one, dz, 3.0, 4, 2.0 ** 0.5), TOL,
-                         "single sender")
+                         "single sender", pervoxel=PV)
 
 
 def test_tv_fma_large_magnitudes(ctx, oracle):
@@ -106,7 +111,7 @@ def test_tv_fma_large_magnitudes(ctx, oracle):
         s = (sal * np.float32(scale)).astype(np.float32)
         with ctx.options(tv_fma=1, tv_poison=1):
             assert_close_rel(ctx.tv_dense_stick(s, dirs, 3.0, 4, 2.0 ** 0.5), oracle.tv_dense_stick(s, dirs, 3.0, 4, 2.0 ** 0.5), TOL,
-                             "saliency scale %g" % scale)
+                             "saliency scale %g" % scale, pervoxel=PV)
 
 
 # ------------------------------------------------------------------------------------------ Gaussian
@@ -120,13 +125,13 @@ def test_gauss_fma_vs_oracle(ctx, oracle, shape, h):
     with ctx.options(gauss_fma=1):
         got, A2 = ctx.gauss_hw(src, sigma, (h, h, h))
     assert A == A2
-    assert_close_rel(got, want, TOL, "fma gaussian h=%d %s" % (h, shape))
+    assert_close_rel(got, want, TOL, "fma gaussian h=%d %s" % (h, shape), pervoxel=PV)
     # zero-mean data: the relative bar is against the field's own (small) scale
     src0 = rng.standard_normal(shape).astype(np.float32)
     want0, _ = oracle.gauss_hw(src0, sigma, (h, h, h))
     with ctx.options(gauss_fma=1):
         got0, _ = ctx.gauss_hw(src0, sigma, (h, h, h))
-    assert_close_rel(got0, want0, TOL, "fma gaussian of zero-mean noise h=%d %s" % (h, shape))
+    assert_close_rel(got0, want0, TOL, "fma gaussian of zero-mean noise h=%d %s" % (h, shape), pervoxel=PV)
 
 
 def test_gauss_fma_leaves_index_paths_exact(ctx, oracle):
@@ -194,7 +199,7 @@ def test_tv_fma_very_wide_windows(ctx, oracle, sigma_tv, h):
     ref = oracle.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5)
     for opts in ({}, {"tv_max_wg": 2, "tv_zrun": 3}):
         with ctx.options(tv_fma=1, tv_poison=1, **opts):
-            assert_close_rel(ctx.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5), ref, TOL, "fma tensor h=%d %s" % (h, opts))
+            assert_close_rel(ctx.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5), ref, TOL, "fma tensor h=%d %s" % (h, opts), pervoxel=PV)
 
 
 def test_tv_fma_receiver_plane_ranges(ctx, oracle):
@@ -243,7 +248,7 @@ def test_tv_fma_negative_saliencies(ctx, oracle):
             ref = oracle.tv_dense_stick(field, dirs, 3.0, ex, 2.0 ** 0.5)
             with ctx.options(tv_fma=1, tv_poison=1):
                 got = ctx.tv_dense_stick(field, dirs, 3.0, ex, 2.0 ** 0.5)
-            assert_close_rel(got, ref, TOL, "fma tensor, %s, exponent %d" % (what, ex))
+            assert_close_rel(got, ref, TOL, "fma tensor, %s, exponent %d" % (what, ex), pervoxel=PV)
             with ctx.options(tv_fma=1, tv_max_wg=2, tv_zrun=3):
                 got = ctx.tv_dense_stick(field, dirs, 3.0, ex, 2.0 ** 0.5)
-            assert_close_rel(got, ref, TOL, "fma tensor, %s, exponent %d, few workgroups" % (what, ex))
+            assert_close_rel(got, ref, TOL, "fma tensor, %s, exponent %d, few workgroups" % (what, ex), pervoxel=PV)

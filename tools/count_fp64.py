@@ -18,7 +18,7 @@ FP64_FLOP = {"ridge_score_kernel": 153, "ridge_directions_kernel": 987, "tensor_
 def main():
     out = os.path.join(tempfile.mkdtemp(), "ridge.s")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-                           "-DVH_EIG_F32_TRIG", "-I" + os.path.join(ROOT, "visfd_amd", "csrc"), "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(ROOT, "visfd_amd", "csrc"), "-I" + os.path.join(ROOT, "include"),
                            "-S", "--cuda-device-only", os.path.join(ROOT, "visfd_amd", "csrc", "ridge.hip"), "-o", out],
                           stderr=subprocess.DEVNULL)
     name, stats = None, {}

@@ -105,6 +105,19 @@ _SIGS = {
                                                 _fp]),
     "visfd_hip_tensor_saliency": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, _vp]),
     "visfd_hip_tensor_saliency_dev": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, _vp]),
+    # the peak-height factor (`-membrane-background`)
+    "visfd_hip_peak_background_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, C.c_float, C.c_float, C.c_int, _vp]),
+    "visfd_hip_ridge_scores_bg_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, C.c_float, C.c_float, C.c_int, _vp, _vp, _vp]),
+    "visfd_hip_tensor_saliency_bg_dev": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, _vp, _vp, _vp]),
+    "visfd_hip_membrane_detect_bg": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, C.c_float, C.c_float, C.c_int, C.c_float,
+                                               C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, C.c_int, _vp, _vp, _vp, _fp]),
+    "visfd_hip_membrane_detect_bg_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, C.c_float, C.c_float, C.c_int,
+                                                   C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, C.c_int,
+                                                   _vp, _vp, _vp, _fp]),
+    "visfd_hip_membrane_detect_slab_bg_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, C.c_float, C.c_float, C.c_int,
+                                                        C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, _fp]),
+    "visfd_hip_membrane_detect_slab_bg": (C.c_int, [_vp, _vp, _i64, _i64, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float,
+                                                    C.c_int, C.c_float, C.c_float, C.c_int, _vp, _vp, _fp]),
     "visfd_hip_bin_array3d": (C.c_int, [_vp, _vp, C.POINTER(_i64), _vp, C.POINTER(_i64), _ip]),
     "visfd_hip_bin_array3d_dev": (C.c_int, [_vp, _vp, C.POINTER(_i64), _vp, C.POINTER(_i64), _ip]),
     "visfd_hip_unbin_array3d": (C.c_int, [_vp, _vp, C.POINTER(_i64), _vp, C.POINTER(_i64), _ip]),
@@ -642,17 +655,20 @@ class Context:
                                                       self._sizes(dst.shape), _i3(offset) if offset is not None else None))
 
     def membrane_detect(self, src, sigma, ratio, order, best_fraction=0.05, threshold_abs=0.0, sigma_tv=0.0,
-                        tv_exponent=4, tv_cutoff=2.0 ** 0.5, mask=None, want_tensor=True, want_dir=False):
-        """HandleTV's compute section on host arrays -> (saliency, tensor or None, dirs or None, threshold)."""
+                        tv_exponent=4, tv_cutoff=2.0 ** 0.5, mask=None, want_tensor=True, want_dir=False,
+                        sigma_background=0.0, normalize_background=True):
+        """HandleTV's compute section on host arrays -> (saliency, tensor or None, dirs or None, threshold).
+        sigma_background > 0: `-membrane-background`, both scores times (image - background)."""
         nz, ny, nx = src.shape
         sal = np.empty_like(src)
         ten = np.zeros((nz, ny, nx, 6), np.float32) if want_tensor else None
         dirs = np.zeros((nz, ny, nx, 3), np.float32) if want_dir else None
         thr = C.c_float()
-        self._chk(self._L.visfd_hip_membrane_detect(self._h, _np(src), _np(mask), nx, ny, nz, float(sigma),
-                                                    float(ratio), int(order), float(best_fraction),
-                                                    float(threshold_abs), float(sigma_tv), int(tv_exponent),
-                                                    float(tv_cutoff), _np(sal), _np(ten), _np(dirs), C.byref(thr)))
+        self._chk(self._L.visfd_hip_membrane_detect_bg(self._h, _np(src), _np(mask), nx, ny, nz, float(sigma),
+                                                       float(ratio), int(order), float(best_fraction),
+                                                       float(threshold_abs), float(sigma_tv), int(tv_exponent),
+                                                       float(tv_cutoff), float(sigma_background), int(bool(normalize_background)),
+                                                       _np(sal), _np(ten), _np(dirs), C.byref(thr)))
         return sal, ten, dirs, thr.value
 
     # ---------------------------------------------------------------- device face (torch)
@@ -700,11 +716,18 @@ class Context:
         self._chk(self._L.visfd_hip_ridge_saliency_dev(self._h, _dev(src), _dev(mask), nx, ny, nz, float(sigma),
                                                        float(ratio), int(order), _dev(sal), _dev(dirs)))
 
-    def ridge_scores_dev(self, src, sal, smoothed, sigma, ratio, order, mask=None):
-        """Smoothing + Hessian + eigenvalues + score for every voxel; `smoothed` receives the smoothed volume."""
+    def ridge_scores_dev(self, src, sal, smoothed, sigma, ratio, order, mask=None, background=None):
+        """Smoothing + Hessian + eigenvalues + score for every voxel; `smoothed` receives the smoothed volume.
+        background (a volume from peak_background_dev): every score times (src - background)."""
         nz, ny, nx = src.shape
-        self._chk(self._L.visfd_hip_ridge_scores_dev(self._h, _dev(src), _dev(mask), nx, ny, nz, float(sigma),
-                                                     float(ratio), int(order), _dev(sal), _dev(smoothed)))
+        self._chk(self._L.visfd_hip_ridge_scores_bg_dev(self._h, _dev(src), _dev(mask), nx, ny, nz, float(sigma),
+                                                        float(ratio), int(order), _dev(background), _dev(sal), _dev(smoothed)))
+
+    def peak_background_dev(self, src, background, sigma_background, ratio, mask=None, normalize=True):
+        """The background of the peak-height factor: ApplyGauss(src, sigma_b, floor(sigma_b * ratio)) (handlers.cpp:1577-1592)."""
+        nz, ny, nx = src.shape
+        self._chk(self._L.visfd_hip_peak_background_dev(self._h, _dev(src), _dev(mask), nx, ny, nz, float(sigma_background),
+                                                        float(ratio), int(bool(normalize)), _dev(background)))
 
     def ridge_directions_dev(self, smoothed, sal, dirs, sigma, order):
         """Principal directions of the voxels with sal != 0 (the others keep what dirs held)."""
@@ -748,9 +771,9 @@ class Context:
                                                             int(z1), float(sigma_tv), int(exponent), float(cutoff),
                                                             int(curves)))
 
-    def tensor_saliency_dev(self, tensor, sal, order, mask=None):
-        self._chk(self._L.visfd_hip_tensor_saliency_dev(self._h, _dev(tensor), _dev(mask), sal.numel(), int(order),
-                                                        _dev(sal)))
+    def tensor_saliency_dev(self, tensor, sal, order, mask=None, image=None, background=None):
+        self._chk(self._L.visfd_hip_tensor_saliency_bg_dev(self._h, _dev(tensor), _dev(mask), sal.numel(), int(order),
+                                                           _dev(image), _dev(background), _dev(sal)))
 
 
 class Slab:
@@ -876,17 +899,18 @@ class Slab:
         self.ctx._chk(self._L.visfd_hip_slab_exchange_dev(self._h, arr, len(tensors), nx, ny, int(depth)))
 
     def membrane_detect(self, src, sal, dirs, tensor, scratch, sigma, ratio, order, best_fraction, sigma_tv, exponent=4,
-                        cutoff=2.0 ** 0.5, src_halo_ready=False):
+                        cutoff=2.0 ** 0.5, src_halo_ready=False, sigma_background=0.0, background=None, normalize_background=True):
         nz, ny, nx = src.shape
         assert nz == self.nz_local and dirs.shape[0] == 3 and tensor.shape[0] == 6
         thr = C.c_float()
-        self.ctx._chk(self._L.visfd_hip_membrane_detect_slab_dev(
-            self._h, _dev(src), _dev(sal), _dev(dirs), _dev(tensor), _dev(scratch), nx, ny, float(sigma), float(ratio), int(order),
-            float(best_fraction), float(sigma_tv), int(exponent), float(cutoff), int(bool(src_halo_ready)), C.byref(thr)))
+        self.ctx._chk(self._L.visfd_hip_membrane_detect_slab_bg_dev(
+            self._h, _dev(src), _dev(sal), _dev(dirs), _dev(tensor), _dev(scratch), _dev(background), nx, ny, float(sigma),
+            float(ratio), int(order), float(best_fraction), float(sigma_tv), int(exponent), float(cutoff), float(sigma_background),
+            int(bool(normalize_background)), int(bool(src_halo_ready)), C.byref(thr)))
         return float(thr.value)
 
     def membrane_detect_host(self, src_owned, sigma, ratio, order, best_fraction, sigma_tv, exponent=4, cutoff=2.0 ** 0.5,
-                             want_tensor=False):
+                             want_tensor=False, sigma_background=0.0, normalize_background=True):
         """visfd_hip_membrane_detect_slab: the slab stage on HOST arrays of the rank's owned planes (numpy float32
         [z1-z0][ny][nx]).  Returns (saliency of the owned planes, tensor [..., 6] or None, threshold)."""
         src_owned = np.ascontiguousarray(src_owned, np.float32)
@@ -895,9 +919,10 @@ class Slab:
         sal = np.empty_like(src_owned)
         ten = np.empty(src_owned.shape + (6,), np.float32) if want_tensor else None
         thr = C.c_float()
-        self.ctx._chk(self._L.visfd_hip_membrane_detect_slab(
+        self.ctx._chk(self._L.visfd_hip_membrane_detect_slab_bg(
             self._h, _np(src_owned), nx, ny, float(sigma), float(ratio), int(order), float(best_fraction), float(sigma_tv),
-            int(exponent), float(cutoff), _np(sal), _np(ten), C.byref(thr)))
+            int(exponent), float(cutoff), float(sigma_background), int(bool(normalize_background)), _np(sal), _np(ten),
+            C.byref(thr)))
         return sal, ten, float(thr.value)
 
     def blob_dog(self, src, sigmas, delta=0.02, ratio=2.5, minima_threshold=np.inf, maxima_threshold=-np.inf,

@@ -23,9 +23,7 @@ SOURCES = ["host_math.cpp", "blob_post.cpp", "connect.cpp", "api.hip", "gauss.hi
 # the vote loop is faster without the SLP vectoriser's packed-f32 shuffles (profiles/r01 notes)
 TV_VARIANT = [("tv_tiled.hip", "tv_tiled", ["-fno-slp-vectorize"]), ("tv_pair.hip", "tv_pair", ["-fno-slp-vectorize"]),
               ("tv_box.hip", "tv_box", ["-fno-slp-vectorize"]),
-              # the device eigen solver takes its one angle (atan2, sin, cos) in single precision: eigenvalues move by ~1e-7 of the
-              # matrix's scale, the order of the difference between the device's and glibc's double-precision libm (csrc/eigen3.hpp)
-              ("ridge.hip", "ridge", ["-DVH_EIG_F32_TRIG"])]
+              ("ridge.hip", "ridge", [])]
 VARIANTS = TV_VARIANT + [("gauss_fused.hip", "gauss_fused_h%d" % h, ["-DVH_FUSED_H=%d" % h, "-fno-slp-vectorize"])
                          for h in range(1, 9)]
 if os.environ.get("VISFD_FUSED_EXTRA_CFGS"):

@@ -30,6 +30,8 @@
 #include <iostream>
 #include <sstream>
 #include <string>
+#include <sys/stat.h>
+#include <ctime>
 #include <thread>
 #include <chrono>
 #include <vector>
@@ -320,6 +322,13 @@ Settings parse(int argc, char** argv) {
       s.width_a[0] = s.width_a[1] = s.width_a[2] = sigma;
       s.type = Settings::SURFACE_RIDGE; i += 3;
     }
+    else if (f == "-detection-background" || f == "-membrane-background" || f == "-curve-background") {   // settings.cpp:2802-2825
+      // the peak-height factor of the score loops: width (sigma, physical units) of the Gaussian whose output is the
+      // background; both scores are multiplied by (image - background), handlers.cpp:1577-1605,1698-1702,1883-1887
+      need(1);
+      s.width_b[0] = s.width_b[1] = s.width_b[2] = num(v, i + 1, f);
+      s.type = Settings::SURFACE_RIDGE; i += 2;
+    }
     else if (f == "-tv") { need(1); s.tv_sigma = num(v, i + 1, f); i += 2; }
     else if (f == "-tv-angle-exponent") { need(1); s.tv_exponent = (int)num(v, i + 1, f); i += 2; }
     else if (f == "-tv-truncate-ratio") { need(1); s.tv_truncate = num(v, i + 1, f); i += 2; }   // settings.cpp:2931-2946
@@ -602,16 +611,22 @@ void handle_membrane_slab(const Settings& s, Mrc& tomo_in, Mrc& out, float ratio
   if (s.slab_id_file == "-" && s.slab_world > 1) throw VisfdErr("Error: -slab with more than one rank needs an id file.\n");
   if (with_id) {
     if (s.slab_rank == 0) {
+      std::remove(s.slab_id_file.c_str());   // an id file left behind by an earlier run must not be picked up by this run's ranks
       hip_detail::check(visfd_hip_slab_unique_id(id));
       const string tmp = s.slab_id_file + ".tmp";
       { std::ofstream f(tmp.c_str(), std::ios::binary); f.write(reinterpret_cast<const char*>(id), 128);
         if (!f) throw VisfdErr("Error: unable to write \"" + tmp + "\".\n"); }
       if (std::rename(tmp.c_str(), s.slab_id_file.c_str()) != 0) throw VisfdErr("Error: unable to create \"" + s.slab_id_file + "\".\n");
     } else {
+      // IDFILE must be unique per run.  Rank 0 removes it before it publishes a new id and again once the communicator is
+      // up; a file older than the ten minutes a rank waits is taken to be a leftover and ignored.
+      const std::time_t started = std::time(nullptr);
       bool got = false;
       for (int tries = 0; tries < 12000 && !got; tries++) {   // up to 10 minutes
+        struct stat st;
+        const bool fresh = ::stat(s.slab_id_file.c_str(), &st) == 0 && st.st_mtime + 600 >= started;
         std::ifstream f(s.slab_id_file.c_str(), std::ios::binary);
-        if (f && f.read(reinterpret_cast<char*>(id), 128) && f.gcount() == 128) got = true;
+        if (fresh && f && f.read(reinterpret_cast<char*>(id), 128) && f.gcount() == 128) got = true;
         else std::this_thread::sleep_for(std::chrono::milliseconds(50));
       }
       if (!got) throw VisfdErr("Error: the id file \"" + s.slab_id_file + "\" did not appear (is rank 0 running?).\n");
@@ -619,9 +634,11 @@ void handle_membrane_slab(const Settings& s, Mrc& tomo_in, Mrc& out, float ratio
   }
   int h_tv = 0;
   hip_detail::check(visfd_hip_tv_tables(s.tv_sigma, s.tv_truncate, &h_tv, nullptr, nullptr));
-  const int ghost = std::max(h_tv, (int)std::floor(s.width_a[0] * ratio) + 1);
+  const float sigma_bg = s.width_b[0] > 0.0f ? s.width_b[0] : 0.0f;
+  const int ghost = std::max(std::max(h_tv, (int)std::floor(s.width_a[0] * ratio) + 1), (int)std::floor(sigma_bg * ratio));
   visfd_hip_slab* slab = nullptr;
   hip_detail::check(visfd_hip_slab_create_rccl(ctx, with_id ? id : nullptr, s.slab_rank, s.slab_world, tomo_in.nz, ghost, &slab));
+  if (with_id && s.slab_rank == 0) std::remove(s.slab_id_file.c_str());   // every rank has joined: the id has served
   int64_t lay[7];
   hip_detail::check(visfd_hip_slab_layout(slab, lay));
   const int64_t z0 = lay[0], z1 = lay[1];
@@ -629,9 +646,9 @@ void handle_membrane_slab(const Settings& s, Mrc& tomo_in, Mrc& out, float ratio
   out.alloc(tomo_in.nx, tomo_in.ny, (int)(z1 - z0));
   float thr = 0;
   const size_t plane = (size_t)tomo_in.nx * tomo_in.ny;
-  const int rc = visfd_hip_membrane_detect_slab(slab, tomo_in.data() + (size_t)z0 * plane, tomo_in.nx, tomo_in.ny, s.width_a[0], ratio,
-                                                order, s.hessian_thr, s.tv_sigma, s.tv_exponent, s.tv_truncate, out.data(), nullptr,
-                                                &thr);
+  const int rc = visfd_hip_membrane_detect_slab_bg(slab, tomo_in.data() + (size_t)z0 * plane, tomo_in.nx, tomo_in.ny, s.width_a[0], ratio,
+                                                   order, s.hessian_thr, s.tv_sigma, s.tv_exponent, s.tv_truncate, sigma_bg,
+                                                   s.normalize ? 1 : 0, out.data(), nullptr, &thr);
   visfd_hip_slab_destroy(slab);
   hip_detail::check(rc);
   cerr << "  (saliency threshold = " << thr << ")\n";
@@ -774,10 +791,11 @@ int main(int argc, char** argv) {
       }
       if (s.load_base.empty()) {
         float thr = 0;
-        hip_detail::check(visfd_hip_membrane_detect(
+        hip_detail::check(visfd_hip_membrane_detect_bg(
             hip_detail::context(), tomo_in.data(), mptr, size[0], size[1], size[2],
             s.width_a[0], ratio, order, s.hessian_thr_is_fraction ? s.hessian_thr : -1.0f, s.hessian_thr, s.tv_sigma,
-            s.tv_exponent, s.tv_truncate, tomo_out.data(), tensor.empty() ? nullptr : tensor.data(), nullptr, &thr));
+            s.tv_exponent, s.tv_truncate, s.width_b[0] > 0.0f ? s.width_b[0] : 0.0f, s.normalize ? 1 : 0, tomo_out.data(),
+            tensor.empty() ? nullptr : tensor.data(), nullptr, &thr));
         cerr << "  (saliency threshold = " << thr << ")\n";
       } else {
         // handlers.cpp:1840-1862: the vote tensors come from "<base>_tensor_<d>.rec" (written by -save-progress)
@@ -794,6 +812,20 @@ int main(int argc, char** argv) {
             if (!mptr || mptr[i] != 0.0f) tensor[6 * i + c] = p[i];
         }
         hip_detail::check(visfd_hip_tensor_saliency_host(tensor.data(), mptr, (int64_t)n, order, tomo_out.data()));
+        if (s.width_b[0] > 0.0f) {   // the peak-height factor of the post-vote loop, handlers.cpp:1577-1592,1883-1887
+          Mrc bgv;
+          bgv.alloc(size[0], size[1], size[2]);
+          const float sb[3] = {s.width_b[0], s.width_b[0], s.width_b[0]};
+          const int hb = (int)std::floor(s.width_b[0] * ratio);
+          const int hwb[3] = {hb, hb, hb};
+          hip_detail::check(visfd_hip_apply_gauss(hip_detail::context(), tomo_in.data(), bgv.data(), mptr, size[0], size[1], size[2], sb, hwb,
+                                                  s.normalize ? 1 : 0, nullptr));
+          const float* img = tomo_in.data();
+          const float* bg = bgv.data();
+          float* o = tomo_out.data();
+          for (size_t i = 0; i < n; i++)
+            if (!mptr || mptr[i] != 0.0f) o[i] *= img[i] - bg[i];
+        }
       }
       if (!tensor.empty() && !s.save_base.empty()) {
         Mrc t;

@@ -257,7 +257,7 @@ const OptionDesc kOptions[] = {
     {"gauss_3pass", &visfd_hip_options::gauss_3pass, nullptr},   {"gauss_cfg", &visfd_hip_options::gauss_cfg, nullptr},
     {"gauss_wg_per_cu", &visfd_hip_options::gauss_wg_per_cu, nullptr}, {"tv_dense", &visfd_hip_options::tv_dense, nullptr},
     {"tv_zrun", &visfd_hip_options::tv_zrun, nullptr}, {"tv_fma", &visfd_hip_options::tv_fma, nullptr},
-    {"gauss_fma", &visfd_hip_options::gauss_fma, nullptr},
+    {"gauss_fma", &visfd_hip_options::gauss_fma, nullptr}, {"eig_f32", &visfd_hip_options::eig_f32, nullptr},
     {"tv_no_replay", &visfd_hip_options::tv_no_replay, nullptr}, {"tv_max_wg", &visfd_hip_options::tv_max_wg, nullptr},
     {"tv_poison", &visfd_hip_options::tv_poison, nullptr},
     {"blob_test_cap", nullptr, &visfd_hip_options::blob_test_cap}, {"debug", &visfd_hip_options::debug, nullptr},
@@ -287,7 +287,7 @@ void options_from_environment(visfd_hip_options* o) {
 }
 }  // namespace
 
-int visfd_hip_abi_version(void) { return 7; }   // 7: + visfd_hip_membrane_detect_slab (host-memory face of the slab stage); 6: + visfd_hip_get_option, tolerance modes (tv_fma, gauss_fma), slab entry points; 5: + visfd_hip_set_option, CompactMultiChannelImage3D/TVDenseStick normalisation in the shim; 2: + blob post-processing, binning, LabelConnected and its host helpers; 3: + host DiagonalizeFlatSym3 / ConvertFlatSym2Evects3; 4: + LocalFluctuations, two-step ridge (scores / directions)
+int visfd_hip_abi_version(void) { return 8; }   // 8: + the peak-height factor (`-membrane-background`): visfd_hip_peak_background_dev, _ridge_scores_bg_dev, _tensor_saliency_bg_dev, _membrane_detect_bg[_dev], _membrane_detect_slab_bg[_dev]; slab Gaussian / blob entry points of the program; 7: + visfd_hip_membrane_detect_slab (host-memory face of the slab stage); 6: + visfd_hip_get_option, tolerance modes (tv_fma, gauss_fma), slab entry points; 5: + visfd_hip_set_option, CompactMultiChannelImage3D/TVDenseStick normalisation in the shim; 2: + blob post-processing, binning, LabelConnected and its host helpers; 3: + host DiagonalizeFlatSym3 / ConvertFlatSym2Evects3; 4: + LocalFluctuations, two-step ridge (scores / directions)
 const char* visfd_hip_last_error(void) { return g_last_error.c_str(); }
 
 int visfd_hip_create(int device, void* stream, visfd_hip_ctx** out) {
@@ -702,8 +702,9 @@ int visfd_hip_ridge_saliency_dev(visfd_hip_ctx* ctx, const float* src, const flo
 
 // The same in two steps for callers that threshold in between (HandleTV does: handlers.cpp:1751-1797): scores for
 // every voxel (the smoothed volume is handed back), then directions of the voxels whose score survived.
-int visfd_hip_ridge_scores_dev(visfd_hip_ctx* ctx, const float* src, const float* mask, int64_t nx, int64_t ny,
-                               int64_t nz, float sigma, float ratio, int order, float* sal, float* smoothed) {
+int visfd_hip_ridge_scores_bg_dev(visfd_hip_ctx* ctx, const float* src, const float* mask, int64_t nx, int64_t ny,
+                                  int64_t nz, float sigma, float ratio, int order, const float* background, float* sal,
+                                  float* smoothed) {
   VH_REQUIRE(ctx && src && sal && smoothed, "null argument");
   VH_REQUIRE(smoothed != src && smoothed != sal, "the smoothed volume needs its own buffer");
   VH_REQUIRE(order == 0 || order == 1, "unsupported eigenvalue order");
@@ -715,7 +716,26 @@ int visfd_hip_ridge_scores_dev(visfd_hip_ctx* ctx, const float* src, const float
   const int hw[3] = {hwv, hwv, hwv};
   const SlabInfo whole = {0, nz};
   VH_TRY(gauss_dev(ctx, src, smoothed, mask, nx, ny, nz, sg, hw, true, whole, nullptr));
-  return dev_ridge_score(ctx, smoothed, mask, nx, ny, nz, sigma, order, sal);
+  return dev_ridge_score(ctx, smoothed, mask, nx, ny, nz, sigma, order, sal, background ? src : nullptr, background);
+}
+int visfd_hip_ridge_scores_dev(visfd_hip_ctx* ctx, const float* src, const float* mask, int64_t nx, int64_t ny,
+                               int64_t nz, float sigma, float ratio, int order, float* sal, float* smoothed) {
+  return visfd_hip_ridge_scores_bg_dev(ctx, src, mask, nx, ny, nz, sigma, ratio, order, nullptr, sal, smoothed);
+}
+// the background of the peak-height factor: ApplyGauss(image, sigma_background, floor(sigma_background * ratio), mask,
+// normalize) -- bin/filter_mrc/handlers.cpp:1577-1592
+int visfd_hip_peak_background_dev(visfd_hip_ctx* ctx, const float* src, const float* mask, int64_t nx, int64_t ny, int64_t nz,
+                                  float sigma_background, float ratio, int normalize, float* background) {
+  VH_REQUIRE(ctx && src && background && background != src, "bad argument");
+  VH_REQUIRE(sigma_background > 0.0f, "the background width must be positive");
+  VH_HIP(hipSetDevice(ctx->device));
+  VH_TRY(check_dims(nx, ny, nz));
+  const int hwv = (int)std::floor(sigma_background * ratio);
+  VH_REQUIRE(hwv >= 0 && hwv <= MAX_HALFWIDTH, "background filter halfwidth must be in [0, 64]");
+  const float sg[3] = {sigma_background, sigma_background, sigma_background};
+  const int hw[3] = {hwv, hwv, hwv};
+  const SlabInfo whole = {0, nz};
+  return gauss_dev(ctx, src, background, mask, nx, ny, nz, sg, hw, normalize != 0, whole, nullptr);
 }
 
 int visfd_hip_ridge_directions_dev(visfd_hip_ctx* ctx, const float* smoothed, int64_t nx, int64_t ny, int64_t nz,
@@ -884,10 +904,11 @@ int visfd_hip_tv_weight_sum(visfd_hip_ctx* ctx, const float* sal, float* den, co
 }
 
 // ---- HandleTV compute section ------------------------------------------------------------------
-int visfd_hip_membrane_detect_dev(visfd_hip_ctx* ctx, const float* src, const float* mask, int64_t nx,
-                                  int64_t ny, int64_t nz, float sigma, float ratio, int order,
-                                  float best_fraction, float threshold_abs, float sigma_tv, int exponent,
-                                  float cutoff, float* sal, float* ten, float* dir, float* thr_out) {
+int visfd_hip_membrane_detect_bg_dev(visfd_hip_ctx* ctx, const float* src, const float* mask, int64_t nx,
+                                     int64_t ny, int64_t nz, float sigma, float ratio, int order,
+                                     float best_fraction, float threshold_abs, float sigma_tv, int exponent,
+                                     float cutoff, float sigma_background, int normalize_background, float* sal, float* ten,
+                                     float* dir, float* thr_out) {
   VH_REQUIRE(ctx && src && sal, "null argument");
   VH_REQUIRE(order == 0 || order == 1, "unsupported eigenvalue order");
   VH_REQUIRE(best_fraction <= 1.0f, "fraction must be <= 1");
@@ -898,7 +919,13 @@ int visfd_hip_membrane_detect_dev(visfd_hip_ctx* ctx, const float* src, const fl
   if (!d) VH_TRY(ws(ctx, WS_TVAUX, (size_t)(3 * n), &d));
   float* smoothed = nullptr;
   VH_TRY(ws(ctx, WS_D, (size_t)n, &smoothed));
-  VH_TRY(visfd_hip_ridge_scores_dev(ctx, src, mask, nx, ny, nz, sigma, ratio, order, sal, smoothed));
+  // optional peak-height factor (`-membrane-background`): scores and post-vote scores are multiplied by image - background
+  float* bg = nullptr;
+  if (sigma_background > 0.0f) {
+    VH_TRY(ws(ctx, WS_C, (size_t)n, &bg));
+    VH_TRY(visfd_hip_peak_background_dev(ctx, src, mask, nx, ny, nz, sigma_background, ratio, normalize_background, bg));
+  }
+  VH_TRY(visfd_hip_ridge_scores_bg_dev(ctx, src, mask, nx, ny, nz, sigma, ratio, order, bg, sal, smoothed));
   float thr = threshold_abs;
   if (best_fraction >= 0.0f) VH_TRY(dev_threshold_fraction(ctx, sal, mask, n, best_fraction, &thr));
   else VH_TRY(dev_apply_threshold(ctx, sal, n, thr));
@@ -911,15 +938,22 @@ int visfd_hip_membrane_detect_dev(visfd_hip_ctx* ctx, const float* src, const fl
     float* t = ten;
     if (!t) VH_TRY(ws(ctx, WS_B, (size_t)(6 * n), &t));
     VH_TRY(dev_tv_dense_stick(ctx, sal, d, t, mask, mask, nx, ny, nz, 0, nz, sigma_tv, exponent, cutoff, false));
-    VH_TRY(dev_tensor_saliency(ctx, t, mask, n, order, sal));
+    VH_TRY(dev_tensor_saliency(ctx, t, mask, n, order, sal, bg ? src : nullptr, bg));
   }
   return VISFD_HIP_OK;
 }
+int visfd_hip_membrane_detect_dev(visfd_hip_ctx* ctx, const float* src, const float* mask, int64_t nx,
+                                  int64_t ny, int64_t nz, float sigma, float ratio, int order,
+                                  float best_fraction, float threshold_abs, float sigma_tv, int exponent,
+                                  float cutoff, float* sal, float* ten, float* dir, float* thr_out) {
+  return visfd_hip_membrane_detect_bg_dev(ctx, src, mask, nx, ny, nz, sigma, ratio, order, best_fraction, threshold_abs, sigma_tv,
+                                          exponent, cutoff, 0.0f, 1, sal, ten, dir, thr_out);
+}
 
-int visfd_hip_membrane_detect(visfd_hip_ctx* ctx, const float* src, const float* mask, int64_t nx, int64_t ny,
-                              int64_t nz, float sigma, float ratio, int order, float best_fraction,
-                              float threshold_abs, float sigma_tv, int exponent, float cutoff, float* sal,
-                              float* ten, float* dir, float* thr_out) {
+int visfd_hip_membrane_detect_bg(visfd_hip_ctx* ctx, const float* src, const float* mask, int64_t nx, int64_t ny,
+                                 int64_t nz, float sigma, float ratio, int order, float best_fraction,
+                                 float threshold_abs, float sigma_tv, int exponent, float cutoff, float sigma_background,
+                                 int normalize_background, float* sal, float* ten, float* dir, float* thr_out) {
   VH_REQUIRE(ctx && src && sal, "null argument");
   VH_HIP(hipSetDevice(ctx->device));
   VH_TRY(check_dims(nx, ny, nz));
@@ -933,8 +967,8 @@ int visfd_hip_membrane_detect(visfd_hip_ctx* ctx, const float* src, const float*
     VH_TRY(ws(ctx, WS_H2D_4, 6 * n, &pten));
     VH_HIP(hipMemsetAsync(pten, 0, sizeof(float) * 6 * n, ctx->stream));
   }
-  VH_TRY(visfd_hip_membrane_detect_dev(ctx, ds, dm, nx, ny, nz, sigma, ratio, order, best_fraction,
-                                       threshold_abs, sigma_tv, exponent, cutoff, dsal, pten, pdir, thr_out));
+  VH_TRY(visfd_hip_membrane_detect_bg_dev(ctx, ds, dm, nx, ny, nz, sigma, ratio, order, best_fraction, threshold_abs, sigma_tv,
+                                          exponent, cutoff, sigma_background, normalize_background, dsal, pten, pdir, thr_out));
   VH_TRY(download(ctx, sal, dsal, n));
   if (ten && pten) {
     VH_TRY(ws(ctx, WS_A, 6 * n, &aos));
@@ -948,14 +982,26 @@ int visfd_hip_membrane_detect(visfd_hip_ctx* ctx, const float* src, const float*
   }
   return VISFD_HIP_OK;
 }
+int visfd_hip_membrane_detect(visfd_hip_ctx* ctx, const float* src, const float* mask, int64_t nx, int64_t ny,
+                              int64_t nz, float sigma, float ratio, int order, float best_fraction,
+                              float threshold_abs, float sigma_tv, int exponent, float cutoff, float* sal,
+                              float* ten, float* dir, float* thr_out) {
+  return visfd_hip_membrane_detect_bg(ctx, src, mask, nx, ny, nz, sigma, ratio, order, best_fraction, threshold_abs, sigma_tv,
+                                      exponent, cutoff, 0.0f, 1, sal, ten, dir, thr_out);
+}
 
 // ---- a15 -------------------------------------------------------------------------------------
-int visfd_hip_tensor_saliency_dev(visfd_hip_ctx* ctx, const float* ten, const float* mask, int64_t nvox,
-                                  int order, float* sal) {
+int visfd_hip_tensor_saliency_bg_dev(visfd_hip_ctx* ctx, const float* ten, const float* mask, int64_t nvox,
+                                     int order, const float* image, const float* background, float* sal) {
   VH_REQUIRE(ctx && ten && sal && nvox > 0, "bad argument");
+  VH_REQUIRE((image == nullptr) == (background == nullptr), "image and background come as a pair");
   VH_REQUIRE(order == 0 || order == 1, "unsupported eigenvalue order");
   VH_HIP(hipSetDevice(ctx->device));
-  return dev_tensor_saliency(ctx, ten, mask, nvox, order, sal);
+  return dev_tensor_saliency(ctx, ten, mask, nvox, order, sal, image, background);
+}
+int visfd_hip_tensor_saliency_dev(visfd_hip_ctx* ctx, const float* ten, const float* mask, int64_t nvox,
+                                  int order, float* sal) {
+  return visfd_hip_tensor_saliency_bg_dev(ctx, ten, mask, nvox, order, nullptr, nullptr, sal);
 }
 
 int visfd_hip_tensor_saliency(visfd_hip_ctx* ctx, const float* ten, const float* mask, int64_t nvox,

@@ -65,6 +65,8 @@ struct visfd_hip_options {
   int tv_fma = 0;           // 1: TOLERANCE MODE of tensor voting: fused multiply-adds, results within 1e-5 of the field's scale
                             //    instead of bit-identical (surfaces, exponent 2 or 4; everything else stays exact)
   int gauss_fma = 0;        // 1: TOLERANCE MODE of the single-sweep Gaussian (plain ApplyGauss only; DoG/LoG stay exact)
+  int eig_f32 = 0;          // 1: TOLERANCE MODE of the device eigen solver: its one angle (atan2, sin, cos) in single precision --
+                            //    eigenvalues and scores move by ~1 float ulp (eigen3.hpp); 0: the reference's double-precision angle
   int tv_zrun = 0;          // receiver planes per unit of work (0: default)
   int tv_no_replay = 0;     // 1: list every sender plane again for every receiver plane (nothing reused from the rings)
   int tv_poison = 0;        // tests: NaN bit patterns in LDS, ring memory and the output before tensor voting runs (tv_box.hip)
@@ -174,13 +176,15 @@ int dev_hessian_saliency(visfd_hip_ctx* ctx, const float* hess_planar, const flo
 int dev_ridge_saliency_fused(visfd_hip_ctx* ctx, const float* smoothed, const float* mask, i64 nx,
                              i64 ny, i64 nz, float sigma, int order, float* saliency,
                              float* dir_planar);
+// peak_img / peak_bg (nullable pair): score *= peak_img - peak_bg, the reference's optional peak-height factor
+// (bin/filter_mrc/handlers.cpp:1698-1702 and :1883-1887, `-membrane-background`)
 int dev_ridge_score(visfd_hip_ctx* ctx, const float* smoothed, const float* mask, i64 nx, i64 ny, i64 nz,
-                    float sigma, int order, float* saliency);
+                    float sigma, int order, float* saliency, const float* peak_img = nullptr, const float* peak_bg = nullptr);
 int dev_ridge_directions(visfd_hip_ctx* ctx, const float* smoothed, const float* saliency, i64 nx, i64 ny, i64 nz,
                          float sigma, int order, float* dir_planar);
 int dev_diagonalize(visfd_hip_ctx* ctx, const float* m6_planar, float* out6_planar, i64 n, int order);
 int dev_tensor_saliency(visfd_hip_ctx* ctx, const float* tensor_planar, const float* mask, i64 nvox,
-                        int order, float* saliency);
+                        int order, float* saliency, const float* peak_img = nullptr, const float* peak_bg = nullptr);
 
 int dev_select_histogram(visfd_hip_ctx* ctx, const float* sal, const float* mask, i64 nvox, int pass,
                          uint32_t prefix, uint64_t* hist_host, uint64_t* n_unmasked_host);

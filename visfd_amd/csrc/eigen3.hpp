@@ -81,6 +81,12 @@ VH_HD D3 null_vector(const Sym3& S, double lam, D3& rep) {
 }
 
 // m6 = (xx,yy,zz,xy,yz,xz).  lam[3] and rows E[3]; order 0 = increasing, 1 = decreasing.
+// F32TRIG (device only; context option eig_f32, tolerance modes): the ONE angle of the root formula -- atan2, sin, cos -- in
+// single precision.  The reference takes it in double (eigen3_simple.hpp:74-81); two double-precision libms (the device's,
+// glibc's) agree to ~1e-16, which vanishes when the eigenvalue is stored as float -- so F32TRIG = false reproduces the
+// reference's float eigenvalues in almost every voxel, while the single-precision angle moves almost every eigenvalue by
+// about one float ulp (~1e-7 of the matrix's scale).  It is therefore NOT part of the default (exact) kernels.
+template <bool F32TRIG = false>
 VH_HD void eig_sym3(const float m6[6], int order, double lam[3], D3 E[3],
                                          bool want_vectors) {
   const double eps = 2.220446049250313e-16;
@@ -110,19 +116,18 @@ VH_HD void eig_sym3(const float m6[6], int order, double lam[3], D3 E[3],
     q = fmax(q, 0.0);
     const double rho = sqrt(a_3);
     double st, ct;
-#if defined(__HIP_DEVICE_COMPILE__) && defined(VH_EIG_F32_TRIG)
-    // the angle and its sine / cosine in single precision (the matrix is scaled to max |entry| = 1, so both arguments
-    // are of order one or smaller): the eigenvalues move by ~1e-7 of the matrix's scale, as they already do between the
-    // device's and glibc's double-precision libm; everything around the angle stays in double
-    {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (F32TRIG) {
+      // (the matrix is scaled to max |entry| = 1, so both arguments of atan2f are of order one or smaller; everything
+      // around the angle stays in double)
       const float thf = atan2f(sqrtf((float)q), (float)half_b) * (1.0f / 3.0f);
       float sf, cf;
       sincosf(thf, &sf, &cf);
       st = (double)sf; ct = (double)cf;
+    } else {
+      const double theta = atan2(sqrt(q), half_b) * inv3;
+      sincos(theta, &st, &ct);
     }
-#elif defined(__HIP_DEVICE_COMPILE__)
-    const double theta = atan2(sqrt(q), half_b) * inv3;
-    sincos(theta, &st, &ct);
 #else
     const double theta = atan2(sqrt(q), half_b) * inv3;
     ct = std::cos(theta); st = std::sin(theta);
@@ -203,10 +208,11 @@ VH_HD void frame_to_shoemake(const D3 M[3], float sm[3]) {
 }
 
 // flat symmetric matrix -> [lam0, lam1, lam2, shoemake0..2] (eigen3_simple.hpp:271-342)
+template <bool F32TRIG = false>
 VH_HD void diagonalize_flat(const float m6[6], int order, float out6[6]) {
   double lam[3];
   D3 E[3];
-  eig_sym3(m6, order, lam, E, true);
+  eig_sym3<F32TRIG>(m6, order, lam, E, true);
   const D3 c01 = cross3(E[0], E[1]);
   if (dot3(E[2], c01) < 0.0) { E[0].x = -E[0].x; E[0].y = -E[0].y; E[0].z = -E[0].z; }
   float sm[3];

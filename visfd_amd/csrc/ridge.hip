@@ -58,9 +58,10 @@ __device__ __forceinline__ Stencil clamped_stencil(const float* S, int ix, int i
 }
 
 // saliency + principal direction from a flat Hessian (handlers.cpp:1653-1740)
+template <bool F32>
 __device__ __forceinline__ void saliency_dir(const float h6[6], int order, float& sal, float dir[3]) {
   float d6[6];
-  eig::diagonalize_flat(h6, order, d6);
+  eig::diagonalize_flat<F32>(h6, order, d6);
   const double l1 = d6[0], l2 = d6[1];
   double N = l1 * l1 - l2 * l2;
   N *= N;
@@ -93,6 +94,7 @@ hessian_kernel(const float* __restrict__ S, const float* __restrict__ mask, int 
   }
 }
 
+template <bool F32>
 __global__ void __launch_bounds__(BLOCK)
 hessian_saliency_kernel(const float* __restrict__ hess, const float* __restrict__ mask, i64 nvox,
                         int order, float* __restrict__ sal, float* __restrict__ dir) {
@@ -103,13 +105,14 @@ hessian_saliency_kernel(const float* __restrict__ hess, const float* __restrict_
 #pragma unroll
   for (int c = 0; c < 6; c++) h6[c] = hess[c * nvox + v];
   float s, d[3];
-  saliency_dir(h6, order, s, d);
+  saliency_dir<F32>(h6, order, s, d);
   sal[v] = s;
   dir[v] = d[0];
   dir[nvox + v] = d[1];
   dir[2 * nvox + v] = d[2];
 }
 
+template <bool F32>
 __global__ void __launch_bounds__(BLOCK)
 ridge_fused_kernel(const float* __restrict__ S, const float* __restrict__ mask, int nx, int ny, int nz,
                    float sigma, int order, float* __restrict__ sal, float* __restrict__ dir) {
@@ -122,7 +125,7 @@ ridge_fused_kernel(const float* __restrict__ S, const float* __restrict__ mask, 
   float h6[6];
   hessian_at(f, sigma * sigma, h6);
   float s, d[3];
-  saliency_dir(h6, order, s, d);
+  saliency_dir<F32>(h6, order, s, d);
   sal[v] = s;
   dir[v] = d[0];
   dir[nvox + v] = d[1];
@@ -132,9 +135,12 @@ ridge_fused_kernel(const float* __restrict__ S, const float* __restrict__ mask, 
 // The two halves of ridge_fused_kernel for pipelines that threshold the saliency before they need directions
 // (handlers.cpp:1751-1797 zeroes 95 % of the voxels; tensor voting reads the direction of the others only):
 // eigenvalues and score for every voxel ...
+template <bool F32>
 __global__ void __launch_bounds__(BLOCK)
 ridge_score_kernel(const float* __restrict__ S, const float* __restrict__ mask, int nx, int ny, int nz,
-                   float sigma, int order, float* __restrict__ sal) {
+                   float sigma, int order, float* __restrict__ sal,
+                   // optional peak-height factor (handlers.cpp:1698-1702): score *= image - background
+                   const float* __restrict__ peak_img, const float* __restrict__ peak_bg) {
   int ix, iy, iz;
   if (!voxel_of_block(nx, ny, ix, iy, iz)) return;
   const i64 v = ((i64)iz * ny + iy) * nx + ix;
@@ -144,11 +150,13 @@ ridge_score_kernel(const float* __restrict__ S, const float* __restrict__ mask, 
   hessian_at(f, sigma * sigma, h6);
   double lam[3];
   eig::D3 E[3];
-  eig::eig_sym3(h6, order, lam, E, false);      // the eigenvalues do not depend on the eigenvector branch
+  eig::eig_sym3<F32>(h6, order, lam, E, false);      // the eigenvalues do not depend on the eigenvector branch
   const double l1 = (float)lam[0], l2 = (float)lam[1];   // stored as float by DiagonalizeFlatSym3, re-read as double
   double N = l1 * l1 - l2 * l2;
   N *= N;
-  __builtin_nontemporal_store((float)N, &sal[v]);
+  float score = (float)N;
+  if (peak_img) score *= peak_img[v] - peak_bg[v];
+  __builtin_nontemporal_store(score, &sal[v]);
 }
 
 // ... and the principal direction of the voxels whose saliency is non-zero.  A workgroup scans DIR_CHUNK
@@ -156,6 +164,7 @@ ridge_score_kernel(const float* __restrict__ S, const float* __restrict__ mask, 
 // vectors, quaternion, Shoemake round trip) on full lanes only: with 5 % survivors one wave-round instead of 16.
 constexpr int DIR_PER = 16;               // voxels scanned per thread: ~5 % survive, so ~200 per workgroup -- the
 constexpr int DIR_CHUNK = DIR_PER * BLOCK;  // eigenvector loop then keeps 3-4 of the 4 waves busy (4 per thread: 8.3 ms)
+template <bool F32>
 __global__ void __launch_bounds__(BLOCK)
 ridge_directions_kernel(const float* __restrict__ S, const float* __restrict__ sal, int nx, int ny, int nz,
                         float sigma, int order, float* __restrict__ dir) {
@@ -202,13 +211,14 @@ ridge_directions_kernel(const float* __restrict__ S, const float* __restrict__ s
     float h6[6];
     hessian_at(f, sigma * sigma, h6);
     float s, d[3];
-    saliency_dir(h6, order, s, d);
+    saliency_dir<F32>(h6, order, s, d);
     dir[v] = d[0];
     dir[nvox + v] = d[1];
     dir[2 * nvox + v] = d[2];
   }
 }
 
+template <bool F32>
 __global__ void __launch_bounds__(BLOCK)
 diagonalize_kernel(const float* __restrict__ m, float* __restrict__ out, i64 n, int order) {
   const i64 v = (i64)blockIdx.x * BLOCK + threadIdx.x;
@@ -216,15 +226,18 @@ diagonalize_kernel(const float* __restrict__ m, float* __restrict__ out, i64 n, 
   float h6[6], d6[6];
 #pragma unroll
   for (int c = 0; c < 6; c++) h6[c] = m[c * n + v];
-  eig::diagonalize_flat(h6, order, d6);
+  eig::diagonalize_flat<F32>(h6, order, d6);
 #pragma unroll
   for (int c = 0; c < 6; c++) out[c * n + v] = d6[c];
 }
 
 // handlers.cpp:1873-1888: score = lambda0 - lambda1 of the diagonalised tensor
+template <bool F32>
 __global__ void __launch_bounds__(BLOCK)
 tensor_saliency_kernel(const float* __restrict__ ten, const float* __restrict__ mask, i64 nvox, int order,
-                       float* __restrict__ sal) {
+                       float* __restrict__ sal,
+                       // optional peak-height factor (handlers.cpp:1883-1887)
+                       const float* __restrict__ peak_img, const float* __restrict__ peak_bg) {
   const i64 v = (i64)blockIdx.x * BLOCK + threadIdx.x;
   if (v >= nvox) return;
   if (mask && mask[v] == 0.0f) return;
@@ -233,9 +246,11 @@ tensor_saliency_kernel(const float* __restrict__ ten, const float* __restrict__ 
   for (int c = 0; c < 6; c++) t6[c] = ten[c * nvox + v];
   double lam[3];
   eig::D3 E[3];
-  eig::eig_sym3(t6, order, lam, E, false);
+  eig::eig_sym3<F32>(t6, order, lam, E, false);
   const double l1 = (float)lam[0], l2 = (float)lam[1];  // stored as float, re-read as double
-  __builtin_nontemporal_store((float)(l1 - l2), &sal[v]);
+  float score = (float)(l1 - l2);
+  if (peak_img) score *= peak_img[v] - peak_bg[v];
+  __builtin_nontemporal_store(score, &sal[v]);
 }
 
 __global__ void __launch_bounds__(BLOCK)
@@ -257,6 +272,13 @@ planar_to_aos_kernel(const float* __restrict__ planar, float* __restrict__ aos, 
   if (mask && mask[v] == 0.0f) return;
   aos[i] = planar[c * n + v];
 }
+
+// the eigen kernels exist in two forms (eigen3.hpp: eig_sym3<F32TRIG>); the context option eig_f32 chooses
+#define VH_EIG_LAUNCH(kernel, grid, ...)                                                          \
+  do {                                                                                            \
+    if (ctx->opt.eig_f32) kernel<true><<<grid, dim3(BLOCK), 0, ctx->stream>>>(__VA_ARGS__);       \
+    else kernel<false><<<grid, dim3(BLOCK), 0, ctx->stream>>>(__VA_ARGS__);                       \
+  } while (0)
 
 int voxel_grid(i64 nx, i64 ny, i64 nz, unsigned* g) {
   if (nx >= (1LL << 31) || ny >= (1LL << 31) || nz >= (1LL << 31))
@@ -292,7 +314,7 @@ int dev_hessian_saliency(visfd_hip_ctx* ctx, const float* hess, const float* mas
                          float* sal, float* dir) {
   unsigned g;
   VH_TRY(linear_grid(nvox, &g));
-  hessian_saliency_kernel<<<dim3(g), dim3(BLOCK), 0, ctx->stream>>>(hess, mask, nvox, order, sal, dir);
+  VH_EIG_LAUNCH(hessian_saliency_kernel, dim3(g), hess, mask, nvox, order, sal, dir);
   VH_HIP(hipGetLastError());
   return VISFD_HIP_OK;
 }
@@ -303,19 +325,18 @@ int dev_ridge_saliency_fused(visfd_hip_ctx* ctx, const float* S, const float* ma
     return fail(VISFD_HIP_EINVAL, "ridge detection requires an image at least 3 voxels wide in x,y,z");
   unsigned g;
   VH_TRY(voxel_grid(nx, ny, nz, &g));
-  ridge_fused_kernel<<<dim3(g), dim3(BLOCK), 0, ctx->stream>>>(S, mask, (int)nx, (int)ny, (int)nz, sigma,
-                                                              order, sal, dir);
+  VH_EIG_LAUNCH(ridge_fused_kernel, dim3(g), S, mask, (int)nx, (int)ny, (int)nz, sigma, order, sal, dir);
   VH_HIP(hipGetLastError());
   return VISFD_HIP_OK;
 }
 
 int dev_ridge_score(visfd_hip_ctx* ctx, const float* S, const float* mask, i64 nx, i64 ny, i64 nz, float sigma,
-                    int order, float* sal) {
+                    int order, float* sal, const float* peak_img, const float* peak_bg) {
   if (nx < 3 || ny < 3 || nz < 3)
     return fail(VISFD_HIP_EINVAL, "ridge detection requires an image at least 3 voxels wide in x,y,z");
   unsigned g;
   VH_TRY(voxel_grid(nx, ny, nz, &g));
-  ridge_score_kernel<<<dim3(g), dim3(BLOCK), 0, ctx->stream>>>(S, mask, (int)nx, (int)ny, (int)nz, sigma, order, sal);
+  VH_EIG_LAUNCH(ridge_score_kernel, dim3(g), S, mask, (int)nx, (int)ny, (int)nz, sigma, order, sal, peak_img, peak_bg);
   VH_HIP(hipGetLastError());
   return VISFD_HIP_OK;
 }
@@ -327,8 +348,7 @@ int dev_ridge_directions(visfd_hip_ctx* ctx, const float* S, const float* sal, i
   if (nx >= (1LL << 31) || ny >= (1LL << 31) || nz >= (1LL << 31)) return fail(VISFD_HIP_EINVAL, "dimension too large");
   const i64 nb = (nx * ny * nz + DIR_CHUNK - 1) / DIR_CHUNK;
   if (nb > 0x7fffffffLL) return fail(VISFD_HIP_EINVAL, "volume too large for one launch");
-  ridge_directions_kernel<<<dim3((unsigned)nb), dim3(BLOCK), 0, ctx->stream>>>(S, sal, (int)nx, (int)ny, (int)nz, sigma,
-                                                                             order, dir);
+  VH_EIG_LAUNCH(ridge_directions_kernel, dim3((unsigned)nb), S, sal, (int)nx, (int)ny, (int)nz, sigma, order, dir);
   VH_HIP(hipGetLastError());
   return VISFD_HIP_OK;
 }
@@ -336,16 +356,16 @@ int dev_ridge_directions(visfd_hip_ctx* ctx, const float* S, const float* sal, i
 int dev_diagonalize(visfd_hip_ctx* ctx, const float* m, float* out, i64 n, int order) {
   unsigned g;
   VH_TRY(linear_grid(n, &g));
-  diagonalize_kernel<<<dim3(g), dim3(BLOCK), 0, ctx->stream>>>(m, out, n, order);
+  VH_EIG_LAUNCH(diagonalize_kernel, dim3(g), m, out, n, order);
   VH_HIP(hipGetLastError());
   return VISFD_HIP_OK;
 }
 
 int dev_tensor_saliency(visfd_hip_ctx* ctx, const float* ten, const float* mask, i64 nvox, int order,
-                        float* sal) {
+                        float* sal, const float* peak_img, const float* peak_bg) {
   unsigned g;
   VH_TRY(linear_grid(nvox, &g));
-  tensor_saliency_kernel<<<dim3(g), dim3(BLOCK), 0, ctx->stream>>>(ten, mask, nvox, order, sal);
+  VH_EIG_LAUNCH(tensor_saliency_kernel, dim3(g), ten, mask, nvox, order, sal, peak_img, peak_bg);
   VH_HIP(hipGetLastError());
   return VISFD_HIP_OK;
 }

@@ -363,10 +363,12 @@ int visfd_hip_slab_exchange_dev(visfd_hip_slab* s, float* const* volumes, int nv
 // HandleTV (handlers.cpp:1501-1892) on one slab.  All volumes have the local shape [nz_local][ny][nx] (dirs: 3 planar
 // channels, tensor: 6); src holds the owned planes (its ghost planes are filled here unless src_halo_ready); valid
 // results are the OWNED planes of sal (the post-vote score) and tensor.
-int visfd_hip_membrane_detect_slab_dev(visfd_hip_slab* s, float* src, float* sal, float* dirs, float* tensor, float* scratch,
-                                       int64_t nx, int64_t ny, float sigma, float ratio, int order, float best_fraction,
-                                       float sigma_tv, int exponent, float cutoff, int src_halo_ready, float* thr_out) {
+int visfd_hip_membrane_detect_slab_bg_dev(visfd_hip_slab* s, float* src, float* sal, float* dirs, float* tensor, float* scratch,
+                                          float* background, int64_t nx, int64_t ny, float sigma, float ratio, int order,
+                                          float best_fraction, float sigma_tv, int exponent, float cutoff, float sigma_background,
+                                          int normalize_background, int src_halo_ready, float* thr_out) {
   VH_REQUIRE(s && src && sal && dirs && tensor && scratch, "null argument");
+  VH_REQUIRE(sigma_background <= 0.0f || background, "the peak-height factor needs a volume for the background");
   VH_REQUIRE(order == 0 || order == 1, "unsupported eigenvalue order");
   visfd_hip_ctx* ctx = s->ctx;
   VH_HIP(hipSetDevice(ctx->device));
@@ -374,15 +376,22 @@ int visfd_hip_membrane_detect_slab_dev(visfd_hip_slab* s, float* src, float* sal
   VH_TRY(check_dims(nx, ny, nzl));
   const int h_gauss = (int)std::floor(sigma * ratio);
   const int h_tv = host_tv_halfwidth(sigma_tv, cutoff);
-  VH_REQUIRE(s->world == 1 || (h_gauss + 1 <= s->ghost && h_tv <= s->ghost), "ghost depth too small for this window");
-  // 1. source halo deep enough for smoothing + the finite-difference stencil
+  const int h_bg = sigma_background > 0.0f ? (int)std::floor(sigma_background * ratio) : 0;
+  VH_REQUIRE(s->world == 1 || (h_gauss + 1 <= s->ghost && h_tv <= s->ghost && h_bg <= s->ghost), "ghost depth too small for this window");
+  // 1. source halo deep enough for smoothing + the finite-difference stencil (and for the background filter)
   if (!src_halo_ready) {
     float* v[1] = {src};
-    VH_TRY(halo_start(s, v, 1, nx, ny, std::min(s->ghost, h_gauss + 1)));
+    VH_TRY(halo_start(s, v, 1, nx, ny, std::min(s->ghost, std::max(h_gauss + 1, h_bg))));
     VH_TRY(halo_wait(s));
   }
+  // optional peak-height factor: the background on every stored plane (owned planes exact, as the scores below)
+  float* bg = nullptr;
+  if (sigma_background > 0.0f) {
+    bg = background;
+    VH_TRY(visfd_hip_peak_background_dev(ctx, src, nullptr, nx, ny, nzl, sigma_background, ratio, normalize_background, bg));
+  }
   // 2. scores on every stored plane (planes closer than h_gauss + 1 to an interior array end are garbage; owned planes exact)
-  VH_TRY(visfd_hip_ridge_scores_dev(ctx, src, nullptr, nx, ny, nzl, sigma, ratio, order, sal, scratch));
+  VH_TRY(visfd_hip_ridge_scores_bg_dev(ctx, src, nullptr, nx, ny, nzl, sigma, ratio, order, bg, sal, scratch));
   // 3. global top-fraction threshold over the owned voxels
   float thr = 0.0f;
   VH_TRY(global_threshold(s, sal + s->own0 * plane, (s->own1 - s->own0) * plane, best_fraction, &thr));
@@ -415,15 +424,22 @@ int visfd_hip_membrane_detect_slab_dev(visfd_hip_slab* s, float* src, float* sal
     VH_TRY(vote(s->own0, s->own1));
   }
   // 6. post-vote score
-  return dev_tensor_saliency(ctx, tensor, nullptr, nvl, order, sal);
+  return dev_tensor_saliency(ctx, tensor, nullptr, nvl, order, sal, bg ? src : nullptr, bg);
+}
+int visfd_hip_membrane_detect_slab_dev(visfd_hip_slab* s, float* src, float* sal, float* dirs, float* tensor, float* scratch,
+                                       int64_t nx, int64_t ny, float sigma, float ratio, int order, float best_fraction,
+                                       float sigma_tv, int exponent, float cutoff, int src_halo_ready, float* thr_out) {
+  return visfd_hip_membrane_detect_slab_bg_dev(s, src, sal, dirs, tensor, scratch, nullptr, nx, ny, sigma, ratio, order, best_fraction,
+                                               sigma_tv, exponent, cutoff, 0.0f, 1, src_halo_ready, thr_out);
 }
 
 // The same stage for a host that keeps its volume in HOST memory (the filter_mrc program started once per GPU): the owned
 // planes go up, the slab stage runs, the owned planes of the score (and, if asked for, of the vote tensors, six interleaved
 // floats per voxel as visfd_hip_membrane_detect returns them) come back.  Device arrays live for the call only.
-int visfd_hip_membrane_detect_slab(visfd_hip_slab* s, const float* src_owned, int64_t nx, int64_t ny, float sigma, float ratio,
-                                   int order, float best_fraction, float sigma_tv, int exponent, float cutoff,
-                                   float* sal_owned, float* tensor_owned, float* thr_out) {
+int visfd_hip_membrane_detect_slab_bg(visfd_hip_slab* s, const float* src_owned, int64_t nx, int64_t ny, float sigma, float ratio,
+                                      int order, float best_fraction, float sigma_tv, int exponent, float cutoff,
+                                      float sigma_background, int normalize_background, float* sal_owned, float* tensor_owned,
+                                      float* thr_out) {
   VH_REQUIRE(s && src_owned && sal_owned, "null argument");
   visfd_hip_ctx* ctx = s->ctx;
   VH_HIP(hipSetDevice(ctx->device));
@@ -433,10 +449,11 @@ int visfd_hip_membrane_detect_slab(visfd_hip_slab* s, const float* src_owned, in
     float* p = nullptr;
     ~Block() { if (p) (void)hipFree(p); }
   } blk;
-  const size_t total = (size_t)nvl * 12 + (tensor_owned ? (size_t)nown * 12 : 0);
+  const bool with_bg = sigma_background > 0.0f;
+  const size_t total = (size_t)nvl * (with_bg ? 13 : 12) + (tensor_owned ? (size_t)nown * 12 : 0);
   if (hipMalloc(&blk.p, total * sizeof(float)) != hipSuccess) {
     (void)hipGetLastError();
-    return fail(VISFD_HIP_ENOMEM, "membrane_detect_slab: device allocation of 12 slab volumes failed");
+    return fail(VISFD_HIP_ENOMEM, "membrane_detect_slab: device allocation of the slab volumes failed");
   }
   float* src = blk.p;
   float* sal = src + nvl;
@@ -445,8 +462,9 @@ int visfd_hip_membrane_detect_slab(visfd_hip_slab* s, const float* src_owned, in
   float* scratch = ten + 6 * nvl;
   VH_HIP(hipMemsetAsync(src, 0, sizeof(float) * (size_t)nvl, ctx->stream));     // ghost planes: filled by the exchange
   VH_HIP(hipMemcpyAsync(src + s->own0 * plane, src_owned, sizeof(float) * (size_t)nown, hipMemcpyHostToDevice, ctx->stream));
-  VH_TRY(visfd_hip_membrane_detect_slab_dev(s, src, sal, dirs, ten, scratch, nx, ny, sigma, ratio, order, best_fraction, sigma_tv,
-                                            exponent, cutoff, 0, thr_out));
+  float* bgv = with_bg ? blk.p + (total - (size_t)nvl) : nullptr;   // (behind everything else)
+  VH_TRY(visfd_hip_membrane_detect_slab_bg_dev(s, src, sal, dirs, ten, scratch, bgv, nx, ny, sigma, ratio, order, best_fraction, sigma_tv,
+                                               exponent, cutoff, sigma_background, normalize_background, 0, thr_out));
   VH_HIP(hipMemcpyAsync(sal_owned, sal + s->own0 * plane, sizeof(float) * (size_t)nown, hipMemcpyDeviceToHost, ctx->stream));
   if (tensor_owned) {
     float* packed = scratch + nvl;          // [6][nown] planar, then [nown][6]
@@ -459,6 +477,12 @@ int visfd_hip_membrane_detect_slab(visfd_hip_slab* s, const float* src_owned, in
   }
   VH_HIP(hipStreamSynchronize(ctx->stream));
   return VISFD_HIP_OK;
+}
+int visfd_hip_membrane_detect_slab(visfd_hip_slab* s, const float* src_owned, int64_t nx, int64_t ny, float sigma, float ratio,
+                                   int order, float best_fraction, float sigma_tv, int exponent, float cutoff,
+                                   float* sal_owned, float* tensor_owned, float* thr_out) {
+  return visfd_hip_membrane_detect_slab_bg(s, src_owned, nx, ny, sigma, ratio, order, best_fraction, sigma_tv, exponent, cutoff,
+                                           0.0f, 1, sal_owned, tensor_owned, thr_out);
 }
 
 // BlobDog (feature.hpp:53-427) on one slab: the lists hold the blobs of OWNED planes only, iz as GLOBAL plane index;

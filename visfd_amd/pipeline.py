@@ -47,7 +47,7 @@ def blob_detect(ctx, src, sigmas, truncate_threshold=TRUNCATE_THRESHOLD, delta=0
 
 def membrane_detect(ctx, src, sal, dirs, tensor, sigma, tv_sigma_ratio, tv_exponent=4, best_fraction=0.05,
                     truncate_threshold=TRUNCATE_THRESHOLD, tv_truncate_ratio=math.sqrt(2.0), minima=True,
-                    mask=None, scratch=None):
+                    mask=None, scratch=None, sigma_background=0.0, background=None):
     """filter_mrc -membrane {minima|maxima} -tv ratio -tv-angle-exponent n: fills `sal` with the
     post-voting saliency (lambda0 - lambda1 of the vote tensor), `tensor` with the 6 vote planes.
     Returns the saliency threshold that was applied before voting."""
@@ -57,10 +57,14 @@ def membrane_detect(ctx, src, sal, dirs, tensor, sigma, tv_sigma_ratio, tv_expon
     # for the smoothed image; allocated here when the caller has none to lend).  Voxels below the threshold keep
     # whatever `dirs` held: nothing downstream reads them.
     smoothed = scratch if scratch is not None else src.new_empty(src.shape)
-    ctx.ridge_scores_dev(src, sal, smoothed, sigma, ratio, order, mask)
+    bg = None
+    if sigma_background > 0:   # -membrane-background: both scores times (src - background), handlers.cpp:1577-1605,1698-1702
+        bg = background if background is not None else src.new_empty(src.shape)
+        ctx.peak_background_dev(src, bg, sigma_background, ratio, mask)
+    ctx.ridge_scores_dev(src, sal, smoothed, sigma, ratio, order, mask, bg)
     thr = ctx.threshold_fraction_dev(sal, best_fraction, mask)
     ctx.ridge_directions_dev(smoothed, sal, dirs, sigma, order)
     sigma_tv = float(np.float32(tv_sigma_ratio) * np.float32(sigma))  # settings.cpp:3535-3540
     ctx.tv_dense_stick_dev(sal, dirs, tensor, sigma_tv, tv_exponent, tv_truncate_ratio, mask, mask)
-    ctx.tensor_saliency_dev(tensor, sal, order, mask)
+    ctx.tensor_saliency_dev(tensor, sal, order, mask, src if bg is not None else None, bg)
     return thr
