@@ -289,6 +289,50 @@ def test_cli_tolerance_modes_from_the_environment(cli, ref_cli, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_labels_end_to_end_in_both_modes(cli, ref_cli, tmp_path):
+    """north_star: "bit-exact for non-max/label indices".  A 64^3 volume with three separate membranes through the whole command --
+    `-membrane ... -tv ... -connect ...`, the vote tensors from THIS program's GPU kernels, not the reference's files --
+    against the reference program's label volume: identical labels in exact mode; in tolerance mode
+    (VISFD_HIP_TV_FMA / GAUSS_FMA / EIG_F32 = 1) the number of voxels whose label differs is counted, written to
+    gpurun_out/r4_label_census.txt and bounded."""
+    src = volgen.three_membranes(64, seed=411)
+    inp = str(tmp_path / "vol.rec")
+    volgen.write_mrc(inp, src, voxel_width=1.0)
+    base = ["-w", 1, "-in", inp, "-membrane", "minima", 3, "-tv", 4, "-tv-angle-exponent", 4, "-bin", 1]
+    # the clustering threshold: a quarter of the largest post-vote saliency of the reference's own run
+    mine, ref = both(cli, ref_cli, tmp_path, base, "sal.rec")
+    sal_ref = volgen.read_mrc(str(ref / "sal.rec"))
+    assert_close_rel(volgen.read_mrc(str(mine / "sal.rec")), sal_ref, 1e-5, "post-vote saliency, exact mode")
+    thr = 0.25 * float(sal_ref.max())
+    tail = ["-connect", thr, "-connect-angle", 30]
+    mine, ref = both(cli, ref_cli, tmp_path, base + tail, "labels.rec")
+    want = volgen.read_mrc(str(ref / "labels.rec"))
+    n_clusters = int(want.max()) - 1                      # (voxels outside every cluster carry the label n_clusters + 1)
+    n_lab = int((want < want.max()).sum())
+    assert n_clusters >= 3 and n_lab > 10000, "the reference found %d clusters, %d labelled voxels" % (n_clusters, n_lab)
+    got = volgen.read_mrc(str(mine / "labels.rec"))
+    lines = ["64^3 synthetic membrane volume, -membrane minima 3 -tv 4 -connect %.6g -connect-angle 30: the reference labels %d voxels "
+             "in %d clusters" % (thr, n_lab, n_clusters)]
+    lines.append("exact mode: %d voxels with a label different from the reference program's" % int((got != want).sum()))
+    assert_bits_equal(got, want, "cluster labels, exact mode, tensors from the GPU")
+    env = {"VISFD_HIP_TV_FMA": "1", "VISFD_HIP_GAUSS_FMA": "1", "VISFD_HIP_EIG_F32": "1"}
+    d = tmp_path / "tol"
+    d.mkdir()
+    r = subprocess.run([cli] + [str(a) for a in base + tail] + ["-out", "labels.rec"], cwd=str(d), capture_output=True, text=True,
+                       env=dict(os.environ, **env))
+    assert r.returncode == 0, r.stderr[-2000:]
+    tol = volgen.read_mrc(str(d / "labels.rec"))
+    ndiff = int((tol != want).sum())
+    lines.append("tolerance mode (tv_fma, gauss_fma, eig_f32): %d voxels with a different label (%.3g of the labelled ones)" % (
+        ndiff, ndiff / n_lab))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "r4_label_census.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+    assert ndiff <= 0.002 * n_lab, lines[-1]
+
+
+@pytest.mark.gpu
 def test_cli_membrane_scenario_equals_reference_program(cli, ref_cli, tmp_path):
     """Both commands of tests/test_membrane_detection.sh through both programs: the six vote-tensor files and the
     post-vote saliency agree to 1e-5 (the senders' directions come from the device's fp64 eigen solver, equal to

@@ -75,6 +75,20 @@ def membrane_volume(shape, seed, sd=100.0, amp=-400.0, thickness=1.5):
     return v.astype(np.float32)
 
 
+def three_membranes(n=64, seed=411):
+    """Noise (1000 +- 100) with three dark membranes that do not touch: two gently tilted planes near z = 12 and z = 51
+    and a spherical shell of radius 9 between them -- three clusters for `-connect`."""
+    rng = np.random.default_rng(seed)
+    v = rng.normal(1000.0, 100.0, (n, n, n)).astype(np.float32)
+    z, y, x = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+    d1 = (z - 12.0) + 0.1 * (x - 32)
+    d2 = (z - 51.0) - 0.08 * (y - 32)
+    r = np.sqrt((z - 32.0) ** 2 + (y - 32.0) ** 2 + (x - 31.0) ** 2) - 9.0
+    for d in (d1, d2, r):
+        v += (-400.0 * np.exp(-0.5 * (d / 1.5) ** 2)).astype(np.float32)
+    return v
+
+
 def eigen_cases(seed, nrand=4096):
     """Flat symmetric matrices (xx,yy,zz,xy,yz,xz): degenerate, diagonal, tiny, huge, random."""
     spec = np.array([
