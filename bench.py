@@ -19,7 +19,7 @@ exchange and an all-reduced radix select (visfd_amd/slab.py); value = all voxels
 
 MODES.  BASELINE.json's north_star asks for bit-exact indices and for float voxel values within 1e-5 relative.  The
 headline step therefore runs the library's TOLERANCE modes where the output is a float field -- tensor voting
-(option tv_fma: fused multiply-adds + mirror-paired sender planes) and the plain Gaussian of stage 1 (gauss_fma) -- and
+(option tv_fma: fused multiply-adds, sub-patches with two sender streams, hit lists: csrc/tv_box.hip) and the plain Gaussian of stage 1 (gauss_fma) -- and
 the exact kernels wherever an index depends on the bits (every LoG of the blob stage, the non-max scan, the radix
 select).  `--mode exact` times the all-exact pipeline instead; the line always carries both (`modes`), and
 tests/test_tolerance_modes.py + tests/test_full_size.py hold the tolerance kernels to 1e-5 of the field's scale.
@@ -445,13 +445,13 @@ def main():
         # tensor voting, the dominant kernel: a VALU-bound stencil priced against the FP32 vector peak as SURVEY.md 8d asks --
         # 45 flop per evaluated vote (feature.hpp:2312-2377), votes = salient senders x non-zero taps (boundary clipping
         # ignored: < 4 % at this size)
-        tv_traffic_of = {"exact": offline_traffic("tv_traffic", shape), "tolerance": offline_traffic("tv_pair_traffic", shape)}
+        tv_traffic_of = {"exact": offline_traffic("tv_traffic", shape), "tolerance": offline_traffic("tv_box_traffic", shape)}
         for mode, kname, ops_per_vote, note in (
                 ("exact", "tv_tiled_kernel (bit-exact: the reference's 32 multiplies/adds per vote in its order, no FMA)", 32.0,
                  "peak = nominal FP32 vector rate, which counts an FMA as 2 flop; the reference's operation order forbids FMA here, "
                  "so the reachable rate is the 70 T lane-operations/s the VALU issues (profiles/r02_microbench_valu.txt)"),
-                ("tolerance", "tv_pair_kernel (option tv_fma: 19 fused instructions per vote, mirror-paired sender planes; 1e-5 "
-                 "contract)", 19.0, "flop counted as the reference's 45 per vote (the algorithmic work unit of SURVEY 8d)")):
+                ("tolerance", "tv_box_kernel (option tv_fma: 19 fused instructions per vote, 4x4x2 sub-patches with two sender streams per "
+                 "wave, box-tested hit lists; 1e-5 contract)", 19.0, "flop counted as the reference's 45 per vote (the algorithmic work unit of SURVEY 8d)")):
             with ctx.options(tv_fma=1 if mode == "tolerance" else 0):
                 tv_ms = timed(lambda: ctx.tv_dense_stick_dev(sal, dirs, ten, sigma_tv, MEMBRANE["tv_exponent"], math.sqrt(2.0)), 2)
             tfl = 45.0 * votes / (tv_ms * 1e-3) / 1e12

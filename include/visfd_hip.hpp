@@ -103,85 +103,78 @@ void Dealloc3D(Entry*** a) {
 // order: the container HandleTV keeps its Hessians and vote tensors in (bin/filter_mrc/handlers.cpp:1564-1565).
 template <typename Scalar>
 class CompactMultiChannelImage3D {
-  Scalar* afI;
-  size_t n_good_voxels;
-  int n_channels_per_voxel;
-  int image_size[3];
+  // Written for this shim (only the public face -- aaaafI, nchannels(), the constructors, Resize -- follows the reference):
+  // the channel values of the unmasked voxels live in one std::vector in scan order, and `aaaafI` is an Alloc3D table of
+  // pointers into it that a single pass binds with a running cursor.
+  std::vector<Scalar> values_;
+  int channels_;
+  int dims_[3];
 
-  void Alloc(int const set_image_size[3], Scalar const* const* const* aaafMask, std::ostream* pReportProgress) {
-    for (int d = 0; d < 3; d++) image_size[d] = set_image_size[d];
-    if (pReportProgress)
-      *pReportProgress << " -- Attempting to allocate space for a " << n_channels_per_voxel << "-channel image\n"
-                       << " -- (If this crashes your computer, find a computer with\n"
-                       << " --  more RAM and use \"ulimit\", OR use a smaller image.)\n";
-    aaaafI = Alloc3D<Scalar*>(image_size);
-    n_good_voxels = 0;
-    for (int iz = 0; iz < image_size[2]; iz++)
-      for (int iy = 0; iy < image_size[1]; iy++)
-        for (int ix = 0; ix < image_size[0]; ix++) {
-          aaaafI[iz][iy][ix] = nullptr;
-          if (!(aaafMask && aaafMask[iz][iy][ix] == 0.0)) n_good_voxels++;
-        }
-    afI = new Scalar[n_good_voxels * (size_t)n_channels_per_voxel];
-    size_t n = 0;
-    for (int iz = 0; iz < image_size[2]; iz++)
-      for (int iy = 0; iy < image_size[1]; iy++)
-        for (int ix = 0; ix < image_size[0]; ix++) {
-          if (aaafMask && aaafMask[iz][iy][ix] == 0.0) continue;
-          aaaafI[iz][iy][ix] = &afI[n * (size_t)n_channels_per_voxel];
-          n++;
-        }
-    if (pReportProgress) *pReportProgress << "        done\n" << std::endl;
-  }
-  void Dealloc() {
-    delete[] afI;
-    Dealloc3D(aaaafI);
-    afI = nullptr;
+  static bool masked_out(Scalar const* const* const* mask, int iz, int iy, int ix) { return mask && mask[iz][iy][ix] == 0.0; }
+
+  void release() {
+    if (aaaafI) Dealloc3D(aaaafI);
     aaaafI = nullptr;
+    values_.clear();
+    values_.shrink_to_fit();
+  }
+  // (re)build the pointer table over values_: voxel by voxel in scan order, unmasked voxels take consecutive records
+  template <typename Keep>
+  void bind(Keep keep) {
+    aaaafI = Alloc3D<Scalar*>(dims_);
+    Scalar* cursor = values_.empty() ? nullptr : &values_[0];
+    for (int iz = 0; iz < dims_[2]; iz++)
+      for (int iy = 0; iy < dims_[1]; iy++)
+        for (int ix = 0; ix < dims_[0]; ix++) {
+          const bool k = keep(iz, iy, ix);
+          aaaafI[iz][iy][ix] = k ? cursor : nullptr;
+          if (k) cursor += channels_;
+        }
   }
 
  public:
-  Scalar**** aaaafI;   // a 3-D array of pointers into the compact array
+  Scalar**** aaaafI;   // a 3-D array of pointers into the compact array (nullptr where the mask is zero)
 
-  int nchannels() { return n_channels_per_voxel; }
-  explicit CompactMultiChannelImage3D(int set_n_channels_per_voxel)
-      : afI(nullptr), n_good_voxels(0), n_channels_per_voxel(set_n_channels_per_voxel), aaaafI(nullptr) {
-    image_size[0] = image_size[1] = image_size[2] = 0;
+  int nchannels() { return channels_; }
+  explicit CompactMultiChannelImage3D(int set_n_channels_per_voxel) : channels_(set_n_channels_per_voxel), aaaafI(nullptr) {
+    dims_[0] = dims_[1] = dims_[2] = 0;
   }
   CompactMultiChannelImage3D(int set_n_channels_per_voxel, int const set_image_size[3],
                              Scalar const* const* const* aaafMask = nullptr, std::ostream* pReportProgress = nullptr)
-      : afI(nullptr), n_good_voxels(0), n_channels_per_voxel(set_n_channels_per_voxel), aaaafI(nullptr) {
+      : channels_(set_n_channels_per_voxel), aaaafI(nullptr) {
+    dims_[0] = dims_[1] = dims_[2] = 0;
     Resize(set_image_size, aaafMask, pReportProgress);
   }
   void Resize(int const set_image_size[3], Scalar const* const* const* aaafMask = nullptr,
               std::ostream* pReportProgress = nullptr) {
-    if (aaaafI) Dealloc();
-    Alloc(set_image_size, aaafMask, pReportProgress);
+    release();
+    for (int d = 0; d < 3; d++) dims_[d] = set_image_size[d];
+    size_t kept = 0;
+    for (int iz = 0; iz < dims_[2]; iz++)
+      for (int iy = 0; iy < dims_[1]; iy++)
+        for (int ix = 0; ix < dims_[0]; ix++) kept += masked_out(aaafMask, iz, iy, ix) ? 0 : 1;
+    if (pReportProgress)
+      *pReportProgress << " -- allocating " << channels_ << " channels for " << kept << " of "
+                       << (size_t)dims_[0] * dims_[1] * dims_[2] << " voxels\n";
+    values_.assign(kept * (size_t)channels_, Scalar());
+    bind([&](int iz, int iy, int ix) { return !masked_out(aaafMask, iz, iy, ix); });
   }
-  ~CompactMultiChannelImage3D() { Dealloc(); }
+  ~CompactMultiChannelImage3D() { release(); }
   CompactMultiChannelImage3D(const CompactMultiChannelImage3D<Scalar>& source)
-      : afI(nullptr), n_good_voxels(0), n_channels_per_voxel(source.n_channels_per_voxel), aaaafI(nullptr) {
-    for (int d = 0; d < 3; d++) image_size[d] = source.image_size[d];
+      : values_(source.values_), channels_(source.channels_), aaaafI(nullptr) {
+    for (int d = 0; d < 3; d++) dims_[d] = source.dims_[d];
     if (!source.aaaafI) return;
-    n_good_voxels = source.n_good_voxels;
-    aaaafI = Alloc3D<Scalar*>(image_size);
-    afI = new Scalar[n_good_voxels * (size_t)n_channels_per_voxel];
-    for (size_t i = 0; i < n_good_voxels * (size_t)n_channels_per_voxel; i++) afI[i] = source.afI[i];
-    for (int iz = 0; iz < image_size[2]; iz++)
-      for (int iy = 0; iy < image_size[1]; iy++)
-        for (int ix = 0; ix < image_size[0]; ix++)
-          aaaafI[iz][iy][ix] = source.aaaafI[iz][iy][ix] ? afI + (source.aaaafI[iz][iy][ix] - source.afI) : nullptr;
+    Scalar**** const theirs = source.aaaafI;
+    bind([&](int iz, int iy, int ix) { return theirs[iz][iy][ix] != nullptr; });   // same voxels, same order: same records
   }
   void swap(CompactMultiChannelImage3D<Scalar>& other) {
-    std::swap(n_good_voxels, other.n_good_voxels);
-    std::swap(n_channels_per_voxel, other.n_channels_per_voxel);
-    for (int d = 0; d < 3; d++) std::swap(image_size[d], other.image_size[d]);
-    std::swap(afI, other.afI);
+    values_.swap(other.values_);   // (a vector's buffer moves with it: both pointer tables stay valid)
+    std::swap(channels_, other.channels_);
+    for (int d = 0; d < 3; d++) std::swap(dims_[d], other.dims_[d]);
     std::swap(aaaafI, other.aaaafI);
   }
-  CompactMultiChannelImage3D(CompactMultiChannelImage3D<Scalar>&& other)
-      : afI(nullptr), n_good_voxels(0), n_channels_per_voxel(other.n_channels_per_voxel), aaaafI(nullptr) {
-    image_size[0] = image_size[1] = image_size[2] = 0;
+  CompactMultiChannelImage3D(CompactMultiChannelImage3D<Scalar>&& other) : channels_(other.channels_), aaaafI(nullptr) {
+    dims_[0] = dims_[1] = dims_[2] = 0;
     this->swap(other);
   }
   CompactMultiChannelImage3D<Scalar>& operator=(CompactMultiChannelImage3D<Scalar> source) {

@@ -79,3 +79,18 @@ def test_cpp_shim_compiles_and_runs_host_entry_points(lib, tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "clusters 2 sizes 270 108 undefined 702" in r.stdout and "blobs kept 2" in r.stdout
+
+
+@pytest.mark.parametrize("src,flags", [
+    ("tv_box.hip", ["-DVH_TV_STAMPS", "-DVH_TV_COUNT"]),
+    ("gauss_fused.hip", ["-DVH_FUSED_H=5", "-DVH_FUSED_STAMPS"]),
+])
+def test_development_builds_cross_compile(src, flags, tmp_path):
+    """The only build parameters left in the kernels are the instrumentation switches named in their sources (where a
+    wave's time goes; what the voting kernel tests and hits).  They are not part of the product build, so nothing else
+    would notice if an edit broke them: cross-compile each for gfx950 (hipcc needs no GPU)."""
+    import subprocess
+    from visfd_amd import build as B
+    cmd = [B.HIPCC] + B.FLAGS + ["-fno-slp-vectorize"] + flags + ["-x", "hip", "-c", os.path.join(B.CSRC, src), "-o", str(tmp_path / "o.o")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]

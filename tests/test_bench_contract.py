@@ -32,7 +32,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     # `roofline` describes the DOMINANT kernel of the step (tensor voting: a VALU-bound stencil priced in TFLOP/s against the
     # FP32 vector peak); the HBM-bound kernel BASELINE.json names is `roofline_gauss`
     assert rf["bound"] == "valu" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
-    assert "tv_pair_kernel" in rf["kernel"] and 0 < rf["share_of_step"] <= 1.0
+    assert "tv_box_kernel" in rf["kernel"] and 0 < rf["share_of_step"] <= 1.0
     rg = out["roofline_gauss"]
     assert rg["bound"] == "hbm" and rg["unit"] == "GB/s" and abs(rg["frac"] - rg["achieved"] / rg["peak"]) < 1e-3
     assert abs(rg["frac_of_copy"] - rg["achieved"] / out["copy_gbs"]) < 1e-3 and rg["tolerance_mode"]["bound"] == "hbm"

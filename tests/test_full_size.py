@@ -154,7 +154,7 @@ def test_membrane_1024_cubed_crops_equal_oracle(gpu, volume, oracle):
 
 def test_membrane_1024_cubed_tolerance_mode(gpu, volume, oracle):
     """The same run with tensor voting in TOLERANCE MODE (option tv_fma: fused multiply-adds, mirror-paired sender planes,
-    csrc/tv_pair.hip): vote tensors within 1e-5 of each crop's scale -- corners, run and tile seams, on the membranes -- and
+    csrc/tv_box.hip): vote tensors within 1e-5 of each crop's scale -- corners, run and tile seams, on the membranes -- and
     the post-vote score within 1e-5 as before."""
     zp = lambda y, x: int(round(0.35 * N - 0.15 * x + 0.1 * y))
     E = 28

@@ -2,7 +2,7 @@
 ds_read_b128 serves a wave in four groups of 16 lanes, banks = (byte address / 4) mod 64, a group takes as many LDS cycles
 as its busiest bank has distinct addresses.  Prints the cycles per half wave (32 receivers of one plane) for table rows of
 `stride` float4 entries, lanes dealt to the 8 x 4 patch in row order ("row") or as two 4-column blocks ("block",
-csrc/tv_pair.hip)."""
+csrc/tv_box.hip)."""
 groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
 
 

@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 if len(sys.argv) > 2 and sys.argv[1] == "report":
     rows = list(csv.DictReader(open(glob.glob(sys.argv[2] + "/*/*kernel_trace.csv")[0])))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    last_tv = max(i for i, r in enumerate(rows) if "tv_pair_kernel" in r["Kernel_Name"])
+    last_tv = max(i for i, r in enumerate(rows) if "tv_box_kernel" in r["Kernel_Name"])
     first = max(i for i, r in enumerate(rows[:last_tv]) if "gauss_fused_kernel<4" in r["Kernel_Name"])
     end = last_tv + 1
     while end < len(rows) and "tensor_saliency" not in rows[end]["Kernel_Name"]:

@@ -29,7 +29,7 @@ with open(os.path.join(P, "%s_bench_1024_summary.txt" % tag), "w") as f:
                                                      float(r["AverageNs"]) / 1e6, r["Percentage"]))
 for a, b in (("bench.json", "%s_bench_1024.json"), ("bench_under_rocprof.json", "%s_bench_1024_under_rocprof.json"),
              ("gauss_traffic.json", "%s_gauss_traffic.json"), ("tv_traffic.json", "%s_tv_traffic.json"),
-             ("gauss_fma_traffic.json", "%s_gauss_fma_traffic.json"), ("tv_pair_traffic.json", "%s_tv_pair_traffic.json"),
+             ("gauss_fma_traffic.json", "%s_gauss_fma_traffic.json"), ("tv_box_traffic.json", "%s_tv_box_traffic.json"),
              ("gauss_launches.txt", "%s_bench_1024_gauss_launches.txt"), ("pytest_gpu.log", "%s_pytest_gpu.txt")):
     if os.path.exists(os.path.join(src_dir, a)):
         shutil.copy(os.path.join(src_dir, a), os.path.join(P, b % tag))

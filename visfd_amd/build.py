@@ -21,13 +21,10 @@ LIB = os.path.join(HERE, "libvisfd_hip.so")
 SOURCES = ["host_math.cpp", "blob_post.cpp", "connect.cpp", "api.hip", "gauss.hip", "blob.hip", "select.hip", "tv.hip", "resample.hip", "slab.hip"]
 # (source, object stem, extra flags): the fused Gaussian is compiled once per window half-width
 # the vote loop is faster without the SLP vectoriser's packed-f32 shuffles (profiles/r01 notes)
-TV_VARIANT = [("tv_tiled.hip", "tv_tiled", ["-fno-slp-vectorize"]), ("tv_pair.hip", "tv_pair", ["-fno-slp-vectorize"]),
-              ("tv_box.hip", "tv_box", ["-fno-slp-vectorize"]),
+TV_VARIANT = [("tv_tiled.hip", "tv_tiled", ["-fno-slp-vectorize"]), ("tv_box.hip", "tv_box", ["-fno-slp-vectorize"]),
               ("ridge.hip", "ridge", [])]
 VARIANTS = TV_VARIANT + [("gauss_fused.hip", "gauss_fused_h%d" % h, ["-DVH_FUSED_H=%d" % h, "-fno-slp-vectorize"])
                          for h in range(1, 9)]
-if os.environ.get("VISFD_FUSED_EXTRA_CFGS"):
-    VARIANTS = [(s, o, f + ["-DVH_FUSED_EXTRA_CFGS"]) for s, o, f in VARIANTS]
 HEADERS = ["common.hpp", "eigen3.hpp", os.path.join("..", "..", "include", "visfd_hip.h")]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -113,7 +113,7 @@ struct Taps {
   int h;
 };
 
-// row stride (in float4 entries) of the tolerance-mode vote table: 2h+1 rounded up to 4 modulo 8 (tv_pair.hip: LDS banks)
+// row stride (in float4 entries) of the tiled kernel's vote table: 2h+1 rounded up to 4 modulo 8 (tv_tiled.hip: LDS banks)
 inline int tv_padded_row(int h) {
   int sp = 2 * h + 1;
   while ((sp & 7) != 4) sp++;

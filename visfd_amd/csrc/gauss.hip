@@ -15,15 +15,8 @@
 #include "common.hpp"
 
 // Outputs that this kernel does not read again are stored non-temporally: stores that allocate in L2 push out the rows
-// neighbouring workgroups share (measured on the single sweep: csrc/gauss_fused.hip).  -DVH_STREAM_STORES=0 restores plain stores.
-#ifndef VH_STREAM_STORES
-#define VH_STREAM_STORES 1
-#endif
-#if VH_STREAM_STORES
+// neighbouring workgroups share (measured on the single sweep: csrc/gauss_fused.hip).
 #define VH_STREAM_STORE(v, p) __builtin_nontemporal_store((v), (p))
-#else
-#define VH_STREAM_STORE(v, p) (*(p) = (v))
-#endif
 
 namespace vh {
 

@@ -42,18 +42,7 @@
 // Cache policy of the output stores: nt (aux = 2).  The result is not read again by this kernel, and stores that allocate
 // in L2 push out the input rows neighbouring tiles share; measured on the tolerance kernel at 2048^3 (same box, alternating
 // runs): 16.5 / 16.1 / 18.0 ms with default-policy stores, 15.3 / 15.2 / 14.9 ms with nt; 1-2 % at 1024^3, every variant.
-#ifndef VH_FUSED_STORE_AUX
-#define VH_FUSED_STORE_AUX 2
-#endif
-#ifndef VH_FUSED_ZFILL
-#define VH_FUSED_ZFILL 1
-#endif
-#ifndef VH_FUSED_STAGGER
-#define VH_FUSED_STAGGER 0
-#endif
-#ifndef VH_FUSED_SCALAR_WAVE
-#define VH_FUSED_SCALAR_WAVE 1
-#endif
+constexpr int VH_FUSED_STORE_AUX = 2;
 
 namespace vh {
 
@@ -136,11 +125,6 @@ __device__ __forceinline__ float lds_read_f1(const float* p) {
   return *(const volatile VH_LDS float*)(uintptr_t)(const VH_LDS void*)p;
 }
 __device__ __forceinline__ float2 lds_read_f2(const float* p) {
-#if defined(VH_FUSED_EXP) && VH_FUSED_EXP == 4   // experiment 4: no LDS reads in the Y pass
-  float x = 1.0f, y = 2.0f;
-  asm volatile("" : "+v"(x), "+v"(y) : "v"(p));
-  return make_float2(x, y);
-#endif
   typedef float v2f_ __attribute__((ext_vector_type(2)));
   const v2f_ v = *(const volatile VH_LDS v2f_*)(const VH_LDS void*)p;
   return make_float2(v.x, v.y);
@@ -233,7 +217,7 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
     col_off[c] = inside ? (unsigned)(gy * nx + gx) * 4u : OOB;
   }
   const int lds_base = 4 * tid;   // BYTE offset of column c in sZ: lds_base + 4 * NT * c
-  const int lane = tid & 63, wave = VH_FUSED_SCALAR_WAVE ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int NYR = C::YBLOCK ? C::YB_ROUNDS : C::YROUNDS;
   int y_off[NYR];    // LDS BYTE offset of (row y, column pair xp); -1: idle lane
   if constexpr (C::YBLOCK) {
@@ -295,16 +279,10 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
   // profiles/r02_gauss_experiments.txt).  The tolerance kernel has half the arithmetic: at 2048^3 a workgroup has ~1.9 us per
   // plane, less than a loaded HBM round trip, so it keeps TWO planes ahead (PF = 2: plane k + 2 is requested into the
   // registers plane k has just left; the march is unrolled 2W times so that the set index stays a compile-time constant).
-#ifndef VH_FUSED_PF
-#define VH_FUSED_PF 2
-#endif
-  constexpr int PF = (FMA && ZPASS) ? VH_FUSED_PF : 1;
+  constexpr int PF = (FMA && ZPASS) ? 2 : 1;
   float xin2[PF][C::NC];
   float (&xin)[C::NC] = xin2[0];
   auto request_plane = [&](int zn, bool wanted, int par = 0) {   // a zero-length descriptor fetches nothing and returns 0.0f
-#if defined(VH_FUSED_EXP) && VH_FUSED_EXP == 1   // experiment: every request re-reads one (cache-resident) plane
-    zn = ktop < nz ? ktop : nz - 1;
-#endif
     const bool zin = wanted && zn >= 0 && zn < nz;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(src + (zin ? (i64)zn * plane : 0)), 0, zin ? plane_bytes : 0, 0x00020000);
@@ -352,7 +330,7 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
   };
   auto z_scatter = [&](int u, int par = 0) { z_scatter_cols(u, 0, C::NC, par); };
   // FILL: the Z pass of the NEXT plane is independent of the Y and X passes of this one, and every Y or X round starts
-  // with an LDS round trip that four waves per SIMD do not cover.  With VH_FUSED_ZFILL the ring update is cut into three
+  // with an LDS round trip that four waves per SIMD do not cover.  At H <= 3 the ring update is cut into three
   // column groups that run right after the reads of the first Y round, the last Y round and the first X round have
   // been requested.
   constexpr int ZF0 = C::NC / 3, ZF1 = (2 * C::NC) / 3;
@@ -604,12 +582,7 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
 #pragma unroll
             for (int c = 0; c < C::NC; c++) asm volatile("" : "+v"(xin2[next_par][c]));   // (the set the next Z pass consumes)
           }
-#if defined(VH_FUSED_EXP) && VH_FUSED_EXP == 2   // experiment: no output stores (values kept live)
-          asm volatile("" :: "v"(a[0]), "v"(a[1]));
-          if (false) {
-#else
           if (C::XV == 4) {
-#endif
             v4f out = {a[0], a[1], a[2], a[3]};
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, out), ro, (int)o_off[r], 0, VH_FUSED_STORE_AUX);
           } else {
@@ -666,14 +639,10 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
   z_step(std::integral_constant<int, W - 1>{}, 0, 0);
   // Main loop, one workgroup barrier per plane.  Between two barriers every wave runs the Y and X passes of plane n
   // (reading buffer n & 1, complete since the barrier) AND the Z pass of plane n+1 (writing the other buffer, whose
-  // readers finished before the barrier); the two pieces are independent.  VH_FUSED_STAGGER=1 lets the two halves of
-  // the workgroup take them in OPPOSITE order (each SIMD hosts waves of both halves), so that LDS-bound Y passes run
-  // beside VALU-bound Z passes: measured neutral at 1024^3 (2.48 against 2.46 ms, profiles/r02_gauss_experiments.txt)
-  // at 1.7x the code, hence off.  Unrolled W times (v) so that the ring indices are constants: plane n+1 has phase v.
-#ifndef VH_FUSED_STAGGER
-#define VH_FUSED_STAGGER 0
-#endif
-  const bool z_first = VH_FUSED_STAGGER && __builtin_amdgcn_readfirstlane(wave) >= C::NW / 2;
+  // readers finished before the barrier); the two pieces are independent.  (Letting the two halves of the workgroup take
+  // them in OPPOSITE order, so that LDS-bound Y passes run beside VALU-bound Z passes, measured neutral at 1024^3 at 1.7x
+  // the code: profiles/r02_gauss_experiments.txt.)  Unrolled W times (v) so that the ring indices are constants: plane
+  // n+1 has phase v.
   for (int nb = 0; nb < nout; nb += PF * W) {
     static_for<0, PF * W>([&](auto V2) {
       constexpr int v2 = decltype(V2)::value;
@@ -683,13 +652,11 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
       const int n = nb + v2;
       if (n < nout) {  // uniform across the workgroup
         VH_STAMP(0);
-#if !(defined(VH_FUSED_EXP) && VH_FUSED_EXP == 3)   // experiment 3: no workgroup barrier (wrong results)
         __syncthreads();
-#endif
         VH_STAMP(3);
         // (the Z pass, which updates the register ring, stands once in the code; the Y/X passes stand before and
         // after it and each wave runs one of the two copies)
-        if (VH_FUSED_ZFILL && C::YBLOCK && H <= 3 && !VH_FUSED_STAGGER) {
+        if (C::YBLOCK && H <= 3) {
           // the ring update of plane n+1 runs inside the Y/X passes of plane n, in three pieces behind their LDS requests.
           // Only for the small windows: the pieces need the next input plane EARLY in the interval, and at H >= 4 (one
           // 1024-thread workgroup per CU, 2.2 us per plane) that exposes the HBM latency the old order hides -- H = 2, 3:
@@ -701,16 +668,10 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
           if (more) z_store(V, n + 1, npar);
           VH_STAMP(1);
         } else {
-          if (!z_first) {   // uniform per wave
-            yx_passes(ze - 1 - n, sZ2[n & 1], [](int) {}, npar);
-            VH_STAMP(6);
-          }
+          yx_passes(ze - 1 - n, sZ2[n & 1], [](int) {}, npar);
+          VH_STAMP(6);
           if (n + 1 < nout) z_step(V, n + 1, npar);
           VH_STAMP(1);
-          if (z_first) {
-            yx_passes(ze - 1 - n, sZ2[n & 1], [](int) {}, npar);
-            VH_STAMP(6);
-          }
         }
       }
     });
@@ -792,14 +753,6 @@ int VH_CAT(launch_gauss_fused_h, VH_FUSED_H)(visfd_hip_ctx* ctx, const float* sr
                                             const float* Dz, i64 dz_offset, bool normalize, int cfg,
                                             const float* minuend, float log_scale, bool fma) {
   constexpr int H = VH_FUSED_H;
-#ifdef VH_FUSED_EXTRA_CFGS   // development: alternative tilings selectable at run time
-  if (cfg == 7) return launch_cfg<H, 64, 32, 1024, 2, 2>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
-  if (cfg == 8) return launch_cfg<H, 64, 32, 1024, 2, 1>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
-  if (cfg == 9) return launch_cfg<H, 128, 32, 1024, 4, 1>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
-  if (cfg == 10) return launch_cfg<H, 64, 32, 512, 4, 2>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
-  if (cfg == 11) return launch_cfg<H, 64, 32, 512, 4, 1>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
-  if (cfg == 12) return launch_cfg<H, 96, 32, 512, 4, 1>(ctx, src, dst, nx, ny, nz, tx, ty, tz, Dx, Dy, Dz, dz_offset, normalize, minuend, log_scale);
-#endif
   (void)cfg;
   // tilings picked from sweeps on MI355X (1024^3; profiles/r01_gauss_tiling_sweep.txt): wide tiles cut the
   // halo recomputation of the Z and Y passes (the kernel is VALU-bound), until the register ring

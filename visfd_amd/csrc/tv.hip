@@ -131,10 +131,6 @@ int dev_tv_box(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* te
                const float* mask_dst, i64 nx, i64 ny, i64 nz, i64 z_out0, i64 z_out1, int h, const float4* dtab_box,
                int exponent, bool* handled);
 
-// declared in tv_pair.hip
-int dev_tv_pair(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* ten, const float* mask_src,
-                const float* mask_dst, i64 nx, i64 ny, i64 nz, i64 z_out0, i64 z_out1, int h, const float4* dtab_fma,
-                int exponent, bool* handled);
 
 // The vote table of (sigma_tv, cutoff) on the device: float4 {w, rhat_x, rhat_y, rhat_z} per offset j in z, y, x order
 // (filter3d.hpp:563-578, feature.hpp:2470-2478).  Built on the host once and kept in the context: a launch with the same
@@ -150,23 +146,22 @@ static int tv_table_device(visfd_hip_ctx* ctx, float sigma_tv, float cutoff, int
   std::vector<float> w(m), rh(3 * m);
   host_tv_tables(sigma_tv, h, w.data(), rh.data());
   // three tables: [0, m) the reference's {w, rhat}, packed (baseline kernel); then the same with rows padded to
-  // tv_padded_row(h) entries (tiled kernel: LDS banks); then the tolerance mode's {w, sqrt(2) rhat}, padded as well
-  // (tv_pair.hip: vote_fma).  Pad entries are never read.
+  // tv_padded_row(h) entries (tiled kernel: LDS banks; pad entries are never read); then the tolerance mode's
+  // {w, sqrt(2) rhat} in the slice layout of tv_box.hip (zero rows and zero row tails, which ARE read: common.hpp)
   const size_t sp = (size_t)tv_padded_row(h), m2 = n * n * sp;
-  // and the same {w, sqrt(2) rhat} in the slice layout of tv_box.hip (zero rows and zero row tails: common.hpp)
   const size_t spb = (size_t)tv_box_row(h), nslb = (size_t)tv_box_slice(h), m3 = n * nslb;
-  std::vector<float4> tab(m + 2 * m2 + m3, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+  std::vector<float4> tab(m + m2 + m3, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
   const float rt2 = 1.41421356237309504880f;
   for (size_t k = 0; k < m; k++) {
     tab[k] = make_float4(w[k], rh[3 * k], rh[3 * k + 1], rh[3 * k + 2]);
     tab[m + (k / n) * sp + (k % n)] = tab[k];
-    tab[m + m2 + (k / n) * sp + (k % n)] = make_float4(w[k], rt2 * rh[3 * k], rt2 * rh[3 * k + 1], rt2 * rh[3 * k + 2]);
-    tab[m + 2 * m2 + (k / (n * n)) * nslb + 4 + ((k / n) % n + 3) * spb + (k % n)] = tab[m + m2 + (k / n) * sp + (k % n)];
+    tab[m + m2 + (k / (n * n)) * nslb + 4 + ((k / n) % n + 3) * spb + (k % n)] =
+        make_float4(w[k], rt2 * rh[3 * k], rt2 * rh[3 * k + 1], rt2 * rh[3 * k + 2]);
   }
   float4* dtab = nullptr;
   ctx->tv_table_dev = nullptr;
-  VH_TRY(ws(ctx, WS_TVTAB, m + 2 * m2 + m3, &dtab));
-  VH_HIP(hipMemcpyAsync(dtab, tab.data(), sizeof(float4) * (m + 2 * m2 + m3), hipMemcpyHostToDevice, ctx->stream));
+  VH_TRY(ws(ctx, WS_TVTAB, m + m2 + m3, &dtab));
+  VH_HIP(hipMemcpyAsync(dtab, tab.data(), sizeof(float4) * (m + m2 + m3), hipMemcpyHostToDevice, ctx->stream));
   VH_HIP(hipStreamSynchronize(ctx->stream));
   ctx->tv_table_dev = reinterpret_cast<float*>(dtab);
   ctx->tv_table_h = h;
@@ -192,14 +187,11 @@ int dev_tv_dense_stick(visfd_hip_ctx* ctx, const float* sal, const float* dir, f
   const size_t m_packed = (size_t)(2 * h + 1) * (2 * h + 1) * (2 * h + 1);
   const size_t m_padded = (size_t)(2 * h + 1) * (2 * h + 1) * (size_t)tv_padded_row(h);
   bool handled = false;
-  // tolerance mode (option tv_fma): fused multiply-adds and mirror-paired sender planes (tv_pair.hip); windows and vote
-  // forms it does not take fall through to the exact kernels
-  if (!ctx->opt.tv_dense && ctx->opt.tv_fma == 1 && !curves)
-    VH_TRY(dev_tv_box(ctx, sal, dir, ten, mask_src, mask_dst, nx, ny, nz, z_out0, z_out1, h,
-                      dtab + m_packed + 2 * m_padded, exponent, &handled));
-  if (!handled && !ctx->opt.tv_dense && ctx->opt.tv_fma && !curves)
-    VH_TRY(dev_tv_pair(ctx, sal, dir, ten, mask_src, mask_dst, nx, ny, nz, z_out0, z_out1, h,
-                       dtab + m_packed + m_padded, exponent, &handled));
+  // tolerance mode (option tv_fma): fused multiply-adds, sub-patches with two sender streams, box-tested hit lists
+  // (tv_box.hip); windows and vote forms it does not take fall through to the exact kernels
+  if (!ctx->opt.tv_dense && ctx->opt.tv_fma && !curves)
+    VH_TRY(dev_tv_box(ctx, sal, dir, ten, mask_src, mask_dst, nx, ny, nz, z_out0, z_out1, h, dtab + m_packed + m_padded, exponent,
+                      &handled));
   if (handled) return VISFD_HIP_OK;
   if (!ctx->opt.tv_dense)
     VH_TRY(dev_tv_tiled(ctx, sal, dir, ten, mask_src, mask_dst, nx, ny, nz, z_out0, z_out1, h, dtab + m_packed, exponent, curves,

@@ -43,39 +43,24 @@ namespace vh {
 
 namespace {
 
-#ifndef VH_TV_NT
-#define VH_TV_NT 512
-#endif
-constexpr int NT = VH_TV_NT;
+constexpr int NT = 512;
 constexpr int NW = NT / 64;
 constexpr int TX = 8, TY = 4 * NW;    // receivers of a workgroup: 8 x 32 on each of TWO consecutive planes; a wave owns four
                                       // rows of both planes (lanes 0-31: plane z, lanes 32-63: plane z+1)
 static_assert(TY <= 64, "row coordinates relative to the tile centre are packed as signed bytes");
-#ifndef VH_TV_CAP
-#define VH_TV_CAP 256
-#endif
-constexpr int CAP = VH_TV_CAP;       // list entries held in LDS per sweep and list (one per thread of the list's share)
-// RECEIVER PAIRS PER PASS (round 3, as tv_pair.hip).  The sender planes the pairs (z, z+1) and (z+2, z+3) meet at step t of their
+constexpr int CAP = 256;             // list entries held in LDS per sweep and list (one per thread of the list's share)
+// RECEIVER PAIRS PER PASS (round 3).  The sender planes the pairs (z, z+1) and (z+2, z+3) meet at step t of their
 // ascending jz are different planes, but jz -- and so the two table slices -- are the same: with NP = 2 a workgroup takes both
 // pairs through the steps together (two lists, two sweeps per barrier interval, each wave 2 x 6 sums).  Every receiver still
 // takes its votes in the reference's order; only the interleaving of DIFFERENT receivers' sums changes.
-#ifndef VH_TV_NP
-#define VH_TV_NP 2
-#endif
-constexpr int NP = (VH_TV_NP * CAP <= NT) ? VH_TV_NP : 1;
+constexpr int NP = 2;
 static_assert(NP * CAP <= NT, "the replay loads one entry per thread");
 constexpr int LST = CAP + 8;         // l_pos entries per list (8 never-hit entries of slack behind each list)
-// PACKED LISTS (round 3, as tv_pair.hip): the lists of a step share the NT entry slots of LDS -- their entries are dealt to the
+// PACKED LISTS (round 3): the lists of a step share the NT entry slots of LDS -- their entries are dealt to the
 // threads as ONE sequence, each list's share of an interval lands contiguously (an even start, 8 never-hit entries of slack
 // behind it), and an interval ends when NT entries are in, not when the longest list has had CAP.  Every list is still swept
 // in its own order, interval after interval, so every receiver takes its votes in the reference's order.
-#ifndef VH_TV_PACK
-#define VH_TV_PACK 1
-#endif
-constexpr int LSLOTS = VH_TV_PACK ? NT + 12 * NP : NP * LST;   // l_pos / l_ent entry slots
-#ifndef VH_TV_LIST2
-#define VH_TV_LIST2 1
-#endif
+constexpr int LSLOTS = NT + 12 * NP;   // l_pos / l_ent entry slots
 constexpr int NCH_MAX = NT >= 512 ? 4 : 5;   // chunks of the region per wave the two-plane lister handles
 constexpr int RING_BYTES = 32;       // bytes per entry of the scratch rings
 constexpr unsigned OOB = 0x7ffffff0u;  // byte offset beyond any plane descriptor: reads give 0
@@ -151,12 +136,8 @@ __device__ __forceinline__ void vote_acc(float T[6], float bse, float m0, float 
   acc(T[2], b2 * m2);
 }
 
-#ifndef VH_TV_WAVES
-#define VH_TV_WAVES 8
-#endif
-
 template <bool MASKED_SRC, int MODE>
-__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MODE != 1 ? VH_TV_WAVES : 2, 8)))
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MODE != 1 ? 8 : 2, 8)))
 tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, float* __restrict__ ten,
                 const float* __restrict__ mask_src, const float* __restrict__ mask_dst,
                 const float4* __restrict__ table /* [(2h+1)^3] : w, rhat_x, rhat_y, rhat_z at j */,
@@ -169,13 +150,10 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
   //             slack past the list hold a never-hit operand, so the sweep runs in whole batches of four and may
   //             prefetch one batch past the end
   //   l_mv[e]   source-mask value of the entry (masked kernels)
-  __shared__ __attribute__((aligned(16))) float4 l_ent[VH_TV_PACK ? LSLOTS : NP * CAP];
+  __shared__ __attribute__((aligned(16))) float4 l_ent[LSLOTS];
   __shared__ __attribute__((aligned(16))) uint2 l_pos[LSLOTS];
-  __shared__ float l_mv[MASKED_SRC ? (VH_TV_PACK ? LSLOTS : NP * CAP) : 1];
+  __shared__ float l_mv[MASKED_SRC ? LSLOTS : 1];
   __shared__ int wave_tot[2][2][NW];
-#if !VH_TV_PACK
-  __shared__ int cull[NP][CAP / 64][2 * NW]; // per list and wave holding entries: entries above / not below the rows each wave can reach
-#endif
   __shared__ unsigned claimed_tile;
   __shared__ int plane_cnt[88];              // entries per ring slot, [2h + 2 NP] (h <= 40)
   // dynamic LDS: two table slices (jz and jz + 1 of the current sender plane), [2][(2h+1)^2] float4
@@ -187,7 +165,7 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
   const int S = 2 * h + 1;       // table row length = planes per ring
   // LDS rows of a slice are SP >= S float4 apart and the lanes of a half wave are dealt to its 8 x 4 receivers as two
   // 4-column blocks, one per 16-lane group of ds_read_b128: 2 instead of 4 LDS cycles per half-wave table read
-  // (tv_pair.hip, tools/lds_bank_model.py; round 3).  Which lane holds which receiver does not touch any receiver's sums.
+  // (tools/lds_bank_model.py; round 3).  Which lane holds which receiver does not touch any receiver's sums.
   const int SP = p.sp;
   const int nsl = S * SP;        // float4 entries per slice (the table in global memory has the same padded rows)
   const int R = p.rw * p.rh;     // region positions per plane
@@ -326,7 +304,7 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
       if (tid == 0) plane_cnt[slot] = total;
     };
 
-    // ---- LISTING, two planes at a time (tv_pair.hip, round 3; window regions of <= 4 chunks per wave: h <= 12).  Every load
+    // ---- LISTING, two planes at a time (round 3; window regions of <= 4 chunks per wave: h <= 12).  Every load
     // of a phase is in flight at once -- the saliencies of both planes (kept in registers across the barrier: one read per
     // voxel), then the normals of a plane's salient voxels -- and both planes share one barrier.  The entries and their order
     // are list_plane's.  A plane index < 0 means "no plane" (zero-length descriptors: nothing is salient).
@@ -435,7 +413,7 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
       auto vote_one = [&](unsigned ent, int k, int s, unsigned e16) {
         const f4v tw = *lds_ptr<f4v>(r16s - e16);
         float fv = tw.x;
-        if (MASKED_SRC) fv = fv * l_mv[(VH_TV_PACK ? li : li * CAP) + s];    // fv = w * mask value first (feature.hpp:2262-2275), then sal * fv
+        if (MASKED_SRC) fv = fv * l_mv[li + s];    // fv = w * mask value first (feature.hpp:2262-2275), then sal * fv
         if (MODE == 3) {
           acc(T[0], fv);                      // "denominator += filter_val" (feature.hpp:2376-2377)
         } else {
@@ -466,8 +444,8 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
       // two register sets swap roles without copies
       int s0 = i0 & ~1;                      // l_pos is read two entries at a time
       // (li: the list's first LDS slot -- packed lists -- or its number)
-      const uint4* pq = reinterpret_cast<const uint4*>(l_pos + (VH_TV_PACK ? li : li * LST)) + (s0 >> 1);
-      unsigned ent = ent_base + 16u * (unsigned)((VH_TV_PACK ? li : li * CAP) + s0);
+      const uint4* pq = reinterpret_cast<const uint4*>(l_pos + li) + (s0 >> 1);
+      unsigned ent = ent_base + 16u * (unsigned)(li + s0);
       asm volatile("" : "+v"(ent));
       uint4 a0 = pq[0], a1 = pq[1];
       while (s0 < i1) {   // uniform
@@ -498,7 +476,7 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
       // interior band while the halo planes above it are still in flight)
       const int sz_hi = min(min(rz + 2 * NP - 1, z_run1 - 1) + h, p.nz - 1), sz_lo = max(rz - h, 0);
       // the window holds at most P planes, so a plane that enters it takes the slot of one that has left
-      if (VH_TV_LIST2 && p.nchunk <= NCH_MAX) {
+      if (p.nchunk <= NCH_MAX) {
         int pend = -1;
         for (int sz = sz_hi; sz >= sz_lo; sz--) {   // uniform
           if (!(p.relist || sz < cached_lo || sz > cached_hi)) continue;
@@ -567,7 +545,6 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
         int rho = (int)__builtin_sqrtf((float)(h * h - jn));
         while (rho * rho > h * h - jn) rho--;
         while ((rho + 1) * (rho + 1) <= h * h - jn) rho++;
-#if VH_TV_PACK
         const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         const int t512 = wave * 64 + ln;                       // this thread's place in the interval's entry sequence
         int pre[NP + 1], pl[NP];                               // (uniform) first position of list k in the step's sequence; its ring slot
@@ -631,58 +608,6 @@ tv_tiled_kernel(const float* __restrict__ sal, const float* __restrict__ dir, fl
           }
           __syncthreads();   // everyone done reading before the lists or the slices are refilled
         }
-#else
-        const int li = min(tid / CAP, NP - 1);                 // (uniform per wave) the list this thread brings entries of
-        const int ltid = tid - li * CAP;
-        const bool bringer = tid < NP * CAP;
-        int my_sz = lsz[0], my_cnt = lcnt[0];
-#pragma unroll
-        for (int k = 1; k < NP; k++)
-          if (li == k) { my_sz = lsz[k]; my_cnt = lcnt[k]; }
-        const unsigned char* ring_plane = ring + (size_t)(((my_sz % P) + P) % P) * plane_stride;
-        for (int done = 0; done < cmax; done += CAP) {          // uniform
-          const int take = bringer ? min(CAP, max(my_cnt - done, 0)) : 0;
-          int epy = -128;                                      // threads without an entry: below every range
-          if (ltid < take) {
-            const unsigned char* src_e = ring_plane + (size_t)(done + ltid) * RING_BYTES;
-            const float4 a = *reinterpret_cast<const float4*>(src_e);
-            const uint4 m = *reinterpret_cast<const uint4*>(src_e + 16);
-            l_ent[li * CAP + ltid] = a;
-            const int e2 = (int)m.y + epz2;
-            l_pos[li * LST + ltid] = make_uint2(m.x | ((unsigned)((-(e2 >> 7)) & 0xff) << 16) | ((unsigned)(e2 & 127) << 24), m.z);
-            if (MASKED_SRC) l_mv[li * CAP + ltid] = __uint_as_float(m.w);
-            epy = (int)(signed char)(m.x >> 8);
-          }
-          if (bringer && ltid < 8) l_pos[li * LST + take + ltid] = make_uint2(NEVER_HIT, 0u);
-          // entries are in descending row order: wave w needs those from the first one at or below row 4w-13+rho to
-          // the last one at or above row 4w-16-rho; the waves that hold entries count both kinds for all waves
-          if (bringer) {
-#pragma unroll
-            for (int w = 0; w < NW; w++) {
-              const int above = __builtin_popcountll(__builtin_amdgcn_ballot_w64(epy > 4 * w - (TY / 2 - 3) + rho));
-              const int upto = __builtin_popcountll(__builtin_amdgcn_ballot_w64(epy >= 4 * w - TY / 2 - rho));
-              if (lane == 0) { cull[li][ltid >> 6][2 * w] = above; cull[li][ltid >> 6][2 * w + 1] = upto; }
-            }
-          }
-          __syncthreads();   // lists (and slices) complete
-#pragma unroll
-          for (int pp = 0; pp < NP; pp++) {
-            int i0 = 0, i1 = 0;
-#pragma unroll
-            for (int w = 0; w < CAP / 64; w++) { i0 += cull[pp][w][2 * wave]; i1 += cull[pp][w][2 * wave + 1]; }
-            i0 = __builtin_amdgcn_readfirstlane(i0);
-            i1 = __builtin_amdgcn_readfirstlane(i1);
-            // the upper plane's receivers see the sender one plane further down: |r - e|^2 grows by 1 - 2 epz
-            const int rcl = r_live[pp] ? recv_c + (half ? 1 - 2 * epz : 0) : 0x100000;
-#if defined(VH_TV_EXP) && VH_TV_EXP == 2   // ablation (wrong results): everything but the sweeps
-            if (i0 > (1 << 20)) sweep(TT[pp], pp, i0, i1, rcl);
-#else
-            if (i1 > i0) sweep(TT[pp], pp, i0, i1, rcl);      // uniform
-#endif
-          }
-          __syncthreads();   // everyone done reading before the lists or the slices are refilled
-        }
-#endif
       }
 
 #pragma unroll
