@@ -496,6 +496,9 @@ typedef struct visfd_hip_transport {
 /* RCCL: rank 0 obtains a 128-byte id (ncclGetUniqueId), the host hands it to every rank by its own means (a file, MPI,
  * torch.distributed ...), every rank creates its slab with it (ncclCommInitRank).  librccl.so is loaded at run time. */
 int visfd_hip_slab_unique_id(void* id_out_128_bytes);
+/* 1 if librccl.so can be loaded in this process (no error is set otherwise): lets every rank agree BEFORE any of them
+ * enters ncclCommInitRank, which would block for ever if one rank could not follow */
+int visfd_hip_slab_rccl_available(void);
 int visfd_hip_slab_create_rccl(visfd_hip_ctx*, const void* unique_id_128_bytes /* may be NULL when world == 1 */, int rank,
                                int world, int64_t nz_global, int ghost, visfd_hip_slab** out);
 int visfd_hip_slab_create_custom(visfd_hip_ctx*, const visfd_hip_transport*, int rank, int world, int64_t nz_global,

@@ -69,3 +69,14 @@ def test_rccl_transport_loopback():
             "s.close(); ctx.close(); print('RCCL-LOOPBACK-OK')\n" % ROOT)
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL-LOOPBACK-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+@pytest.mark.gpu
+def test_reserved_workgroup_slots_admit_a_second_stream():
+    """The 64 workgroup slots a slab run keeps free while a halo is in flight (csrc/slab.hip -> option tv_reserve_wg) are
+    evidence, not a guess: with them a kernel of a second stream, queued right after the vote has started, finishes long
+    before the vote does; without them -- the exact kernel owns every wave slot of the chip -- it waits for the vote's
+    workgroups to exit (tools/reserve_check.py, timed with events)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "reserve_check.py")], cwd=ROOT, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "RESERVE-OK" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])

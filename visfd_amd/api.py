@@ -147,6 +147,7 @@ _SIGS = {
     "visfd_hip_slab_destroy": (C.c_int, [_vp]),
     "visfd_hip_slab_layout": (C.c_int, [_vp, C.POINTER(_i64)]),
     "visfd_hip_slab_set_reserve": (C.c_int, [_vp, C.c_int]),
+    "visfd_hip_slab_rccl_available": (C.c_int, []),
     "visfd_hip_slab_selftest": (C.c_int, [_vp, _i64]),
     "visfd_hip_slab_exchange_dev": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, _i64, _i64, C.c_int]),
     "visfd_hip_membrane_detect_slab_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, C.c_float, C.c_float, C.c_int,
@@ -800,10 +801,21 @@ class Slab:
         elif transport == "rccl" or world == 1:
             idbuf = (C.c_char * 128)()
             if world > 1:
-                if rank == 0:
-                    ctx._chk(self._L.visfd_hip_slab_unique_id(C.addressof(idbuf)))
-                box = [bytes(idbuf)]
+                # Every rank takes the SAME steps whatever fails where: the broadcast always runs (an empty id says that rank 0
+                # could not make one), then the ranks agree (MIN over "I have an id and can load RCCL") before any of them
+                # enters ncclCommInitRank, which blocks until all have joined.
+                ok_here = bool(self._L.visfd_hip_slab_rccl_available())
+                box = [b""]
+                if rank == 0 and ok_here and self._L.visfd_hip_slab_unique_id(C.addressof(idbuf)) == 0:
+                    box = [bytes(idbuf)]
                 dist.broadcast_object_list(box, src=0, group=group)
+                ok_here = ok_here and len(box[0]) == 128
+                on_gpu = dist.get_backend(group) == "nccl"
+                flag = torch.tensor([1 if ok_here else 0], dtype=torch.int32, device="cuda" if on_gpu else "cpu")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                if not int(flag.item()):
+                    raise VisfdHipError(2, "the library's RCCL communicator cannot come up on every rank (rank %d: %s)" % (
+                        rank, "ok" if ok_here else "no id from rank 0 or librccl.so not loadable"))
                 idbuf = (C.c_char * 128).from_buffer_copy(box[0])
             ctx._chk(self._L.visfd_hip_slab_create_rccl(ctx._h, C.addressof(idbuf) if world > 1 else None, rank, world, nz_global,
                                                         ghost, C.byref(self._h)))
@@ -937,8 +949,9 @@ class Slab:
                                                      float(ratio), float(minima_threshold), float(maxima_threshold),
                                                      int(bool(src_halo_ready)), C.addressof(mn), cap, C.byref(nmin),
                                                      C.addressof(mx), cap, C.byref(nmax))
-            if rc == 4:   # VISFD_HIP_ECAPACITY
-                cap = max(int(nmin.value), int(nmax.value)) + 16
+            if rc == 4:   # VISFD_HIP_ECAPACITY: a LOCAL retry -- the ghost planes are in place, so no exchange and no other rank
+                cap = max(int(nmin.value), int(nmax.value), cap) + 16
+                src_halo_ready = True
                 continue
             self.ctx._chk(rc)
             break

@@ -13,7 +13,7 @@
 // the interior receiver planes (those whose windows touch owned sender planes only); the two bands next to the interior
 // faces follow once the halo has landed.  The voting kernels are persistent grids sized to fill every wave slot of the
 // chip, and a transfer kernel that arrives behind such a grid would wait for a workgroup to EXIT -- i.e. for the whole
-// interior vote.  So while a halo is in flight the grid is capped (option tv_max_wg) to leave `reserve_wg` workgroup
+// interior vote.  So while a halo is in flight the grid is capped (option tv_reserve_wg) to leave `reserve_wg` workgroup
 // slots (default 64 = 16 CUs' worth) free for the transport's kernels.
 #include <dlfcn.h>
 
@@ -181,6 +181,18 @@ int halo_wait(visfd_hip_slab* s) {
   return VISFD_HIP_OK;
 }
 
+// An error between halo_start and halo_wait must not leave the handle "in flight" for ever (every later exchange would be
+// refused): on such a path the transfer is drained and the flag cleared.
+struct HaloGuard {
+  visfd_hip_slab* s;
+  ~HaloGuard() {
+    if (s->in_flight) {
+      (void)hipStreamSynchronize(s->xfer);
+      s->in_flight = false;
+    }
+  }
+};
+
 // Exact global k-th largest saliency over all ranks' owned voxels (three radix rounds, each all-reducing 2048 counters
 // on the device), then every owned voxel below it is zeroed (handlers.cpp:1751-1797).
 int global_threshold(visfd_hip_slab* s, float* sal_owned, i64 nvox, float fraction, float* thr_out) {
@@ -220,6 +232,13 @@ int global_threshold(visfd_hip_slab* s, float* sal_owned, i64 nvox, float fracti
 }  // namespace
 
 extern "C" {
+
+int visfd_hip_slab_rccl_available(void) {
+  Rccl* r = nullptr;
+  const int rc = load_rccl(&r);
+  if (rc != VISFD_HIP_OK) set_error("");
+  return rc == VISFD_HIP_OK ? 1 : 0;
+}
 
 int visfd_hip_slab_unique_id(void* id_out) {
   VH_REQUIRE(id_out, "null argument");
@@ -403,6 +422,7 @@ int visfd_hip_membrane_detect_slab_bg_dev(visfd_hip_slab* s, float* src, float* 
     VH_HIP(hipMemsetAsync(sal + (s->own1 + h_tv) * plane, 0, sizeof(float) * (size_t)((nzl - s->own1 - h_tv) * plane), ctx->stream));
   float* chans[4] = {sal, dirs, dirs + nvl, dirs + 2 * nvl};
   VH_TRY(halo_start(s, chans, 4, nx, ny, std::min(s->ghost, h_tv)));
+  HaloGuard guard{s};
   auto vote = [&](i64 za, i64 zb) -> int {
     return dev_tv_dense_stick(ctx, sal, dirs, tensor, nullptr, nullptr, nx, ny, nzl, za, zb, sigma_tv, exponent, cutoff, false);
   };
@@ -410,11 +430,12 @@ int visfd_hip_membrane_detect_slab_bg_dev(visfd_hip_slab* s, float* src, float* 
   const i64 hi_band = s->own1 - (s->rank < s->world - 1 ? h_tv : 0);
   if (s->world > 1 && hi_band > lo_band) {
     // 5a. the interior, beside the transfer: leave workgroup slots free for the transport's kernels
-    const int saved = ctx->opt.tv_max_wg;
-    const int cap = ctx->num_cus * 4 - s->reserve_wg;
-    if (cap >= 1 && (saved <= 0 || saved > cap)) ctx->opt.tv_max_wg = cap;
+    // (option tv_reserve_wg: each voting kernel subtracts it from its OWN chip-filling grid -- 4 workgroups per CU for the
+    // exact kernel, 3 for the tolerance kernel)
+    const int saved = ctx->opt.tv_reserve_wg;
+    ctx->opt.tv_reserve_wg = std::max(saved, s->reserve_wg);
     const int rc = vote(lo_band, hi_band);
-    ctx->opt.tv_max_wg = saved;
+    ctx->opt.tv_reserve_wg = saved;
     VH_TRY(rc);
     VH_TRY(halo_wait(s));
     if (lo_band > s->own0) VH_TRY(vote(s->own0, lo_band));             // 5b. the bands that read ghost planes
@@ -503,8 +524,14 @@ int visfd_hip_blob_dog_slab_dev(visfd_hip_slab* s, float* src, int64_t nx, int64
     VH_TRY(halo_wait(s));
   }
   int64_t nmin = 0, nmax = 0;
-  VH_TRY(visfd_hip_blob_dog_dev(s->ctx, src, nullptr, nx, ny, s->nz_local, blob_sigma, n_sigma, nullptr, delta, ratio, min_thr,
-                                max_thr, 0, minima, min_cap, &nmin, maxima, max_cap, &nmax));
+  const int rc = visfd_hip_blob_dog_dev(s->ctx, src, nullptr, nx, ny, s->nz_local, blob_sigma, n_sigma, nullptr, delta, ratio, min_thr,
+                                        max_thr, 0, minima, min_cap, &nmin, maxima, max_cap, &nmax);
+  if (rc == VISFD_HIP_ECAPACITY) {   // the caller retries with the capacities it is told here -- locally: the ghost planes are in place
+    *n_min = nmin;                   // (src_halo_ready = 1 on the retry), so no other rank takes part
+    *n_max = nmax;
+    return rc;
+  }
+  VH_TRY(rc);
   auto own = [&](visfd_hip_blob* b, int64_t n, int64_t cap) -> int64_t {
     int64_t m = 0;
     for (int64_t i = 0; i < std::min(n, cap); i++)
@@ -515,7 +542,6 @@ int visfd_hip_blob_dog_slab_dev(visfd_hip_slab* s, float* src, int64_t nx, int64
       }
     return m;
   };
-  if (nmin > min_cap || nmax > max_cap) { *n_min = nmin; *n_max = nmax; return fail(VISFD_HIP_ECAPACITY, "blob list capacity too small"); }
   *n_min = own(minima, nmin, min_cap);
   *n_max = own(maxima, nmax, max_cap);
   return VISFD_HIP_OK;

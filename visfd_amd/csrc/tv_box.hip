@@ -33,6 +33,7 @@
 // scale on every case the exact kernel is tested on, including crops of the 1024^3 bench volume).  One documented
 // difference in kind: a NON-FINITE saliency spreads to the (up to 3 voxel wide) rim of zero-weight receivers around
 // its ball (0 * inf), where the reference -- and the exact kernel, which is the default -- leave finite values.
+#include <algorithm>
 #include <type_traits>
 #include <vector>
 
@@ -752,6 +753,9 @@ int dev_tv_box(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* te
   if (wg_per_cu > 3) wg_per_cu = 3;   // 6 waves per SIMD (80 VGPRs)
   if (wg_per_cu < 1) wg_per_cu = 1;
   i64 ngrid = (i64)ctx->num_cus * (i64)wg_per_cu;
+  // slab runs: workgroup slots left free for the transport's kernels while a halo is in flight (slab.hip) -- counted
+  // against THIS kernel's own chip-filling grid
+  if (ctx->opt.tv_reserve_wg > 0) ngrid = std::max<i64>(ngrid - ctx->opt.tv_reserve_wg, 1);
   if (ctx->opt.tv_max_wg > 0 && ngrid > ctx->opt.tv_max_wg) ngrid = ctx->opt.tv_max_wg;
   if (ngrid > nblk) ngrid = nblk;
   unsigned char* scratch = nullptr;

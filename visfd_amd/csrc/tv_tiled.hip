@@ -678,6 +678,9 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
   if (wg_per_cu > max_wg) wg_per_cu = max_wg;
   if (wg_per_cu < 1) wg_per_cu = 1;
   i64 ngrid = (i64)ctx->num_cus * (i64)wg_per_cu;
+  // slab runs: workgroup slots left free for the transport's kernels while a halo is in flight (slab.hip) -- counted
+  // against THIS kernel's own chip-filling grid
+  if (ctx->opt.tv_reserve_wg > 0) ngrid = std::max<i64>(ngrid - ctx->opt.tv_reserve_wg, 1);
   if (ctx->opt.tv_max_wg > 0 && ngrid > ctx->opt.tv_max_wg) ngrid = ctx->opt.tv_max_wg;   // tests: many units per workgroup
   if (ngrid > nblk) ngrid = nblk;
   // scratch rings: (2h+1) planes x (8+2h)(32+2h) entries of 32 bytes per workgroup (2.9 GB for h = 12 on 256 CUs).  Very

@@ -188,6 +188,7 @@ def membrane_detect_slab(ops, layout, src, sal, dirs, tensor, sigma, tv_sigma_ra
     h_gauss = int(math.floor(np.float32(sigma) * np.float32(ratio)))
     sigma_tv = float(np.float32(tv_sigma_ratio) * np.float32(sigma))
     if isinstance(L, api.Slab):   # the C-ABI path: everything below happens in csrc/slab.hip
+        check_stream(L.ctx, src)   # (the library queues on its context's stream: it must be torch's current one)
         smoothed = scratch if scratch is not None else src.new_empty(src.shape)
         return L.membrane_detect(src, sal, dirs, tensor, smoothed, sigma, ratio, order, best_fraction, sigma_tv, tv_exponent,
                                  tv_truncate_ratio, src_halo_ready)
@@ -282,6 +283,7 @@ def blob_detect_slab(ops, layout, src, sigmas, truncate_threshold=0.03, delta=0.
     depth = int(math.floor(ratio * smax)) + 1
     assert L.world == 1 or depth <= L.ghost, "ghost depth too small for the widest LoG"
     if isinstance(L, api.Slab) and not use_ratios:   # the C-ABI path (absolute thresholds prune inside the scan)
+        check_stream(L.ctx, src)
         mins, maxs = L.blob_dog(src, sigmas, delta, ratio, minima_threshold, maxima_threshold, src_halo_ready, cap)
         if L.world > 1:
             mins, maxs = _all_gather_rows(src, (mins, maxs), group)
