@@ -547,6 +547,15 @@ int visfd_hip_blob_dog_slab_dev(visfd_hip_slab*, float* src, int64_t nx, int64_t
                                 float maxima_threshold, int src_halo_ready,
                                 visfd_hip_blob* minima, int64_t minima_capacity, int64_t* n_minima,
                                 visfd_hip_blob* maxima, int64_t maxima_capacity, int64_t* n_maxima);
+/* Host-memory faces for a host that runs one process per GPU (`filter_mrc -gauss|-blob ... -slab`): the rank's OWNED planes
+ * [z1-z0][ny][nx] in, the owned planes of the filtered volume / the blobs of the owned planes (iz GLOBAL) out.  A blob list that
+ * does not fit returns VISFD_HIP_ECAPACITY with the needed counts in n_minima / n_maxima; the retry is local. */
+int visfd_hip_apply_gauss_slab(visfd_hip_slab*, const float* src_owned, int64_t nx, int64_t ny, const float sigma[3],
+                               const int halfwidth[3], int normalize, float* dst_owned, float* A_out);
+int visfd_hip_blob_dog_slab(visfd_hip_slab*, const float* src_owned, int64_t nx, int64_t ny, const float* blob_sigma, int n_sigma,
+                            float delta_sigma_over_sigma, float truncate_ratio, float minima_threshold, float maxima_threshold,
+                            visfd_hip_blob* minima, int64_t minima_capacity, int64_t* n_minima,
+                            visfd_hip_blob* maxima, int64_t maxima_capacity, int64_t* n_maxima);
 
 #ifdef __cplusplus
 }

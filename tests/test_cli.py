@@ -559,7 +559,35 @@ def test_cli_membrane_slab_mode_one_rank_equals_plain_run(cli, tmp_path, id_file
     assert "slab 0 of 1" in r.stderr
     assert open(plain, "rb").read() == open(slab, "rb").read()
     if id_file != "-":
-        assert os.path.getsize(idf) == 128
+        assert not os.path.exists(idf), "rank 0 removes the id file once the communicator is up (no stale ids for a later run)"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("id_file", ["-", "rccl.id"])
+def test_cli_gauss_blob_and_background_slab_mode_one_rank_equal_plain_runs(cli, tmp_path, id_file):
+    """BASELINE config 5 is "full Gauss+TV pipeline": `-slab` also runs `-gauss` (visfd_hip_apply_gauss_slab), `-blob`
+    (visfd_hip_blob_dog_slab) and the membrane stage with its peak-height factor; with one rank every output equals the
+    plain run's byte for byte (volumes) / line for line (blob lists)."""
+    blob_in = os.path.join(GOLDEN, "test_blob_detect.rec")
+    mem_in = os.path.join(GOLDEN, "test_image_membrane.rec")
+    idf = "-" if id_file == "-" else str(tmp_path / "rccl.id")
+    for k, flags in enumerate([("-in", blob_in, "-gauss", 40, "-w", 19.6),
+                               ("-in", blob_in, "-gauss-aniso", 30, 45, 25, "-w", 19.6, "-normalize-filters", "no"),
+                               ("-w", 19.2, "-in", mem_in, "-membrane", "minima", 55, "-tv", 4, "-bin", 1, "-membrane-background", 120)]):
+        plain, slab = tmp_path / ("plain%d.rec" % k), tmp_path / ("slab%d.rec" % k)
+        r = run(cli, *flags, "-out", plain)
+        assert r.returncode == 0, r.stderr
+        r = run(cli, *flags, "-out", slab, "-slab", 0, 1, idf)
+        assert r.returncode == 0, r.stderr
+        assert open(plain, "rb").read() == open(slab, "rb").read(), flags
+    bflags = ("-in", blob_in, "-w", 19.6, "-blob-s", "all", None, 20.0, 48.0, 1.3, "-minima-threshold", -20, "-maxima-threshold", 20)
+    outs = []
+    for tag, extra in (("plain", ()), ("slab", ("-slab", 0, 1, idf))):
+        f = [str(tmp_path / (tag + "_b")) if a is None else a for a in bflags]
+        r = run(cli, *f, *extra)
+        assert r.returncode == 0, r.stderr
+        outs.append([open(str(tmp_path / (tag + "_b")) + suffix).read() for suffix in (".minima.txt", ".maxima.txt")])
+    assert outs[0] == outs[1] and len(outs[0][0]) > 0
 
 
 def test_cli_slab_mode_argument_checks(cli, tmp_path):

@@ -1,6 +1,11 @@
 """Stack the per-rank output files of `filter_mrc ... -slab RANK WORLD IDFILE` (mode-2 MRC files of consecutive Z-slabs) into
 one MRC file:   python tools/join_slabs.py out.rec slab0.rec slab1.rec ...
-The header is the first slab's, with nz, mz, the cell's z extent and the density statistics of the whole volume."""
+The header is the first slab's, with nz, mz, the cell's z extent and the density statistics of the whole volume.
+
+Blob lists (`-blob ... -slab`: every rank writes "<file>.slab<RANK>", rows x y z diameter score with GLOBAL z):
+    python tools/join_slabs.py --blobs {minima|maxima} out.txt list.slab0 list.slab1 ...
+merges them in the order the program writes a list: by score (ascending for minima, descending for maxima), ties in rank
+order (= z order)."""
 import sys
 
 import numpy as np
@@ -16,7 +21,22 @@ def read(path):
     return raw[:1024], data
 
 
+def join_blobs(kind, out, parts):
+    rows = []
+    for p in parts:
+        for ln in open(p):
+            if ln.strip():
+                rows.append((float(ln.split()[4]), ln))
+    rows.sort(key=lambda r: r[0], reverse=(kind == "maxima"))   # (stable: ties keep rank order)
+    with open(out, "w") as f:
+        f.writelines(ln for _, ln in rows)
+
+
 def main():
+    if len(sys.argv) >= 5 and sys.argv[1] == "--blobs":
+        if sys.argv[2] not in ("minima", "maxima"):
+            raise SystemExit(__doc__)
+        return join_blobs(sys.argv[2], sys.argv[3], sys.argv[4:])
     if len(sys.argv) < 3:
         raise SystemExit(__doc__)
     parts = [read(p) for p in sys.argv[2:]]

@@ -148,6 +148,9 @@ _SIGS = {
     "visfd_hip_slab_layout": (C.c_int, [_vp, C.POINTER(_i64)]),
     "visfd_hip_slab_set_reserve": (C.c_int, [_vp, C.c_int]),
     "visfd_hip_slab_rccl_available": (C.c_int, []),
+    "visfd_hip_apply_gauss_slab": (C.c_int, [_vp, _vp, _i64, _i64, _fp, _ip, C.c_int, _vp, _fp]),
+    "visfd_hip_blob_dog_slab": (C.c_int, [_vp, _vp, _i64, _i64, _fp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                                          _vp, _i64, C.POINTER(_i64), _vp, _i64, C.POINTER(_i64)]),
     "visfd_hip_slab_selftest": (C.c_int, [_vp, _i64]),
     "visfd_hip_slab_exchange_dev": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, _i64, _i64, C.c_int]),
     "visfd_hip_membrane_detect_slab_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, C.c_float, C.c_float, C.c_int,

@@ -600,11 +600,10 @@ float ratio_of(const Settings& s) {
 // wait for the file.  IDFILE "-" with WORLD 1 runs without a communicator.  Every rank reads the whole input, computes its
 // owned planes (halos, the global top-fraction threshold and the overlapped votes are csrc/slab.hip's business) and returns
 // them in `out` (nz = z1 - z0), which main() writes to this rank's own -out file; tools/join_slabs.py stacks the files.
-void handle_membrane_slab(const Settings& s, Mrc& tomo_in, Mrc& out, float ratio, int order, int64_t* z0_out) {
-  if (!(s.tv_sigma > 0)) throw VisfdErr("Error: -slab needs -tv (tensor voting).\n");
-  if (!s.hessian_thr_is_fraction) throw VisfdErr("Error: -slab needs the fractional threshold (-tv-best), not -detection-threshold.\n");
-  if (!s.mask.empty() || !s.load_base.empty() || !s.save_base.empty() || s.cluster_connected_voxels)
-    throw VisfdErr("Error: -slab runs the plain -membrane ... -tv stage only (no -mask, -save/-load-progress, -connect).\n");
+// One rank's slab handle for `-slab RANK WORLD IDFILE`: rank 0 makes the RCCL id and publishes it as IDFILE (written under a
+// temporary name, then renamed; removed again once every rank has joined); the other ranks wait for the file.  IDFILE "-"
+// with WORLD 1 runs without a communicator.
+visfd_hip_slab* open_slab(const Settings& s, int64_t nz, int ghost) {
   visfd_hip_ctx* ctx = hip_detail::context();
   unsigned char id[128];
   const bool with_id = !(s.slab_id_file == "-" && s.slab_world == 1);
@@ -632,13 +631,92 @@ void handle_membrane_slab(const Settings& s, Mrc& tomo_in, Mrc& out, float ratio
       if (!got) throw VisfdErr("Error: the id file \"" + s.slab_id_file + "\" did not appear (is rank 0 running?).\n");
     }
   }
+  visfd_hip_slab* slab = nullptr;
+  hip_detail::check(visfd_hip_slab_create_rccl(ctx, with_id ? id : nullptr, s.slab_rank, s.slab_world, nz, ghost, &slab));
+  if (with_id && s.slab_rank == 0) std::remove(s.slab_id_file.c_str());   // every rank has joined: the id has served
+  return slab;
+}
+
+// this rank's planes as an MRC file of their own: the input's header with nz, the cell's z extent and the z origin of the slab
+void write_slab_part(const Settings& s, Mrc& tomo_in, Mrc& part, int64_t z0) {
+  std::memcpy(part.raw_header, tomo_in.raw_header, 1024);
+  float fw[256];
+  std::memcpy(fw, part.raw_header, 1024);
+  const float dz = tomo_in.cella[2] / (float)tomo_in.nz;
+  part.cella[0] = tomo_in.cella[0]; part.cella[1] = tomo_in.cella[1]; part.cella[2] = dz * (float)part.nz;
+  fw[51] += dz * (float)z0;                                // MRC2014 origin z (word 52)
+  std::memcpy(part.raw_header, fw, 1024);
+  if (!s.out.empty()) {
+    cerr << "writing this slab's planes (in 32-bit float mode)\n";
+    part.write(s.out, part);
+  }
+}
+
+// -gauss ... -slab: this rank filters its owned planes (the ghost planes come from the neighbours; the normaliser follows
+// global plane indices, so only the true faces of the volume are borders) and returns them in `out`.
+void handle_gauss_slab(const Settings& s, Mrc& tomo_in, Mrc& out, float ratio, int64_t* z0_out) {
+  if (!s.mask.empty()) throw VisfdErr("Error: -slab does not combine with -mask.\n");
+  int hw[3];
+  hip_detail::check(visfd_hip_gauss_halfwidths(s.width_a, ratio, hw));
+  visfd_hip_slab* slab = open_slab(s, tomo_in.nz, hw[2]);
+  int64_t lay[7];
+  hip_detail::check(visfd_hip_slab_layout(slab, lay));
+  const int64_t z0 = lay[0], z1 = lay[1];
+  cerr << "slab " << s.slab_rank << " of " << s.slab_world << ": planes [" << z0 << ", " << z1 << "), ghost depth " << hw[2] << "\n";
+  out.alloc(tomo_in.nx, tomo_in.ny, (int)(z1 - z0));
+  const size_t plane = (size_t)tomo_in.nx * tomo_in.ny;
+  float A = 0;
+  const int rc = visfd_hip_apply_gauss_slab(slab, tomo_in.data() + (size_t)z0 * plane, tomo_in.nx, tomo_in.ny, s.width_a, hw,
+                                            s.normalize ? 1 : 0, out.data(), &A);
+  visfd_hip_slab_destroy(slab);
+  hip_detail::check(rc);
+  cerr << "  ... where  A = " << A << "\n";
+  *z0_out = z0;
+}
+
+// -blob ... -slab: the blobs of this rank's owned planes (absolute score thresholds only: ratios need the global best score).
+// Rows come back with GLOBAL z; every rank writes its own list files, tools/join_slabs.py merges them.
+void handle_blob_slab(const Settings& s, Mrc& tomo_in, float ratio, vector<visfd_hip_blob>* mins, vector<visfd_hip_blob>* maxs) {
+  if (!s.mask.empty()) throw VisfdErr("Error: -slab does not combine with -mask.\n");
+  for (int d = 0; d < 3; d++)
+    if (s.blob_aspect_ratio[d] != 1.0f) throw VisfdErr("Error: -slab runs isotropic blob detection only (no -blob-aspect-ratio).\n");
+  vector<float> sig(s.blob_diameters.size());
+  hip_detail::check(visfd_hip_blob_diameters_to_sigmas(s.blob_diameters.data(), (int)sig.size(), sig.data()));
+  float smax = 0;
+  for (size_t i = 0; i < sig.size(); i++) smax = std::max(smax, sig[i]);
+  const int ghost = (int)std::floor(ratio * (double)smax * (1.0 + 0.5 * s.delta)) + 1;
+  visfd_hip_slab* slab = open_slab(s, tomo_in.nz, ghost);
+  int64_t lay[7];
+  hip_detail::check(visfd_hip_slab_layout(slab, lay));
+  const int64_t z0 = lay[0];
+  cerr << "slab " << s.slab_rank << " of " << s.slab_world << ": planes [" << z0 << ", " << lay[1] << "), ghost depth " << ghost << "\n";
+  const size_t plane = (size_t)tomo_in.nx * tomo_in.ny;
+  int64_t cap = 1 << 16, nmin = 0, nmax = 0;
+  int rc;
+  for (;;) {
+    mins->resize((size_t)cap);
+    maxs->resize((size_t)cap);
+    rc = visfd_hip_blob_dog_slab(slab, tomo_in.data() + (size_t)z0 * plane, tomo_in.nx, tomo_in.ny, sig.data(), (int)sig.size(), s.delta,
+                                 ratio, s.score_upper, s.score_lower, mins->data(), cap, &nmin, maxs->data(), cap, &nmax);
+    if (rc != VISFD_HIP_ECAPACITY) break;
+    cap = std::max(std::max(nmin, nmax), cap) + 16;
+  }
+  visfd_hip_slab_destroy(slab);
+  hip_detail::check(rc);
+  mins->resize((size_t)nmin);
+  maxs->resize((size_t)nmax);
+}
+
+void handle_membrane_slab(const Settings& s, Mrc& tomo_in, Mrc& out, float ratio, int order, int64_t* z0_out) {
+  if (!(s.tv_sigma > 0)) throw VisfdErr("Error: -slab needs -tv (tensor voting).\n");
+  if (!s.hessian_thr_is_fraction) throw VisfdErr("Error: -slab needs the fractional threshold (-tv-best), not -detection-threshold.\n");
+  if (!s.mask.empty() || !s.load_base.empty() || !s.save_base.empty() || s.cluster_connected_voxels)
+    throw VisfdErr("Error: -slab runs the plain -membrane ... -tv stage only (no -mask, -save/-load-progress, -connect).\n");
   int h_tv = 0;
   hip_detail::check(visfd_hip_tv_tables(s.tv_sigma, s.tv_truncate, &h_tv, nullptr, nullptr));
   const float sigma_bg = s.width_b[0] > 0.0f ? s.width_b[0] : 0.0f;
   const int ghost = std::max(std::max(h_tv, (int)std::floor(s.width_a[0] * ratio) + 1), (int)std::floor(sigma_bg * ratio));
-  visfd_hip_slab* slab = nullptr;
-  hip_detail::check(visfd_hip_slab_create_rccl(ctx, with_id ? id : nullptr, s.slab_rank, s.slab_world, tomo_in.nz, ghost, &slab));
-  if (with_id && s.slab_rank == 0) std::remove(s.slab_id_file.c_str());   // every rank has joined: the id has served
+  visfd_hip_slab* slab = open_slab(s, tomo_in.nz, ghost);
   int64_t lay[7];
   hip_detail::check(visfd_hip_slab_layout(slab, lay));
   const int64_t z0 = lay[0], z1 = lay[1];
@@ -710,7 +788,17 @@ int main(int argc, char** argv) {
     float const* const* const* M = mask.loaded ? mask.a : nullptr;
     const float ratio = ratio_of(s);
 
-    if (s.type == Settings::GAUSS) {
+    if (s.slab_world > 0 && bin > 1) throw VisfdErr("Error: -slab does not combine with binning (use -bin 1).\n");
+    if (s.slab_world > 0 && s.type != Settings::GAUSS && s.type != Settings::BLOB && s.type != Settings::SURFACE_RIDGE)
+      throw VisfdErr("Error: -slab runs with -gauss, -blob and -membrane ... -tv.\n");
+    if (s.type == Settings::GAUSS && s.slab_world > 0) {
+      cerr << "filter_type = Gaussian (Z-slab mode)\n";
+      Mrc part;
+      int64_t z0 = 0;
+      handle_gauss_slab(s, tomo_in, part, ratio, &z0);
+      write_slab_part(s, tomo_in, part, z0);
+      return 0;
+    } else if (s.type == Settings::GAUSS) {
       cerr << "filter_type = Gaussian\n";
       const float A = ApplyGauss(size, tomo_in.a, tomo_out.a, M, s.width_a, s.truncate_ratio, s.truncate_threshold,
                                  s.normalize, &cerr);
@@ -740,11 +828,30 @@ int main(int argc, char** argv) {
     } else if (s.type == Settings::BLOB) {
       vector<std::array<float, 3> > cmin, cmax;
       vector<float> dmin, dmax, smin, smax;
+      string slab_suffix;
+      if (s.slab_world > 0) {
+        // this rank's blobs (global z); with more than one rank every rank writes "<file>.slab<RANK>" (tools/join_slabs.py)
+        vector<visfd_hip_blob> bl[2];
+        handle_blob_slab(s, tomo_in, ratio, &bl[0], &bl[1]);
+        for (int side = 0; side < 2; side++) {
+          vector<std::array<float, 3> >& c = side ? cmax : cmin;
+          vector<float>& dia = side ? dmax : dmin;
+          vector<float>& sc = side ? smax : smin;
+          vector<float> sg(bl[side].size());
+          c.resize(sg.size()); dia.resize(sg.size()); sc.resize(sg.size());
+          for (size_t i = 0; i < sg.size(); i++) {
+            c[i][0] = (float)bl[side][i].ix; c[i][1] = (float)bl[side][i].iy; c[i][2] = (float)bl[side][i].iz;
+            sg[i] = bl[side][i].sigma; sc[i] = bl[side][i].score;
+          }
+          if (!sg.empty()) hip_detail::check(visfd_hip_blob_sigmas_to_diameters(sg.data(), (int)sg.size(), dia.data()));
+        }
+        if (s.slab_world > 1) { std::ostringstream o; o << ".slab" << s.slab_rank; slab_suffix = o.str(); }
+      } else
       BlobDogD(size, tomo_in.a, M, s.blob_diameters, &cmin, &cmax, &dmin, &dmax, &smin, &smax, s.blob_aspect_ratio, s.delta, ratio,
                s.score_upper, s.score_lower, false, &cerr);
       // physical units + sort by score (handlers.cpp:853-909), ties keep list order
       for (int side = 0; side < 2; side++) {
-        const string& fname = side ? s.blob_max_file : s.blob_min_file;
+        const string fname = (side ? s.blob_max_file : s.blob_min_file).empty() ? string() : (side ? s.blob_max_file : s.blob_min_file) + slab_suffix;
         if (fname.empty()) continue;
         vector<std::array<float, 3> >& c = side ? cmax : cmin;
         vector<float>& dia = side ? dmax : dmin;
@@ -770,23 +877,10 @@ int main(int argc, char** argv) {
       vector<float> tensor(want_tensor ? 6 * n : 0);
       const float* mptr = mask.loaded ? mask.data() : nullptr;
       if (s.slab_world > 0) {
-        if (bin > 1) throw VisfdErr("Error: -slab does not combine with binning (use -bin 1).\n");
         Mrc part;
         int64_t z0 = 0;
         handle_membrane_slab(s, tomo_in, part, ratio, order, &z0);
-        // this rank's planes as an MRC file of their own: the input's header with nz, the cell's z extent and the z origin
-        // of the slab
-        std::memcpy(part.raw_header, tomo_in.raw_header, 1024);
-        float fw[256];
-        std::memcpy(fw, part.raw_header, 1024);
-        const float dz = tomo_in.cella[2] / (float)tomo_in.nz;
-        part.cella[0] = tomo_in.cella[0]; part.cella[1] = tomo_in.cella[1]; part.cella[2] = dz * (float)part.nz;
-        fw[51] += dz * (float)z0;                                // MRC2014 origin z (word 52)
-        std::memcpy(part.raw_header, fw, 1024);
-        if (!s.out.empty()) {
-          cerr << "writing this slab's planes (in 32-bit float mode)\n";
-          part.write(s.out, part);
-        }
+        write_slab_part(s, tomo_in, part, z0);
         return 0;
       }
       if (s.load_base.empty()) {

@@ -508,6 +508,69 @@ int visfd_hip_membrane_detect_slab(visfd_hip_slab* s, const float* src_owned, in
 
 // BlobDog (feature.hpp:53-427) on one slab: the lists hold the blobs of OWNED planes only, iz as GLOBAL plane index;
 // merging the ranks' lists (and ratio thresholds, which need the global best score) is the host's job.
+// ---- host-memory faces of the Gaussian and of the blob detector for a host that starts one process per GPU
+// (`filter_mrc ... -slab RANK WORLD IDFILE` with -gauss / -blob): owned planes in, owned planes / owned blobs out ----------
+namespace {
+struct DevBlock {
+  float* p = nullptr;
+  ~DevBlock() { if (p) (void)hipFree(p); }
+};
+// the rank's stored planes on the device: zeros in the ghost planes (the exchange fills them), the owned planes from the host
+int upload_owned(visfd_hip_slab* s, const float* src_owned, i64 nx, i64 ny, float* src) {
+  visfd_hip_ctx* ctx = s->ctx;
+  const i64 plane = nx * ny;
+  VH_HIP(hipMemsetAsync(src, 0, sizeof(float) * (size_t)(plane * s->nz_local), ctx->stream));
+  VH_HIP(hipMemcpyAsync(src + s->own0 * plane, src_owned, sizeof(float) * (size_t)((s->own1 - s->own0) * plane), hipMemcpyHostToDevice,
+                        ctx->stream));
+  return VISFD_HIP_OK;
+}
+}  // namespace
+
+int visfd_hip_apply_gauss_slab(visfd_hip_slab* s, const float* src_owned, int64_t nx, int64_t ny, const float sigma[3],
+                               const int hw[3], int normalize, float* dst_owned, float* A_out) {
+  VH_REQUIRE(s && src_owned && dst_owned && sigma && hw, "null argument");
+  visfd_hip_ctx* ctx = s->ctx;
+  VH_HIP(hipSetDevice(ctx->device));
+  const i64 nzl = s->nz_local, plane = nx * ny, nvl = plane * nzl;
+  VH_TRY(check_dims(nx, ny, nzl));
+  VH_REQUIRE(s->world == 1 || hw[2] <= s->ghost, "ghost depth too small for this window");
+  DevBlock blk;
+  if (hipMalloc(&blk.p, sizeof(float) * 2 * (size_t)nvl) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(VISFD_HIP_ENOMEM, "apply_gauss_slab: device allocation of two slab volumes failed");
+  }
+  float* src = blk.p;
+  float* dst = src + nvl;
+  VH_TRY(upload_owned(s, src_owned, nx, ny, src));
+  float* v[1] = {src};
+  VH_TRY(halo_start(s, v, 1, nx, ny, std::min(s->ghost, hw[2])));
+  VH_TRY(halo_wait(s));
+  // the normaliser follows GLOBAL plane indices (filter3d.hpp:1004-1021): only the true faces of the volume are borders
+  VH_TRY(visfd_hip_apply_gauss_slab_dev(ctx, src, dst, nx, ny, nzl, s->lo, s->nz_global, sigma, hw, normalize, A_out));
+  VH_HIP(hipMemcpyAsync(dst_owned, dst + s->own0 * plane, sizeof(float) * (size_t)((s->own1 - s->own0) * plane), hipMemcpyDeviceToHost,
+                        ctx->stream));
+  VH_HIP(hipStreamSynchronize(ctx->stream));
+  return VISFD_HIP_OK;
+}
+
+int visfd_hip_blob_dog_slab(visfd_hip_slab* s, const float* src_owned, int64_t nx, int64_t ny, const float* blob_sigma, int n_sigma,
+                            float delta, float ratio, float min_thr, float max_thr, visfd_hip_blob* minima, int64_t min_cap,
+                            int64_t* n_min, visfd_hip_blob* maxima, int64_t max_cap, int64_t* n_max) {
+  VH_REQUIRE(s && src_owned, "null argument");
+  visfd_hip_ctx* ctx = s->ctx;
+  VH_HIP(hipSetDevice(ctx->device));
+  const i64 nzl = s->nz_local, plane = nx * ny;
+  VH_TRY(check_dims(nx, ny, nzl));
+  DevBlock blk;
+  if (hipMalloc(&blk.p, sizeof(float) * (size_t)(plane * nzl)) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(VISFD_HIP_ENOMEM, "blob_dog_slab: device allocation of the slab volume failed");
+  }
+  VH_TRY(upload_owned(s, src_owned, nx, ny, blk.p));
+  return visfd_hip_blob_dog_slab_dev(s, blk.p, nx, ny, blob_sigma, n_sigma, delta, ratio, min_thr, max_thr, 0, minima, min_cap, n_min,
+                                     maxima, max_cap, n_max);
+}
+
 int visfd_hip_blob_dog_slab_dev(visfd_hip_slab* s, float* src, int64_t nx, int64_t ny, const float* blob_sigma, int n_sigma,
                                 float delta, float ratio, float min_thr, float max_thr, int src_halo_ready,
                                 visfd_hip_blob* minima, int64_t min_cap, int64_t* n_min, visfd_hip_blob* maxima,
