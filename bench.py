@@ -40,7 +40,7 @@ import time
 
 import numpy as np
 
-os.environ.setdefault("OMP_NUM_THREADS", "16")  # host threads for the CPU baseline (the box share per GPU)
+CPU_SHARE_THREADS = 16   # the box's host-thread share per GPU (gpurun: "16 for one GPU")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -103,7 +103,8 @@ def cpu_model():
 
 def cpu_baseline(src, sample):
     """The same three stages with the reference's OpenMP code on the host, on `src`: a sample^3 volume from the bench's own
-    generator (synth_volume: same noise, blob density per voxel and membrane geometry as the GPU workload)."""
+    generator (same noise statistics, blob density per voxel and membrane geometry as the GPU workload).  Runs in a process
+    of its own whose environment fixed the OpenMP team before the runtime started (cpu_baseline_child)."""
     from oracle import pyoracle as po
     kind = "reference" if po.available("ref") else "port"
     if kind == "port" and not po.available("oracle"):
@@ -131,11 +132,69 @@ def cpu_baseline(src, sample):
         "value": round(nvox / (t3 - t0) / 1e6, 4), "unit": "Mvoxels/s", "cores": cores, "kind": kind,
         "cpu_model": cpu_model(), "host_cpus": os.cpu_count(),
         "omp": {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OMP_PROC_BIND", "OMP_PLACES")},
-        "sample": "%d^3 volume from the bench generator (synth_volume: noise + blobs + membranes, seed 12345), the same three "
-                  "stages with the %s (gauss %.3fs, blob %.3fs, membrane+TV %.3fs)"
+        "sample": "%d^3 volume from the bench generator (noise + blobs + membranes, seed 12345; the host's random stream), the same "
+                  "three stages with the %s (gauss %.3fs, blob %.3fs, membrane+TV %.3fs)"
                   % (sample, "reference's own templates (oracle/_ref)" if kind == "reference" else "CPU restatement (oracle/)",
                      t1 - t0, t2 - t1, t3 - t2),
     }
+
+
+def synth_volume_host(shape, seed):
+    """synth_volume on the host for the CPU baseline's sample (the baseline's processes never touch the GPU): the same
+    construction -- per-plane seeded normal(1000, 100) noise, the two tilted planes and the shell, 4096 blobs per 1024^3 voxels
+    blurred with sigma 3 -- with the host's random stream and the checker's (bit-identical) Gaussian for the blur."""
+    from oracle import pyoracle as po
+    nz, ny, nx = shape
+    rng = np.random.default_rng(seed)
+    vol = (rng.standard_normal(shape, dtype=np.float32) * np.float32(100.0) + np.float32(1000.0)).astype(np.float32)
+    z = np.arange(nz, dtype=np.float32).reshape(nz, 1, 1)
+    y = np.arange(ny, dtype=np.float32).reshape(1, ny, 1)
+    x = np.arange(nx, dtype=np.float32).reshape(1, 1, nx)
+    for (a, b, c, d0) in ((0.15, -0.1, 1.0, 0.35 * nz), (1.0, 0.2, 0.1, 0.6 * nx)):
+        dist = (a * x + b * y + c * z - d0) / math.sqrt(a * a + b * b + c * c)
+        vol -= (400.0 * np.exp(-(dist * dist) / (2 * 1.5 * 1.5))).astype(np.float32)
+    r = np.sqrt((x - 0.5 * nx) ** 2 + (y - 0.4 * ny) ** 2 + (z - 0.5 * nz) ** 2)
+    vol -= (400.0 * np.exp(-((r - 0.3 * min(nx, ny)) ** 2) / (2 * 1.5 * 1.5))).astype(np.float32)
+    imp = np.zeros(shape, np.float32)
+    nblobs = max(8, int(4096 * (nz * ny * nx) / 1024 ** 3))
+    imp.reshape(-1)[rng.integers(0, nz * ny * nx, nblobs)] = -300.0 * (2 * math.pi * 9.0) ** 1.5
+    L = po.load("ref" if po.available("ref") else "oracle")
+    blur, _ = L.gauss_ratio(imp, (3.0, 3.0, 3.0), L.ratio_from_threshold(0.03))
+    return np.ascontiguousarray(vol + blur, np.float32)
+
+
+def cpu_baseline_child(argv):
+    """`bench.py --cpu-child ...`: the CPU baseline off the GPU process's clock.
+      --cpu-child orchestrate SAMPLE SHARE_SAMPLE   make the samples, then one worker per OpenMP team: every host thread
+                                                    (nproc, the headline `cpu_baseline`) and the per-GPU share; one JSON line
+      --cpu-child run FILE SAMPLE                   time the three stages on FILE with the team the environment names
+    A worker's environment (OMP_NUM_THREADS, OMP_PROC_BIND=close, OMP_PLACES=cores) is set by the orchestrator BEFORE the
+    worker starts: libgomp reads it once."""
+    import subprocess
+    import tempfile
+    if argv[0] == "run":
+        print(json.dumps(cpu_baseline(np.load(argv[1]), int(argv[2]))))
+        return 0
+    sample, share_sample = int(argv[1]), int(argv[2])
+    nproc = os.cpu_count() or 1
+    out = None
+    with tempfile.TemporaryDirectory(prefix="visfd_bench_") as d:
+        for threads, edge in ((nproc, sample), (min(CPU_SHARE_THREADS, nproc), share_sample)):
+            f = os.path.join(d, "sample_%d.npy" % edge)
+            if not os.path.exists(f):
+                np.save(f, synth_volume_host((edge, edge, edge), 12345))
+            env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="close", OMP_PLACES="cores")
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-child", "run", f, str(edge)], env=env,
+                               stdout=subprocess.PIPE, text=True)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            res = json.loads(line[-1]) if (r.returncode == 0 and line) else {"value": None, "cores": threads, "kind": "unavailable",
+                                                                              "sample": "worker failed (rc %d)" % r.returncode}
+            if out is None:
+                out = res
+            else:
+                out["per_gpu_share"] = res
+    print(json.dumps(out))
+    return 0
 
 
 STAGE_BYTES_PER_VOXEL = {"gauss": 8.0, "blob_dog": 216.0, "membrane_tv": 112.0}   # SURVEY.md 8d
@@ -170,6 +229,8 @@ def pipeline_roofline(stage_ms, ms_per_step, nvox):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-child":
+        raise SystemExit(cpu_baseline_child(sys.argv[2:]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
@@ -177,7 +238,8 @@ def main():
     ap.add_argument("--size", type=int, default=1024, help="edge of the per-GPU volume")
     ap.add_argument("--nz", type=int, default=0, help="planes per GPU (default: --size); e.g. --size 2048 --nz 512 is one "
                                                        "slab of BASELINE config 5")
-    ap.add_argument("--cpu-sample", type=int, default=256, help="edge of the CPU baseline's sample volume")
+    ap.add_argument("--cpu-sample", type=int, default=256, help="edge of the CPU baseline's sample volume (all host threads)")
+    ap.add_argument("--cpu-share-sample", type=int, default=176, help="edge of the sample of the per-GPU-share run (%d threads)" % CPU_SHARE_THREADS)
     ap.add_argument("--mode", choices=("tolerance", "exact"), default="tolerance",
                     help="headline mode: tolerance = FMA tensor voting + FMA plain Gaussian (1e-5 contract), exact = bit-exact kernels only")
     ap.add_argument("--no-cpu", action="store_true")
@@ -200,12 +262,20 @@ def main():
         sys.stdout.flush()
         raise SystemExit(r.returncode)
 
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    # The CPU baseline (N = 1 only) runs in processes of its own, started BEFORE this one initialises the GPU and beside the
+    # GPU work: it needs its OpenMP team fixed in its environment, and the driver's command should not wait for it.
+    cpu_proc = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        import subprocess
+        cpu_proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-child", "orchestrate", str(args.cpu_sample),
+                                     str(args.cpu_share_sample)], stdout=subprocess.PIPE, text=True)
+
     import torch
     import torch.distributed as dist
     from visfd_amd import api, pipeline, slab
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
@@ -530,13 +600,13 @@ def main():
             del big, bout
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:   # the CPU baseline is an N=1 line only
+    if cpu_proc is not None:   # the CPU baseline is an N=1 line only
         try:
-            cs = args.cpu_sample
-            sample = synth_volume(torch, ctx, (cs, cs, cs), device, seed=12345).cpu().numpy()
-            torch.cuda.synchronize()
-            cpu = cpu_baseline(sample, cs)
+            so, _ = cpu_proc.communicate(timeout=300)
+            line = [ln for ln in so.splitlines() if ln.startswith("{")]
+            cpu = json.loads(line[-1])
         except Exception as e:  # the checker libraries are optional on the GPU box
+            cpu_proc.kill()
             cpu = {"value": None, "unit": "Mvoxels/s", "cores": 0, "kind": "unavailable", "sample": "failed: %s" % e}
 
     if rank == 0:
