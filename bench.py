@@ -165,8 +165,8 @@ def synth_volume_host(shape, seed):
 
 def cpu_baseline_child(argv):
     """`bench.py --cpu-child ...`: the CPU baseline off the GPU process's clock.
-      --cpu-child orchestrate SAMPLE SHARE_SAMPLE   make the samples, then one worker per OpenMP team: every host thread
-                                                    (nproc, the headline `cpu_baseline`) and the per-GPU share; one JSON line
+      --cpu-child orchestrate SAMPLE   make the sample, then one worker per OpenMP team -- every host thread (nproc), 64 and
+                                       the per-GPU share of 16 -- and print one JSON line: the best team's result, all teams listed
       --cpu-child run FILE SAMPLE                   time the three stages on FILE with the team the environment names
     A worker's environment (OMP_NUM_THREADS, OMP_PROC_BIND=close, OMP_PLACES=cores) is set by the orchestrator BEFORE the
     worker starts: libgomp reads it once."""
@@ -175,24 +175,25 @@ def cpu_baseline_child(argv):
     if argv[0] == "run":
         print(json.dumps(cpu_baseline(np.load(argv[1]), int(argv[2]))))
         return 0
-    sample, share_sample = int(argv[1]), int(argv[2])
+    sample = int(argv[1])
     nproc = os.cpu_count() or 1
-    out = None
+    teams = sorted({nproc, min(64, nproc), min(CPU_SHARE_THREADS, nproc)}, reverse=True)
+    runs = []
     with tempfile.TemporaryDirectory(prefix="visfd_bench_") as d:
-        for threads, edge in ((nproc, sample), (min(CPU_SHARE_THREADS, nproc), share_sample)):
-            f = os.path.join(d, "sample_%d.npy" % edge)
-            if not os.path.exists(f):
-                np.save(f, synth_volume_host((edge, edge, edge), 12345))
+        f = os.path.join(d, "sample.npy")
+        np.save(f, synth_volume_host((sample, sample, sample), 12345))
+        for threads in teams:
             env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="close", OMP_PLACES="cores")
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-child", "run", f, str(edge)], env=env,
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-child", "run", f, str(sample)], env=env,
                                stdout=subprocess.PIPE, text=True)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-            res = json.loads(line[-1]) if (r.returncode == 0 and line) else {"value": None, "cores": threads, "kind": "unavailable",
-                                                                              "sample": "worker failed (rc %d)" % r.returncode}
-            if out is None:
-                out = res
-            else:
-                out["per_gpu_share"] = res
+            runs.append(json.loads(line[-1]) if (r.returncode == 0 and line) else
+                        {"value": None, "cores": threads, "kind": "unavailable", "sample": "worker failed (rc %d)" % r.returncode})
+    # the headline is the box's BEST team (the reference's OpenMP loops do not scale to every thread of a 256-thread host);
+    # every team that ran is listed beside it: all host threads, 64, and the per-GPU share
+    good = [r for r in runs if r.get("value")]
+    out = dict(max(good, key=lambda r: r["value"])) if good else dict(runs[0])
+    out["teams"] = [{"cores": r["cores"], "value": r.get("value"), "omp": r.get("omp")} for r in runs]
     print(json.dumps(out))
     return 0
 
@@ -238,8 +239,8 @@ def main():
     ap.add_argument("--size", type=int, default=1024, help="edge of the per-GPU volume")
     ap.add_argument("--nz", type=int, default=0, help="planes per GPU (default: --size); e.g. --size 2048 --nz 512 is one "
                                                        "slab of BASELINE config 5")
-    ap.add_argument("--cpu-sample", type=int, default=256, help="edge of the CPU baseline's sample volume (all host threads)")
-    ap.add_argument("--cpu-share-sample", type=int, default=176, help="edge of the sample of the per-GPU-share run (%d threads)" % CPU_SHARE_THREADS)
+    ap.add_argument("--cpu-sample", type=int, default=144, help="edge of the CPU baseline's sample volume (about 10-20 s of CPU "
+                                                                "work over its three OpenMP teams)")
     ap.add_argument("--mode", choices=("tolerance", "exact"), default="tolerance",
                     help="headline mode: tolerance = FMA tensor voting + FMA plain Gaussian (1e-5 contract), exact = bit-exact kernels only")
     ap.add_argument("--no-cpu", action="store_true")
@@ -264,13 +265,15 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    # The CPU baseline (N = 1 only) runs in processes of its own, started BEFORE this one initialises the GPU and beside the
-    # GPU work: it needs its OpenMP team fixed in its environment, and the driver's command should not wait for it.
+    # The CPU baseline (N = 1 only) runs in processes of its own, started BEFORE this one initialises the GPU: it needs its
+    # OpenMP team fixed in its environment.  It runs beside this process's set-up (imports, context, the synthetic volume)
+    # and is WAITED FOR before the first step: a 256-thread OpenMP job beside the timed steps starves the blob stage's
+    # host side (measured: 125 -> 600 ms).
     cpu_proc = None
     if rank == 0 and world == 1 and not args.no_cpu:
         import subprocess
-        cpu_proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-child", "orchestrate", str(args.cpu_sample),
-                                     str(args.cpu_share_sample)], stdout=subprocess.PIPE, text=True)
+        cpu_proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-child", "orchestrate", str(args.cpu_sample)],
+                                    stdout=subprocess.PIPE, text=True)
 
     import torch
     import torch.distributed as dist
@@ -338,6 +341,16 @@ def main():
     dirs = torch.empty((3,) + shape, device=device, dtype=torch.float32)
     ten = torch.empty((6,) + shape, device=device, dtype=torch.float32)
     torch.cuda.synchronize()
+
+    cpu = None
+    if cpu_proc is not None:
+        try:
+            so, _ = cpu_proc.communicate(timeout=600)
+            line = [ln for ln in so.splitlines() if ln.startswith("{")]
+            cpu = json.loads(line[-1])
+        except Exception as e:  # the checker libraries are optional on the GPU box
+            cpu_proc.kill()
+            cpu = {"value": None, "unit": "Mvoxels/s", "cores": 0, "kind": "unavailable", "sample": "failed: %s" % e}
 
     MODE_OPTS = {"tolerance": dict(tv_fma=1, gauss_fma=1, eig_f32=1), "exact": dict(tv_fma=0, gauss_fma=0, eig_f32=0)}
     ratio = api.ratio_from_threshold(0.03)
@@ -598,16 +611,6 @@ def main():
                 "single_sweep_exact": o2("gauss_fused_kernel<H=5> (bit-exact: what LoG -> non-max indices need)", f_ms),
                 "one_pass": o2("conv_march_kernel<5> / conv_row_kernel<5> (average of the Z, Y, X launches)", p2_ms)}
             del big, bout
-
-    cpu = None
-    if cpu_proc is not None:   # the CPU baseline is an N=1 line only
-        try:
-            so, _ = cpu_proc.communicate(timeout=300)
-            line = [ln for ln in so.splitlines() if ln.startswith("{")]
-            cpu = json.loads(line[-1])
-        except Exception as e:  # the checker libraries are optional on the GPU box
-            cpu_proc.kill()
-            cpu = {"value": None, "unit": "Mvoxels/s", "cores": 0, "kind": "unavailable", "sample": "failed: %s" % e}
 
     if rank == 0:
         out = {
