@@ -177,14 +177,21 @@ def cpu_baseline_child(argv):
         return 0
     sample = int(argv[1])
     nproc = os.cpu_count() or 1
-    teams = sorted({nproc, min(64, nproc), min(CPU_SHARE_THREADS, nproc)}, reverse=True)
+    # (team, edge of its sample): the reference's OpenMP loops get SLOWER beyond a few dozen threads (measured on the 256-thread
+    # GPU box: 0.60 Mvoxels/s with 16, 0.42 with 64, 0.05 with 256), so the large teams get smaller samples to keep the
+    # whole leg at 15-20 s
+    teams = sorted({(nproc, max(32, sample // 2)), (min(64, nproc), max(32, sample * 8 // 9)), (min(CPU_SHARE_THREADS, nproc), sample)},
+                   reverse=True)
+    if nproc <= CPU_SHARE_THREADS:
+        teams = [(nproc, sample)]
     runs = []
     with tempfile.TemporaryDirectory(prefix="visfd_bench_") as d:
-        f = os.path.join(d, "sample.npy")
-        np.save(f, synth_volume_host((sample, sample, sample), 12345))
-        for threads in teams:
+        for threads, edge in teams:
+            f = os.path.join(d, "sample_%d.npy" % edge)
+            if not os.path.exists(f):
+                np.save(f, synth_volume_host((edge, edge, edge), 12345))
             env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="close", OMP_PLACES="cores")
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-child", "run", f, str(sample)], env=env,
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-child", "run", f, str(edge)], env=env,
                                stdout=subprocess.PIPE, text=True)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             runs.append(json.loads(line[-1]) if (r.returncode == 0 and line) else
@@ -193,7 +200,7 @@ def cpu_baseline_child(argv):
     # every team that ran is listed beside it: all host threads, 64, and the per-GPU share
     good = [r for r in runs if r.get("value")]
     out = dict(max(good, key=lambda r: r["value"])) if good else dict(runs[0])
-    out["teams"] = [{"cores": r["cores"], "value": r.get("value"), "omp": r.get("omp")} for r in runs]
+    out["teams"] = [{"cores": r["cores"], "value": r.get("value"), "omp": r.get("omp"), "sample_edge": e} for r, (_, e) in zip(runs, teams)]
     print(json.dumps(out))
     return 0
 
