@@ -48,7 +48,8 @@ enum Slot {
   WS_HIST,                         // radix-select histograms
   WS_TVTAB,                        // tensor-voting lookup table
   WS_TVAUX,                        // tensor-voting auxiliaries
-  WS_TVSCRATCH,                    // tensor voting: per-workgroup rings of compacted sender planes
+  WS_TVSCRATCH,                    // tensor voting: per-workgroup rings of compacted sender planes (exact kernel) / the launch's sender lists
+  WS_TVLIST,                       // tolerance-mode tensor voting: row offsets of the sender lists
   WS_H2D_0, WS_H2D_1, WS_H2D_2, WS_H2D_3, WS_H2D_4,  // staging for the host-pointer face
   WS_NSLOTS
 };

@@ -9,9 +9,10 @@
 // receivers (8 x 4 x 2) with a v_dot4 + v_cmp and votes under the execution mask of the lanes it reaches.  That sweep
 // used 49 % of its lanes (ball of radius h against an 8 x 4 x 2 patch) at ~27 issue slots per vote step.
 //
-// This kernel keeps the skeleton (persistent workgroups claiming units from a global counter, per-workgroup rings of
-// listed sender planes in global memory, packed lists, mirror-paired planes, two receiver pairs per pass) and
-// replaces the sweep:
+// This kernel keeps the skeleton (persistent workgroups claiming units from a global counter, packed lists, mirror-paired
+// planes, two receiver pairs per pass), lists the senders ONCE for the whole launch (tvl_* kernels below: the round-3
+// kernels listed every sender plane again in every workgroup that reached it -- 7 region voxels read per receiver column,
+// 12-15 % of a wave's time) and replaces the sweep:
 //
 //   * SUB-PATCHES OF 32 RECEIVERS, TWO SENDER STREAMS PER WAVE.  A wave owns, per receiver pair, two sub-patches of
 //     4 x 4 x 2 receivers (the left and right half of its 8 x 4 rows).  Lanes 0-31 and lanes 32-63 hold the SAME 32
@@ -49,15 +50,9 @@ constexpr int TX = 8, TY = 4 * NW;     // a workgroup's tile of receivers: 8 x 3
 constexpr int NP = 2;                  // receiver pairs (z, z+1), (z+2, z+3) per pass: they need the same two slices at step d
 constexpr int NLIST = 2 * NP;          // lists per interval: (A, B) of pair 0, (A, B) of pair 1
 constexpr int NSUB = 2;                // sub-patches per wave and pair: x 0..3 and x 4..7
-constexpr int NCH_MAX = 4;             // chunks of the region per wave the two-plane lister handles (h <= 12)
 constexpr int LSLOTS = NT;             // LDS entry slots of an interval: one per thread
 constexpr int HCAP = 36;               // hit entries per (wave, sub-patch, stream): 64 tests per chunk -> <= 32, + null + read-ahead
 constexpr int YPAD = 3;                // zero rows above and below a table slice (a 4-row sub-patch overhangs by 3)
-constexpr unsigned OOB = 0x7ffffff0u;  // byte offset beyond any plane descriptor: reads give 0
-
-__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)byte_off, 0, 0));
-}
 
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
@@ -86,11 +81,9 @@ struct BoxParams {
   int z_out0, z_out1;    // receiver planes [z_out0, z_out1)
   int h;
   int rw, rh;            // region width = TX + 2h, height = TY + 2h
-  int rw_magic;          // q / rw == (q * rw_magic) >> 20 for every region position q (checked by the launcher)
-  int nchunk;            // 64-voxel chunks of the region per wave
   int tiles_x, tiles_y;
   int zrun;              // receiver planes per unit of work
-  int relist;            // 1: list every sender plane again for every pass (option tv_no_replay; tests)
+  int zl0, nzl;          // sender planes [zl0, zl0 + nzl) are listed (tvl_* kernels below)
   int sp;                // row stride of a table slice in float4 entries (tv_box_row)
   int nsl;               // float4 entries of a table slice (tv_box_slice)
 };
@@ -171,44 +164,38 @@ __device__ __forceinline__ void vote_hits(float (&T)[6], unsigned hp, int nst, u
   }
 }
 
-template <bool MASKED_SRC, int MODE>
+template <int MODE>
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6)))
-tv_box_kernel(const float* __restrict__ sal, const float* __restrict__ dir, float* __restrict__ ten,
-              const float* __restrict__ mask_src, const float* __restrict__ mask_dst,
+tv_box_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
               const float4* __restrict__ table /* [2h+1] slices of nsl entries: w, sqrt(2) rhat at j, zero padding */,
               BoxParams p, unsigned* __restrict__ tile_counter, unsigned ntiles,
-              unsigned char* __restrict__ scratch /* per-workgroup rings of compacted sender planes */) {
+              // the sender lists of tvl_write_kernel: for every listed plane and every 8-column tile column, the salient senders
+              // of the columns the tile column can reach, in descending (y, x); rows[(zl (ny+1) + y) ntx + tx] = index of
+              // the first entry of the rows below y (0 for y = ny, the list's length... offsets are absolute)
+              const float4* __restrict__ lst_ent, const unsigned* __restrict__ lst_pos, const unsigned* __restrict__ lst_rows) {
   // l_ent[e]  float4 {saliency (scaled), n0, n1, n2} of the interval's e-th entry; l_ent[LSLOTS]: the null sender (zeros)
   // l_pos[e]  {region position bytes (ex, ey), byte offset of the sender in a table slice: 16 (ey SP + ex)}
   // l_hit     per wave and sub-patch, the hits of the current chunk of 64 tested entries, dealt alternately to two streams
   __shared__ __attribute__((aligned(16))) float4 l_ent[LSLOTS + 1];
   __shared__ __attribute__((aligned(16))) uint2 l_pos[LSLOTS];
   __shared__ __attribute__((aligned(16))) uint2 l_hit[NW][NSUB][2][HCAP];
-  __shared__ int wave_tot[2][2][NW];
   __shared__ unsigned claimed_tile;
-  __shared__ int plane_cnt[88];              // entries per ring slot, [2h + 2 NP] (h <= 40)
+  __shared__ unsigned plane_beg[88];         // per sender plane of a pass (slot = plane - (rz - h), < 2h + 2 NP <= 84): first entry ...
+  __shared__ int plane_cnt[88];              // ... and number of entries of this tile's rows in the plane's list
   __shared__ int rho_tab[44];                // floor(sqrt(h^2 - j^2)), j = 0..h: the radius of slice j
   extern __shared__ __attribute__((aligned(16))) unsigned char slices[];   // two table slices: S_j (jz = +j) in slot j & 1
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = p.h;
-  const int S = 2 * h + 1;
   // LDS rows of a table slice are SP float4 apart, SP = 4 mod 8 and >= S + 3 (tv_box_row): row offsets of 64 or 192 bytes
   // modulo the 256 bytes of the 64 banks.  ds_read_b128 serves a half wave as two groups of 16 lanes, {0-3, 12-15, 20-27}
   // and the rest (MI355X_MICROARCH.md); the lanes of a half wave are dealt to their 4 x 4 x 2 receivers so that each group
   // is the four rows of ONE receiver plane: four 64-byte segments on different banks, whatever the sender's offset.
   const int SP = p.sp;
   const int nsl = p.nsl;
-  const int R = p.rw * p.rh;
   const i64 plane = (i64)p.nx * p.ny;
   const i64 nvox = plane * p.nz;
-  const int plane_bytes = (int)(plane * 4);
-  constexpr int ENT_BYTES = 20;
-  const size_t plane_stride = (size_t)R * ENT_BYTES;   // a ring slot: float4 ent[R]; unsigned pos[R]
-  const int P = S + 2 * NP - 1;   // sender planes the receiver planes of a pass reach = slots of the ring
-  unsigned char* const ring = scratch + (size_t)blockIdx.x * plane_stride * P;
-  int npar = 0;
   int slot_has[2] = {-1, -1};                // which slice S_j each LDS slot holds (uniform)
   bool up = false;                           // direction of d for the next pass (flips after every pass)
   float4* const sl4 = reinterpret_cast<float4*>(slices);
@@ -262,175 +249,6 @@ tv_box_kernel(const float* __restrict__ sal, const float* __restrict__ dir, floa
       unsigned ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
       asm volatile("" : "+v"(ln));
       return ln;
-    };
-
-    // ---- LISTING, two planes at a time (window regions of <= 4 chunks per wave: h <= 12).  Every load of a phase is in
-    // flight at once -- the saliencies of both planes (kept in registers across the barrier: one read per voxel), then the
-    // normals of a plane's salient voxels -- and both planes share one barrier.  A plane index < 0 means "no plane".
-    // Entries are written in DESCENDING region position (row order, which the row-range culling needs).
-    auto list_two = [&](int sz0, int sz1) {
-      constexpr int NCH = NCH_MAX;
-      const int q0 = wave * p.nchunk * 64 + lane;
-      unsigned off[NCH];
-#pragma unroll
-      for (int j = 0; j < NCH; j++) {
-        const int q = q0 + 64 * j;
-        const int ey = (int)(((unsigned)q * (unsigned)p.rw_magic) >> 20);
-        const int ex = q - ey * p.rw;
-        const int sx = x0 - h + ex, sy = y0 - h + ey;
-        const bool ok = j < p.nchunk && q < R && sx >= 0 && sx < p.nx && sy >= 0 && sy < p.ny;
-        off[j] = ok ? (unsigned)(sy * p.nx + sx) * 4u : OOB;
-      }
-      float sv[2][NCH];
-      int cnt[2] = {0, 0};
-#pragma unroll
-      for (int k = 0; k < 2; k++) {
-        const int sz = k ? sz1 : sz0;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(sal + (i64)(sz < 0 ? 0 : sz) * plane), 0,
-                                                                            sz < 0 ? 0 : plane_bytes, 0x00020000);
-#pragma unroll
-        for (int j = 0; j < NCH; j++) sv[k][j] = buf_load(rs, off[j]);
-        if (MASKED_SRC) {
-          const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)(mask_src + (i64)(sz < 0 ? 0 : sz) * plane), 0,
-                                                                              sz < 0 ? 0 : plane_bytes, 0x00020000);
-#pragma unroll
-          for (int j = 0; j < NCH; j++)
-            if (buf_load(rm, off[j]) == 0.0f) sv[k][j] = 0.0f;
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 2; k++)
-#pragma unroll
-        for (int j = 0; j < NCH; j++) cnt[k] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(sv[k][j] != 0.0f));
-      const int par = (npar++) & 1;
-      if (lane == 0) { wave_tot[par][0][wave] = cnt[0]; wave_tot[par][1][wave] = cnt[1]; }
-      __syncthreads();
-#pragma unroll
-      for (int k = 0; k < 2; k++) {
-        const int sz = k ? sz1 : sz0;
-        if (sz < 0) continue;   // uniform
-        int running = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < NW; w++) {
-          const int t = wave_tot[par][k][w];
-          running += (w > wave) ? t : 0;
-          total += t;
-        }
-        running = __builtin_amdgcn_readfirstlane(running);
-        const int slot = sz % P;
-        unsigned char* const ring_plane = ring + (size_t)slot * plane_stride;
-        if (tid == 0) plane_cnt[slot] = total;
-        if (cnt[k] == 0) continue;   // uniform
-        const __amdgpu_buffer_rsrc_t rd0 =
-            __builtin_amdgcn_make_buffer_rsrc((void*)(dir + (i64)sz * plane), 0, plane_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rd1 =
-            __builtin_amdgcn_make_buffer_rsrc((void*)(dir + nvox + (i64)sz * plane), 0, plane_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rd2 =
-            __builtin_amdgcn_make_buffer_rsrc((void*)(dir + 2 * nvox + (i64)sz * plane), 0, plane_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)((MASKED_SRC ? mask_src : sal) + (i64)sz * plane), 0, plane_bytes, 0x00020000);
-        float n0[NCH], n1[NCH], n2[NCH], mvv[NCH];
-#pragma unroll
-        for (int j = 0; j < NCH; j++) {   // the normals of the salient voxels only, all chunks requested before the first use
-          n0[j] = n1[j] = n2[j] = 0.0f;
-          mvv[j] = 1.0f;
-          if (sv[k][j] != 0.0f) {
-            n0[j] = buf_load(rd0, off[j]);
-            n1[j] = buf_load(rd1, off[j]);
-            n2[j] = buf_load(rd2, off[j]);
-            if (MASKED_SRC) mvv[j] = buf_load(rm, off[j]);
-          }
-        }
-#pragma unroll
-        for (int j = NCH - 1; j >= 0; j--) {
-          const bool f = sv[k][j] != 0.0f;
-          const unsigned long long bal = __builtin_amdgcn_ballot_w64(f);
-          const int tb = __builtin_popcountll(bal);
-          const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-          if (f) {
-            const int idx = running + (tb - below - 1);
-            const int q = q0 + 64 * j;
-            const int ey = (int)(((unsigned)q * (unsigned)p.rw_magic) >> 20);
-            const int ex = q - ey * p.rw;
-            float s = sv[k][j] * (MODE == 0 ? 0.25f : 0.5f);
-            if (MASKED_SRC) s = s * mvv[j];
-            reinterpret_cast<float4*>(ring_plane)[idx] = make_float4(s, n0[j], n1[j], n2[j]);
-            reinterpret_cast<unsigned*>(ring_plane + (size_t)R * 16)[idx] = (unsigned)ex | ((unsigned)ey << 8);
-          }
-          running += tb;
-        }
-      }
-    };
-
-    // ---- LISTING, one plane, any window: sender plane sz of this tile's region into its ring slot ------------------------
-    auto list_plane = [&](int sz) {
-      const __amdgpu_buffer_rsrc_t rs =
-          __builtin_amdgcn_make_buffer_rsrc((void*)(sal + (i64)sz * plane), 0, plane_bytes, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)((MASKED_SRC ? mask_src : sal) + (i64)sz * plane), 0, plane_bytes, 0x00020000);
-      const int q0 = wave * p.nchunk * 64 + lane;
-      auto voff_of = [&](int q, int& ex, int& ey) -> unsigned {
-        ey = (int)(((unsigned)q * (unsigned)p.rw_magic) >> 20);
-        ex = q - ey * p.rw;
-        const int sx = x0 - h + ex, sy = y0 - h + ey;
-        const bool ok = q < R && sx >= 0 && sx < p.nx && sy >= 0 && sy < p.ny;
-        return ok ? (unsigned)(sy * p.nx + sx) * 4u : OOB;
-      };
-      auto salient = [&](unsigned off) -> float {
-        float s = buf_load(rs, off);
-        if (MASKED_SRC) {
-          if (buf_load(rm, off) == 0.0f) s = 0.0f;
-        }
-        return s;
-      };
-      int cnt = 0;
-#pragma unroll 1
-      for (int j = 0; j < p.nchunk; j++) {
-        int ex, ey;
-        const float s = salient(voff_of(q0 + 64 * j, ex, ey));
-        cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(s != 0.0f));
-      }
-      const int par = (npar++) & 1;
-      if (lane == 0) wave_tot[par][0][wave] = cnt;
-      __syncthreads();
-      int running = 0, total = 0;
-#pragma unroll
-      for (int w = 0; w < NW; w++) {
-        const int t = wave_tot[par][0][w];
-        running += (w > wave) ? t : 0;
-        total += t;
-      }
-      running = __builtin_amdgcn_readfirstlane(running);
-      const int slot = sz % P;
-      unsigned char* const ring_plane = ring + (size_t)slot * plane_stride;
-      if (cnt > 0) {
-        const __amdgpu_buffer_rsrc_t rd0 =
-            __builtin_amdgcn_make_buffer_rsrc((void*)(dir + (i64)sz * plane), 0, plane_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rd1 =
-            __builtin_amdgcn_make_buffer_rsrc((void*)(dir + nvox + (i64)sz * plane), 0, plane_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rd2 =
-            __builtin_amdgcn_make_buffer_rsrc((void*)(dir + 2 * nvox + (i64)sz * plane), 0, plane_bytes, 0x00020000);
-#pragma unroll 1
-        for (int j = p.nchunk - 1; j >= 0; j--) {
-          int ex, ey;
-          const unsigned off = voff_of(q0 + 64 * j, ex, ey);
-          const float s = salient(off);
-          const bool f = s != 0.0f;
-          const unsigned long long bal = __builtin_amdgcn_ballot_w64(f);
-          if (bal == 0ull) continue;   // uniform
-          const int tb = __builtin_popcountll(bal);
-          const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-          if (f) {
-            const int idx = running + (tb - below - 1);
-            float sc = s * (MODE == 0 ? 0.25f : 0.5f);
-            if (MASKED_SRC) sc = sc * buf_load(rm, off);
-            reinterpret_cast<float4*>(ring_plane)[idx] = make_float4(sc, buf_load(rd0, off), buf_load(rd1, off), buf_load(rd2, off));
-            reinterpret_cast<unsigned*>(ring_plane + (size_t)R * 16)[idx] = (unsigned)ex | ((unsigned)ey << 8);
-          }
-          running += tb;
-        }
-      }
-      if (tid == 0) plane_cnt[slot] = total;
     };
 
     float TT[NP][NSUB][6];
@@ -487,26 +305,22 @@ tv_box_kernel(const float* __restrict__ sal, const float* __restrict__ dir, floa
       }
     };
 
-    int cached_lo = 1, cached_hi = 0;
+    // rows of the sender lists this tile reaches: [y0 - h, y0 + TY + h) clipped to the image
+    const int row_lo = max(y0 - h, 0), row_hi = min(y0 + TY - 1 + h, p.ny - 1);
     for (int rz = z_run0; rz < z_run1; rz += 2 * NP) {
       // sender planes that reach the LIVE receivers of this pass (a run may end inside a pass: nothing above the last
       // live receiver + h is needed -- or, in a slab run, complete -- then)
       const int sz_hi = min(min(rz + 2 * NP - 1, z_run1 - 1) + h, p.nz - 1), sz_lo = max(rz - h, 0);
-      if (p.nchunk <= NCH_MAX) {
-        int pend = -1;
-        for (int sz = sz_hi; sz >= sz_lo; sz--) {   // uniform
-          if (!(p.relist || sz < cached_lo || sz > cached_hi)) continue;
-          if (pend < 0) { pend = sz; continue; }
-          list_two(pend, sz);
-          pend = -1;
-        }
-        if (pend >= 0) list_two(pend, -1);
-      } else {
-        for (int sz = sz_hi; sz >= sz_lo; sz--)   // uniform
-          if (p.relist || sz < cached_lo || sz > cached_hi) list_plane(sz);
+      // where this tile's rows start in each of those planes' lists and how many entries they have: the lists are in descending
+      // row order, lst_rows[.. y ..] = index of the first entry of a row < y (see tvl_scan_kernel)
+      __syncthreads();   // every wave is done with the previous pass's ranges (its trailing steps may have had no barrier)
+      if (tid < sz_hi - sz_lo + 1) {
+        const size_t r0 = ((size_t)(sz_lo + tid - p.zl0) * (size_t)(p.ny + 1)) * (size_t)p.tiles_x + (size_t)tile_x;
+        const unsigned beg = lst_rows[r0 + (size_t)(row_hi + 1) * (size_t)p.tiles_x];
+        const unsigned end = lst_rows[r0 + (size_t)row_lo * (size_t)p.tiles_x];
+        plane_beg[sz_lo + tid - (rz - h)] = beg;
+        plane_cnt[sz_lo + tid - (rz - h)] = (int)(end - beg);
       }
-      cached_lo = sz_lo;
-      cached_hi = sz_hi;
 
 #pragma unroll
       for (int pp = 0; pp < NP; pp++)
@@ -514,19 +328,14 @@ tv_box_kernel(const float* __restrict__ sal, const float* __restrict__ dir, floa
         for (int s = 0; s < NSUB; s++)
 #pragma unroll
           for (int k = 0; k < 6; k++) TT[pp][s][k] = 0.0f;
-      __syncthreads();   // ring entries and counts of this pass are visible
+      __syncthreads();   // the list ranges of this pass are visible
       VH_STAMP(0);
 
       // d = 1 .. h+1.  Pair pp (receiver planes z = rz + 2 pp and z + 1): sender planes A = z + d (above: jz = -d for the
       // lower receiver plane, 1-d for the upper one) and B = z + 1 - d (below: jz = d-1 and d).  All of them need the slices
       // S_(d-1) and S_d; the direction of d alternates from pass to pass, so that every step -- the first of a pass
       // included -- finds one of its two slices in LDS already.
-      const int rzs = rz % P;            // ring slot of plane rz; the planes of a pass are within (-P, 2P) of it
-      auto ring_slot = [&](int sz) -> int {
-        int sl = rzs + (sz - rz);
-        sl = sl < 0 ? sl + P : sl;
-        return sl >= P ? sl - P : sl;
-      };
+      auto plane_slot = [&](int sz) -> int { return sz - (rz - h); };   // (only used for planes in [sz_lo, sz_hi])
       for (int step = 0; step <= h; step++) {
         const int d = up ? step + 1 : h + 1 - step;
         int lsz[NLIST], lcnt[NLIST];     // list 2 pp: plane A of pair pp; list 2 pp + 1: its plane B
@@ -537,8 +346,8 @@ tv_box_kernel(const float* __restrict__ sal, const float* __restrict__ dir, floa
           const bool pair_live = z < z_run1;                   // (uniform) a pair beyond the end of the run takes no votes
           lsz[2 * pp] = z + d;
           lsz[2 * pp + 1] = z + 1 - d;
-          lcnt[2 * pp] = (pair_live && lsz[2 * pp] <= sz_hi) ? __builtin_amdgcn_readfirstlane(plane_cnt[ring_slot(lsz[2 * pp])]) : 0;
-          lcnt[2 * pp + 1] = (pair_live && lsz[2 * pp + 1] >= sz_lo) ? __builtin_amdgcn_readfirstlane(plane_cnt[ring_slot(lsz[2 * pp + 1])]) : 0;
+          lcnt[2 * pp] = (pair_live && lsz[2 * pp] <= sz_hi) ? __builtin_amdgcn_readfirstlane(plane_cnt[plane_slot(lsz[2 * pp])]) : 0;
+          lcnt[2 * pp + 1] = (pair_live && lsz[2 * pp + 1] >= sz_lo) ? __builtin_amdgcn_readfirstlane(plane_cnt[plane_slot(lsz[2 * pp + 1])]) : 0;
           cmax = max(cmax, max(lcnt[2 * pp], lcnt[2 * pp + 1]));
         }
         if (cmax == 0) continue;   // uniform
@@ -559,9 +368,9 @@ tv_box_kernel(const float* __restrict__ sal, const float* __restrict__ dir, floa
 #pragma unroll
         for (int k = 0; k < NLIST; k++) pre[k + 1] = pre[k] + lcnt[k];
         const int total = pre[NLIST];
-        int pl[NLIST];                                         // (uniform) ring slot of list k's plane
+        unsigned pl[NLIST];                                    // (uniform) first entry of list k in the global lists
 #pragma unroll
-        for (int k = 0; k < NLIST; k++) pl[k] = ring_slot(lsz[k]);
+        for (int k = 0; k < NLIST; k++) pl[k] = lcnt[k] > 0 ? __builtin_amdgcn_readfirstlane(plane_beg[plane_slot(lsz[k])]) : 0u;
         for (int done = 0; done < total; done += NT) {   // uniform
           // PACKED LISTS: the lists of a step are dealt to the threads as ONE sequence; list k's share of this interval:
           // sequence positions = LDS slots [c[k], c[k] + len[k])
@@ -577,16 +386,15 @@ tv_box_kernel(const float* __restrict__ sal, const float* __restrict__ dir, floa
 #pragma unroll
           for (int k = 1; k < NLIST; k++) k_me += (g >= pre[k]) ? 1 : 0;
           const bool have = g < total;
-          int idx = g, pl_me = pl[0];
+          unsigned idx = pl[0] + (unsigned)g;
 #pragma unroll
           for (int k = 1; k < NLIST; k++)
-            if (k_me == k) { idx = g - pre[k]; pl_me = pl[k]; }
-          const unsigned char* ring_plane = ring + (size_t)pl_me * plane_stride;
+            if (k_me == k) idx = pl[k] + (unsigned)(g - pre[k]);
           float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
           unsigned m = 0u;
           if (have) {
-            a = reinterpret_cast<const float4*>(ring_plane)[idx];
-            m = reinterpret_cast<const unsigned*>(ring_plane + (size_t)R * 16)[idx];
+            a = lst_ent[idx];
+            m = lst_pos[idx];
           }
           if (done == 0) {
 #pragma unroll
@@ -599,9 +407,10 @@ tv_box_kernel(const float* __restrict__ sal, const float* __restrict__ dir, floa
               else for (int i = tid; i < nsl; i += NT) dst4[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
           }
-          if (have) {
+          if (have) {   // list entries carry {column within the tile column's window, image row}: the region row here
             l_ent[tid] = a;
-            l_pos[tid] = make_uint2(m, 16u * (((m >> 8) & 0xffu) * (unsigned)SP + (m & 0xffu)));
+            const unsigned ex = m & 0xffu, ey = (m >> 8) - (unsigned)(y0 - h);
+            l_pos[tid] = make_uint2(ex | (ey << 8), 16u * (ey * (unsigned)SP + ex));
           }
           VH_STAMP(1);
           __syncthreads();   // lists (and slices) complete
@@ -694,6 +503,101 @@ tv_box_kernel(const float* __restrict__ sal, const float* __restrict__ dir, floa
 #endif
 }
 
+// ---- THE SENDER LISTS, once per launch ---------------------------------------------------------------------------------
+// For every listed plane z and every tile column tx (8 receiver columns), the salient, unmasked senders of the columns
+// [8 tx - h, 8 tx + 8 + h) -- everything a tile of that column can reach in x -- as one list in DESCENDING (y, x) (the order
+// the vote kernel's row-range culling needs), 20 bytes per entry: float4 {saliency * 1/4 or 1/2 (* mask value), normal} and one
+// word {x - (8 tx - h), y << 8}.  A sender appears in the lists of the (up to 1 + 2h/8 + 1) tile columns that reach it.
+// rows[(zl (ny + 1) + y) ntx + tx]: index (into the global entry arrays) of the first entry of list (zl, tx) with a row
+// below y -- so the entries of the rows [ylo, yhi] are [rows[.. yhi + 1 ..], rows[.. ylo ..]).
+// Three kernels: count per (plane, row, tile column); suffix sums per (plane, tile column) with one atomic add per list for
+// its place in the global arrays; write.  A workgroup takes one image row: its salient flags as a bit mask in LDS, every
+// window's count / every sender's place in its windows by popcounts over at most four words.
+struct ListGeo {
+  int nx, ny, nz;
+  int zl0, nzl;   // listed planes [zl0, zl0 + nzl)
+  int ntx, h;
+};
+constexpr int LNT = 256;
+constexpr int LWORDS_MAX = 2048;   // nx <= 65536
+
+__device__ __forceinline__ unsigned popc_range(const unsigned* w, int lo, int hi) {   // set bits of [lo, hi), hi - lo <= 96
+  unsigned c = 0;
+  for (int i = lo >> 5; i <= (hi - 1) >> 5 && lo < hi; i++) {
+    unsigned m = w[i];
+    if (i == (lo >> 5)) m &= ~0u << (lo & 31);
+    if (i == ((hi - 1) >> 5) && (hi & 31)) m &= ~0u >> (32 - (hi & 31));
+    c += (unsigned)__builtin_popcount(m);
+  }
+  return c;
+}
+
+template <bool WRITE, int MODE>
+__global__ void __launch_bounds__(LNT)
+tvl_row_kernel(const float* __restrict__ sal, const float* __restrict__ dir, const float* __restrict__ mask_src, ListGeo g,
+               unsigned* __restrict__ rows, float4* __restrict__ ent, unsigned* __restrict__ pos) {
+  __shared__ unsigned bits[LWORDS_MAX + 4];
+  const int y = blockIdx.x % g.ny, zl = blockIdx.x / g.ny;
+  const i64 plane = (i64)g.nx * g.ny, nvox = plane * g.nz;
+  const i64 row = (i64)(g.zl0 + zl) * plane + (i64)y * g.nx;
+  const int nwords = (g.nx + 31) >> 5;
+  const int lane = threadIdx.x & 63;
+  for (int x0 = 0; x0 < ((g.nx + LNT - 1) / LNT) * LNT; x0 += LNT) {   // uniform
+    const int x = x0 + (int)threadIdx.x;
+    bool f = false;
+    if (x < g.nx) f = sal[row + x] != 0.0f && !(mask_src && mask_src[row + x] == 0.0f);
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(f);
+    if (lane == 0 && (x >> 5) < nwords + 2) { bits[x >> 5] = (unsigned)bal; bits[(x >> 5) + 1] = (unsigned)(bal >> 32); }
+  }
+  __syncthreads();
+  unsigned* const rrow = rows + ((size_t)zl * (size_t)(g.ny + 1) + (size_t)y) * (size_t)g.ntx;
+  if (!WRITE) {
+    for (int tx = threadIdx.x; tx < g.ntx; tx += LNT) rrow[tx] = popc_range(bits, max(8 * tx - g.h, 0), min(8 * tx + 8 + g.h, g.nx));
+    return;
+  }
+  for (int x = threadIdx.x; x < g.nx; x += LNT) {
+    if (!((bits[x >> 5] >> (x & 31)) & 1u)) continue;
+    float s = sal[row + x] * (MODE == 0 ? 0.25f : 0.5f);
+    if (mask_src) s = s * mask_src[row + x];
+    const float4 e = make_float4(s, dir[row + x], dir[nvox + row + x], dir[2 * nvox + row + x]);
+    // tile columns whose window holds x: 8 tx - h <= x < 8 tx + 8 + h
+    const int t0 = max((x - 8 - g.h) / 8 + ((x - 8 - g.h) >= 0 ? 1 : 0), 0);
+    const int t1 = min((x + g.h) / 8, g.ntx - 1);
+    for (int tx = t0; tx <= t1; tx++) {
+      const int lo = 8 * tx - g.h, hi = min(8 * tx + 8 + g.h, g.nx);
+      if (x < lo || x >= hi) continue;
+      // rows[.. y + 1 ..] = first entry of the rows below y + 1 = first entry of row y; within the row: descending x
+      const unsigned idx = rrow[g.ntx + tx] + popc_range(bits, x + 1, hi);
+      ent[idx] = e;
+      pos[idx] = (unsigned)(x - lo) | ((unsigned)y << 8);
+    }
+  }
+}
+
+// one thread per list (zl, tx): counts -> offsets.  Before: rows[zl][y][tx] = entries of row y (y < ny).  After:
+// rows[zl][y][tx] = base + (entries of the rows >= y): the index behind row y's last entry... see the header comment; the
+// list's place `base` in the global arrays comes from one atomic add (the lists' order in memory does not matter).
+__global__ void __launch_bounds__(LNT)
+tvl_scan_kernel(ListGeo g, unsigned* __restrict__ rows, unsigned long long* __restrict__ total) {
+  const int i = blockIdx.x * LNT + threadIdx.x;
+  if (i >= g.nzl * g.ntx) return;
+  const int zl = i / g.ntx, tx = i - zl * g.ntx;
+  unsigned* const col = rows + (size_t)zl * (size_t)(g.ny + 1) * (size_t)g.ntx + tx;
+  unsigned sum = 0;
+  for (int y = 0; y < g.ny; y++) sum += col[(size_t)y * g.ntx];
+  const unsigned base = (unsigned)atomicAdd(total, (unsigned long long)sum);
+  // descending rows: the entries of row y sit behind those of every row above it
+  unsigned run = base;
+  unsigned prev = col[(size_t)(g.ny - 1) * g.ntx];
+  col[(size_t)g.ny * g.ntx] = run;            // rows below ny: the list's first entry
+  for (int y = g.ny - 1; y >= 0; y--) {
+    const unsigned c = prev;
+    if (y > 0) prev = col[(size_t)(y - 1) * g.ntx];
+    run += c;
+    col[(size_t)y * g.ntx] = run;              // first entry of a row below y = behind row y's entries
+  }
+}
+
 // Test aid (context option tv_poison): fills every CU's LDS with NaN bit patterns before the voting kernel runs, so that a
 // vote that uses LDS (or ring memory, or an output voxel) the kernel has not written shows up as NaN on every box -- not
 // only on one whose previous tenant happened to leave such bits behind.
@@ -714,8 +618,7 @@ int dev_tv_box(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* te
   *handled = false;
   if (exponent != 2 && exponent != 4) return VISFD_HIP_OK;
   if (h < 1 || h > 40) return VISFD_HIP_OK;
-  if (nx * ny >= (1LL << 29)) return VISFD_HIP_OK;
-  const int n = 2 * h + 1;
+  if (nx * ny >= (1LL << 29) || nx > 32 * LWORDS_MAX || ny >= (1 << 24)) return VISFD_HIP_OK;
   hipStream_t st = ctx->stream;
   BoxParams p;
   p.nx = (int)nx; p.ny = (int)ny; p.nz = (int)nz;
@@ -723,18 +626,12 @@ int dev_tv_box(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* te
   p.h = h;
   p.rw = TX + 2 * h;
   p.rh = TY + 2 * h;
-  const int R = p.rw * p.rh;
-  p.nchunk = (R + NT - 1) / NT;
-  p.rw_magic = ((1 << 20) + p.rw - 1) / p.rw;
-  for (int q = 0; q < p.nchunk * NT; q++)
-    if ((int)(((unsigned)q * (unsigned)p.rw_magic) >> 20) != q / p.rw) return fail(VISFD_HIP_EINVAL, "tv_box: region index division");
-  if (p.rw > 255 || p.rh > 255) return VISFD_HIP_OK;   // region positions travel as bytes
+  if (p.rw > 255 || p.rh > 255) return VISFD_HIP_OK;   // window columns and region rows travel as bytes
   p.sp = tv_box_row(h);
   p.nsl = tv_box_slice(h);
   const size_t slice_bytes = sizeof(float4) * (size_t)p.nsl;
   p.tiles_x = (int)((nx + TX - 1) / TX);
   p.tiles_y = (int)((ny + TY - 1) / TY);
-  p.relist = ctx->opt.tv_no_replay ? 1 : 0;
   p.zrun = 32;
   if (ctx->opt.tv_zrun >= 1 && ctx->opt.tv_zrun <= 4096) p.zrun = ctx->opt.tv_zrun;
   if ((i64)p.zrun > z_out1 - z_out0) p.zrun = (int)(z_out1 - z_out0);
@@ -744,11 +641,46 @@ int dev_tv_box(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* te
   if (nblk > 0x7fffffffLL) return fail(VISFD_HIP_EINVAL, "volume too large for one launch");
   if (nblk <= 0) { *handled = true; return VISFD_HIP_OK; }
   const size_t lds = 2 * slice_bytes;
-  const size_t lds_static = sizeof(float4) * (LSLOTS + 1) + sizeof(uint2) * LSLOTS + sizeof(uint2) * NW * NSUB * 2 * HCAP + 1024;
+  const size_t lds_static = sizeof(float4) * (LSLOTS + 1) + sizeof(uint2) * LSLOTS + sizeof(uint2) * NW * NSUB * 2 * HCAP + 1536;
   if (lds + lds_static > 150 * 1024) return VISFD_HIP_OK;   // window too wide: the caller falls back
+
+  // ---- the sender lists of the planes the receiver planes [z_out0, z_out1) reach -------------------------------------------
+  ListGeo g;
+  g.nx = p.nx; g.ny = p.ny; g.nz = p.nz; g.h = h; g.ntx = p.tiles_x;
+  g.zl0 = (int)std::max<i64>(z_out0 - h, 0);
+  g.nzl = (int)(std::min<i64>(z_out1 + h, nz) - g.zl0);
+  p.zl0 = g.zl0; p.nzl = g.nzl;
+  const size_t nrows = (size_t)g.nzl * (size_t)(ny + 1) * (size_t)g.ntx;
+  if ((i64)g.nzl * ny > 0x7fffffffLL) return VISFD_HIP_OK;
+  unsigned* rows = nullptr;
   unsigned* counter = nullptr;
   VH_TRY(ws(ctx, WS_COUNTER, 16, &counter));
-  VH_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned), st));
+  if (ws(ctx, WS_TVLIST, nrows, &rows) != VISFD_HIP_OK) { set_error(""); (void)hipGetLastError(); return VISFD_HIP_OK; }
+  unsigned long long* total_dev = reinterpret_cast<unsigned long long*>(counter + 4);
+  VH_HIP(hipMemsetAsync(counter, 0, 16 * sizeof(unsigned), st));
+  const unsigned row_blocks = (unsigned)((i64)g.nzl * ny);
+#define VH_TVL_ROWS(WR, ENT, POS)                                                                                         \
+  do {                                                                                                                    \
+    if (exponent == 4) tvl_row_kernel<WR, 0><<<dim3(row_blocks), dim3(LNT), 0, st>>>(sal, dir, mask_src, g, rows, ENT, POS); \
+    else tvl_row_kernel<WR, 2><<<dim3(row_blocks), dim3(LNT), 0, st>>>(sal, dir, mask_src, g, rows, ENT, POS);             \
+  } while (0)
+  VH_TVL_ROWS(false, nullptr, nullptr);
+  tvl_scan_kernel<<<dim3((unsigned)(((size_t)g.nzl * g.ntx + LNT - 1) / LNT)), dim3(LNT), 0, st>>>(g, rows, total_dev);
+  VH_HIP(hipGetLastError());
+  // the lists' total length decides the size of the entry arrays: the one place this launch waits for the device
+  unsigned long long total = 0;
+  VH_HIP(hipMemcpyAsync(&total, total_dev, sizeof(total), hipMemcpyDeviceToHost, st));
+  VH_HIP(hipStreamSynchronize(st));
+  if (total >= (1ull << 32) - 2048) return VISFD_HIP_OK;   // 32-bit entry indices: the caller falls back
+  unsigned char* lists = nullptr;
+  if (ws(ctx, WS_TVSCRATCH, (size_t)(total + 16) * 20, &lists) != VISFD_HIP_OK) { set_error(""); (void)hipGetLastError(); return VISFD_HIP_OK; }
+  float4* const lst_ent = reinterpret_cast<float4*>(lists);
+  unsigned* const lst_pos = reinterpret_cast<unsigned*>(lists + (size_t)(total + 16) * 16);
+  if (ctx->opt.tv_poison) VH_HIP(hipMemsetAsync(lists, 0xff, (size_t)(total + 16) * 20, st));
+  VH_TVL_ROWS(true, lst_ent, lst_pos);
+#undef VH_TVL_ROWS
+  VH_HIP(hipGetLastError());
+
   size_t wg_per_cu = (160 * 1024) / (lds + lds_static);
   if (wg_per_cu > 3) wg_per_cu = 3;   // 6 waves per SIMD (80 VGPRs)
   if (wg_per_cu < 1) wg_per_cu = 1;
@@ -758,32 +690,19 @@ int dev_tv_box(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* te
   if (ctx->opt.tv_reserve_wg > 0) ngrid = std::max<i64>(ngrid - ctx->opt.tv_reserve_wg, 1);
   if (ctx->opt.tv_max_wg > 0 && ngrid > ctx->opt.tv_max_wg) ngrid = ctx->opt.tv_max_wg;
   if (ngrid > nblk) ngrid = nblk;
-  unsigned char* scratch = nullptr;
-  const size_t per_wg = (size_t)(n + 2 * NP - 1) * R * 20;
-  if ((size_t)ngrid * per_wg > ((size_t)16 << 30)) ngrid = (i64)(((size_t)16 << 30) / per_wg);
-  for (; ngrid >= 1; ngrid /= 2) {
-    if (ws(ctx, WS_TVSCRATCH, per_wg * (size_t)ngrid, &scratch) == VISFD_HIP_OK) break;
-    scratch = nullptr;
-    set_error("");
-    (void)hipGetLastError();
-  }
-  if (!scratch) return VISFD_HIP_OK;
   if (ctx->opt.tv_poison) {   // tests: everything the kernel may read without having written it becomes NaN
-    VH_HIP(hipMemsetAsync(scratch, 0xff, per_wg * (size_t)ngrid, st));
     VH_HIP(hipMemsetAsync(ten, 0xff, sizeof(float) * 6 * (size_t)(nx * ny * nz), st));
     VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_poison_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    lds_poison_kernel<<<dim3(1024), dim3(256), 160 * 1024, st>>>(counter + 2);
+    lds_poison_kernel<<<dim3(1024), dim3(256), 160 * 1024, st>>>(counter + 8);
   }
-#define VH_BOX_LAUNCH(MSK, MD)                                                                        \
-  do {                                                                                               \
-    VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tv_box_kernel<MSK, MD>),               \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
-    tv_box_kernel<MSK, MD><<<dim3((unsigned)ngrid), dim3(NT), lds, st>>>(sal, dir, ten, mask_src,     \
-                                                                        mask_dst, dtab_box, p, counter, \
-                                                                        (unsigned)nblk, scratch);    \
+#define VH_BOX_LAUNCH(MD)                                                                                              \
+  do {                                                                                                                 \
+    VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tv_box_kernel<MD>),                                      \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                 \
+    tv_box_kernel<MD><<<dim3((unsigned)ngrid), dim3(NT), lds, st>>>(ten, mask_dst, dtab_box, p, counter, (unsigned)nblk, \
+                                                                   lst_ent, lst_pos, rows);                            \
   } while (0)
-  if (mask_src) { if (exponent == 4) VH_BOX_LAUNCH(true, 0); else VH_BOX_LAUNCH(true, 2); }
-  else          { if (exponent == 4) VH_BOX_LAUNCH(false, 0); else VH_BOX_LAUNCH(false, 2); }
+  if (exponent == 4) VH_BOX_LAUNCH(0); else VH_BOX_LAUNCH(2);
 #undef VH_BOX_LAUNCH
   VH_HIP(hipGetLastError());
 #ifdef VH_TV_COUNT

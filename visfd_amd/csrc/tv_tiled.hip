@@ -55,7 +55,6 @@ constexpr int CAP = 256;             // list entries held in LDS per sweep and l
 // takes its votes in the reference's order; only the interleaving of DIFFERENT receivers' sums changes.
 constexpr int NP = 2;
 static_assert(NP * CAP <= NT, "the replay loads one entry per thread");
-constexpr int LST = CAP + 8;         // l_pos entries per list (8 never-hit entries of slack behind each list)
 // PACKED LISTS (round 3): the lists of a step share the NT entry slots of LDS -- their entries are dealt to the
 // threads as ONE sequence, each list's share of an interval lands contiguously (an even start, 8 never-hit entries of slack
 // behind it), and an interval ends when NT entries are in, not when the longest list has had CAP.  Every list is still swept
