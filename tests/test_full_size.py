@@ -99,7 +99,7 @@ def _check_membrane(gpu, oracle, src, crops, E, dense=0.12, ridge_crops=4, tv_fm
         got_c = np.ascontiguousarray(np.stack([_crop(ten[k], c0, c0 + E) for k in range(6)], axis=-1))
         assert np.abs(want_c).max() > 0
         if tv_fma:   # tolerance mode: 1e-5 of the crop's own scale (stricter than the field's)
-            assert_close_rel(got_c, want_c, 1e-5, "tolerance-mode vote tensor in the crop at %s" % ((z0, y0, x0),), pervoxel=0.005)
+            assert_close_rel(got_c, want_c, 1e-5, "tolerance-mode vote tensor in the crop at %s" % ((z0, y0, x0),), pervoxel=0.02)
             assert not np.array_equal(got_c.view(np.uint32), want_c.view(np.uint32)), "the tolerance kernel did not run"
         else:
             assert_bits_equal(got_c, want_c, "vote tensor in the crop at %s" % ((z0, y0, x0),))

@@ -396,15 +396,36 @@ tv_box_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
             a = lst_ent[idx];
             m = lst_pos[idx];
           }
+          // the new slice(s) of this step: every load is requested BEFORE the first LDS store waits for one (entries and slice
+          // share one round trip; a copy loop that loads and stores element by element is three)
+          const int ft = wave * 64 + (int)fresh_lane();     // (this thread's index again: addresses hoisted out of the step loop are spilled)
+          const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          float4 s00 = z4, s01 = z4, s10 = z4, s11 = z4;
+          const bool ld0 = done == 0 && need[0] >= 0 && need[0] <= h, ld1 = done == 0 && need[1] >= 0 && need[1] <= h;   // uniform
+          if (ld0) {
+            const float4* src4 = table + (i64)(need[0] + h) * nsl;
+            if (ft < nsl) s00 = src4[ft];
+            if (ft + NT < nsl) s01 = src4[ft + NT];
+          }
+          if (ld1) {
+            const float4* src4 = table + (i64)(need[1] + h) * nsl;
+            if (ft < nsl) s10 = src4[ft];
+            if (ft + NT < nsl) s11 = src4[ft + NT];
+          }
           if (done == 0) {
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-              if (need[k] < 0) continue;   // uniform
-              const int j = need[k];
-              const float4* src4 = table + (i64)(j + h) * nsl;
-              float4* dst4 = sl4 + (j & 1) * nsl;
-              if (j <= h) for (int i = tid; i < nsl; i += NT) dst4[i] = src4[i];
-              else for (int i = tid; i < nsl; i += NT) dst4[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (need[0] >= 0) {   // uniform; slice h + 1 is zeros (s00, s01 still are)
+              float4* dst4 = sl4 + (need[0] & 1) * nsl;
+              if (ft < nsl) dst4[ft] = s00;
+              if (ft + NT < nsl) dst4[ft + NT] = s01;
+              const float4* src4 = table + (i64)(need[0] + h) * nsl;
+              for (int i = ft + 2 * NT; i < nsl; i += NT) dst4[i] = ld0 ? src4[i] : z4;   // (windows wider than h = 12)
+            }
+            if (need[1] >= 0) {
+              float4* dst4 = sl4 + (need[1] & 1) * nsl;
+              if (ft < nsl) dst4[ft] = s10;
+              if (ft + NT < nsl) dst4[ft + NT] = s11;
+              const float4* src4 = table + (i64)(need[1] + h) * nsl;
+              for (int i = ft + 2 * NT; i < nsl; i += NT) dst4[i] = ld1 ? src4[i] : z4;
             }
           }
           if (have) {   // list entries carry {column within the tile column's window, image row}: the region row here
