@@ -532,7 +532,7 @@ tv_box_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
 // rows[(zl (ny + 1) + y) ntx + tx]: index (into the global entry arrays) of the first entry of list (zl, tx) with a row
 // below y -- so the entries of the rows [ylo, yhi] are [rows[.. yhi + 1 ..], rows[.. ylo ..]).
 // Three kernels: count per (plane, row, tile column); suffix sums per (plane, tile column) with one atomic add per list for
-// its place in the global arrays; write.  A workgroup takes one image row: its salient flags as a bit mask in LDS, every
+// its place in the global arrays; write.  A WAVE takes one image row: its salient flags as a bit mask in LDS, every
 // window's count / every sender's place in its windows by popcounts over at most four words.
 struct ListGeo {
   int nx, ny, nz;
@@ -540,7 +540,7 @@ struct ListGeo {
   int ntx, h;
 };
 constexpr int LNT = 256;
-constexpr int LWORDS_MAX = 2048;   // nx <= 65536
+constexpr int LWORDS_MAX = 512;    // nx <= 16384
 
 __device__ __forceinline__ unsigned popc_range(const unsigned* w, int lo, int hi) {   // set bits of [lo, hi), hi - lo <= 96
   unsigned c = 0;
@@ -557,26 +557,38 @@ template <bool WRITE, int MODE>
 __global__ void __launch_bounds__(LNT)
 tvl_row_kernel(const float* __restrict__ sal, const float* __restrict__ dir, const float* __restrict__ mask_src, ListGeo g,
                unsigned* __restrict__ rows, float4* __restrict__ ent, unsigned* __restrict__ pos) {
-  __shared__ unsigned bits[LWORDS_MAX + 4];
-  const int y = blockIdx.x % g.ny, zl = blockIdx.x / g.ny;
+  // ONE WAVE PER IMAGE ROW (no workgroup barrier: a wave's bit mask is its own): its salient flags as a bit mask in LDS,
+  // 64 voxels per ballot
+  __shared__ unsigned bits_all[LNT / 64][LWORDS_MAX + 4];
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const i64 r = (i64)blockIdx.x * (LNT / 64) + wave;      // row number among the listed rows
+  if (r >= (i64)g.nzl * g.ny) return;                      // (uniform per wave)
+  unsigned* const bits = bits_all[wave];
+  const int y = (int)(r % g.ny), zl = (int)(r / g.ny);
   const i64 plane = (i64)g.nx * g.ny, nvox = plane * g.nz;
   const i64 row = (i64)(g.zl0 + zl) * plane + (i64)y * g.nx;
-  const int nwords = (g.nx + 31) >> 5;
-  const int lane = threadIdx.x & 63;
-  for (int x0 = 0; x0 < ((g.nx + LNT - 1) / LNT) * LNT; x0 += LNT) {   // uniform
-    const int x = x0 + (int)threadIdx.x;
+  const int nchunks = (g.nx + 63) >> 6;
+  unsigned any = 0;
+  for (int c = 0; c < nchunks; c++) {   // uniform
+    const int x = 64 * c + lane;
     bool f = false;
     if (x < g.nx) f = sal[row + x] != 0.0f && !(mask_src && mask_src[row + x] == 0.0f);
     const unsigned long long bal = __builtin_amdgcn_ballot_w64(f);
-    if (lane == 0 && (x >> 5) < nwords + 2) { bits[x >> 5] = (unsigned)bal; bits[(x >> 5) + 1] = (unsigned)(bal >> 32); }
+    if (lane == 0) { bits[2 * c] = (unsigned)bal; bits[2 * c + 1] = (unsigned)(bal >> 32); }
+    any |= (unsigned)bal | (unsigned)(bal >> 32);
   }
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   unsigned* const rrow = rows + ((size_t)zl * (size_t)(g.ny + 1) + (size_t)y) * (size_t)g.ntx;
   if (!WRITE) {
-    for (int tx = threadIdx.x; tx < g.ntx; tx += LNT) rrow[tx] = popc_range(bits, max(8 * tx - g.h, 0), min(8 * tx + 8 + g.h, g.nx));
+    for (int tx = lane; tx < g.ntx; tx += 64)
+      rrow[tx] = any ? popc_range(bits, max(8 * tx - g.h, 0), min(8 * tx + 8 + g.h, g.nx)) : 0u;
     return;
   }
-  for (int x = threadIdx.x; x < g.nx; x += LNT) {
+  if (!any) return;   // (uniform)
+  for (int c = 0; c < nchunks; c++) {   // uniform
+    if ((bits[2 * c] | bits[2 * c + 1]) == 0u) continue;   // uniform
+    const int x = 64 * c + lane;
     if (!((bits[x >> 5] >> (x & 31)) & 1u)) continue;
     float s = sal[row + x] * (MODE == 0 ? 0.25f : 0.5f);
     if (mask_src) s = s * mask_src[row + x];
@@ -679,7 +691,7 @@ int dev_tv_box(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* te
   if (ws(ctx, WS_TVLIST, nrows, &rows) != VISFD_HIP_OK) { set_error(""); (void)hipGetLastError(); return VISFD_HIP_OK; }
   unsigned long long* total_dev = reinterpret_cast<unsigned long long*>(counter + 4);
   VH_HIP(hipMemsetAsync(counter, 0, 16 * sizeof(unsigned), st));
-  const unsigned row_blocks = (unsigned)((i64)g.nzl * ny);
+  const unsigned row_blocks = (unsigned)(((i64)g.nzl * ny + LNT / 64 - 1) / (LNT / 64));
 #define VH_TVL_ROWS(WR, ENT, POS)                                                                                         \
   do {                                                                                                                    \
     if (exponent == 4) tvl_row_kernel<WR, 0><<<dim3(row_blocks), dim3(LNT), 0, st>>>(sal, dir, mask_src, g, rows, ENT, POS); \
