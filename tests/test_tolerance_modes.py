@@ -46,7 +46,7 @@ def test_tv_fma_seeded_goldens(ctx, tag):
     g = golden("membrane_seeded")
     m = volgen.block_mask(volgen.MEM_SHAPE, seed=302) if tag == "mask" else None
     sal, dirs = g[tag + "_salthr"], g[tag + "_dir"]
-    for opts in ({}, {"tv_max_wg": 3}, {"tv_max_wg": 1, "tv_zrun": 3}, {"tv_no_replay": 1}):
+    for opts in ({}, {"tv_max_wg": 3}, {"tv_max_wg": 1, "tv_zrun": 3}, {"tv_no_fold": 1}):
         with ctx.options(tv_fma=1, tv_poison=1, **opts):
             for ex in (4, 2):
                 ten = ctx.tv_dense_stick(sal, dirs, volgen.MEM_TV_SIGMA, ex, 2.0 ** 0.5, m, m)
@@ -72,7 +72,7 @@ def test_tv_fma_windows(ctx, oracle, sigma_tv, shape):
     ref = oracle.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5)
     ref_m = oracle.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5, mask, mask)
     ref2 = oracle.tv_dense_stick(sal, dirs, sigma_tv, 2, 2.0 ** 0.5)
-    for opts in ({}, {"tv_max_wg": 3}, {"tv_max_wg": 1}, {"tv_max_wg": 2, "tv_zrun": 4}, {"tv_max_wg": 2, "tv_no_replay": 1},
+    for opts in ({}, {"tv_max_wg": 3}, {"tv_max_wg": 1}, {"tv_max_wg": 2, "tv_zrun": 4}, {"tv_max_wg": 2, "tv_no_fold": 1},
                  {"tv_zrun": 1}, {"tv_zrun": 5}):
         with ctx.options(tv_fma=1, tv_poison=1, **opts):
             assert_close_rel(ctx.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5), ref, TOL, "fma tensor %g %s" % (sigma_tv, opts), pervoxel=PV)

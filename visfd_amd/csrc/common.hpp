@@ -70,6 +70,7 @@ struct visfd_hip_options {
                             //    eigenvalues and scores move by ~1 float ulp (eigen3.hpp); 0: the reference's double-precision angle
   int tv_zrun = 0;          // receiver planes per unit of work (0: default)
   int tv_no_replay = 0;     // 1: list every sender plane again for every receiver plane (nothing reused from the rings)
+  int tv_no_fold = 0;       // tests: tolerance-mode voting never folds the saliency into the listed normals (tv_box.hip: vote_fma)
   int tv_poison = 0;        // tests: NaN bit patterns in LDS, ring memory and the output before tensor voting runs (tv_box.hip)
   int tv_reserve_wg = 0;    // workgroup slots the persistent voting grid leaves free (slab runs: the halo transport's kernels)
   int tv_max_wg = 0;        // cap on the persistent grid (0: fill the chip); tests use it to make workgroups claim many units

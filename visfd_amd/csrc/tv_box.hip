@@ -96,15 +96,21 @@ __device__ __forceinline__ void fmacc(float& t, float a, float b) {
 // and 2 - t^2 = 2 (1 - u^2); the factor 1/2 (exponent 2) or 1/4 (exponent 4) the decay then lacks is applied to the sender's
 // saliency when it is listed (an exact scaling), as is the sender's mask value.  ZNEG: the slice in LDS is the one of -jz:
 // rhat_z has the opposite sign.
-template <int MODE, bool ZNEG>
-__device__ __forceinline__ void vote_fma(float (&T)[6], const f4v& snd /* sal, n */, const f4v& tw /* w, R */) {
+//
+// FOLD (every listed saliency is positive -- the usual case: the ridge score is a square): the saliency is folded into the
+// listed normal, n' = a n with a^6 = s (exponent 4; a^4 = s for exponent 2), and the record carries c = 2 a^2 in the
+// saliency's place: t' = R.n' = a t, q' = c - t'^2 = a^2 q, m' = t' R - n' = a m, so that w q'^2 m' m'^T = s w q^2 m m^T
+// without the multiplication by the saliency: 18 instructions.  (Round 3 measured no gain from this form -- that kernel was
+// bound by the latency of a vote's LDS reads; this one issues vector instructions 75 % of the time.)
+template <int MODE, bool ZNEG, bool FOLD>
+__device__ __forceinline__ void vote_fma(float (&T)[6], const f4v& snd /* sal, n  or  c, n' */, const f4v& tw /* w, R */) {
   const float Rz = ZNEG ? -tw.w : tw.w;    // (a source modifier of the instructions below)
   const float t = __builtin_fmaf(Rz, snd.w, __builtin_fmaf(tw.z, snd.z, tw.y * snd.y));
-  const float q = __builtin_fmaf(-t, t, 2.0f);
+  const float q = __builtin_fmaf(-t, t, FOLD ? snd.x : 2.0f);
   const float m0 = __builtin_fmaf(t, tw.y, -snd.y);
   const float m1 = __builtin_fmaf(t, tw.z, -snd.z);
   const float m2 = __builtin_fmaf(t, Rz, -snd.w);
-  const float sw = snd.x * tw.x;
+  const float sw = FOLD ? tw.x : snd.x * tw.x;
   const float bse = (MODE == 0) ? (sw * q) * q : sw * q;
   const float b0 = bse * m0, b1 = bse * m1, b2 = bse * m2;
   fmacc(T[0], b0, m0);
@@ -135,7 +141,7 @@ __device__ __forceinline__ uint2 lds_u2(unsigned a) {
 // of the votes.
 __device__ __forceinline__ u4v lds_u4(unsigned a) { return *(const volatile __attribute__((address_space(3))) u4v*)(uintptr_t)a; }
 
-template <int MODE, bool ZNEG, int OFF>
+template <int MODE, bool ZNEG, bool FOLD, int OFF>
 __device__ __forceinline__ void vote_hits(float (&T)[6], unsigned hp, int nst, unsigned r16) {
   u4v h0 = lds_u4(hp + (unsigned)OFF), h1 = lds_u4(hp + (unsigned)(OFF + 16));
   f4v sa = lds_f4(h0.x), ta = lds_f4(r16 - h0.y);
@@ -144,27 +150,27 @@ __device__ __forceinline__ void vote_hits(float (&T)[6], unsigned hp, int nst, u
   for (;;) {   // uniform
     sb = lds_f4(h0.z);
     tb = lds_f4(r16 - h0.w);
-    vote_fma<MODE, ZNEG>(T, sa, ta);
+    vote_fma<MODE, ZNEG, FOLD>(T, sa, ta);
     if (++k >= nst) break;
     sa = lds_f4(h1.x);
     ta = lds_f4(r16 - h1.y);
     h0 = lds_u4(hp + (unsigned)(OFF + 32));
-    vote_fma<MODE, ZNEG>(T, sb, tb);
+    vote_fma<MODE, ZNEG, FOLD>(T, sb, tb);
     if (++k >= nst) break;
     sb = lds_f4(h1.z);
     tb = lds_f4(r16 - h1.w);
-    vote_fma<MODE, ZNEG>(T, sa, ta);
+    vote_fma<MODE, ZNEG, FOLD>(T, sa, ta);
     if (++k >= nst) break;
     sa = lds_f4(h0.x);
     ta = lds_f4(r16 - h0.y);
     h1 = lds_u4(hp + (unsigned)(OFF + 48));
     hp += 32u;
-    vote_fma<MODE, ZNEG>(T, sb, tb);
+    vote_fma<MODE, ZNEG, FOLD>(T, sb, tb);
     if (++k >= nst) break;
   }
 }
 
-template <int MODE>
+template <int MODE, bool FOLD>
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6)))
 tv_box_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
               const float4* __restrict__ table /* [2h+1] slices of nsl entries: w, sqrt(2) rhat at j, zero padding */,
@@ -297,8 +303,8 @@ tv_box_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
         asm volatile("" ::: "memory");
         const unsigned hp = hb + (fresh_lane() >> 5) * (unsigned)(HCAP * 8);
         __builtin_amdgcn_s_setprio(1);   // a voting wave is on its workgroup's critical path; waves that list or fill are not (337 -> 333 ms)
-        if (nh[0] > 0) vote_hits<MODE, ZNEG, 0>(TT[pp][0], hp, (nh[0] + 1) >> 1, r16);              // (uniform)
-        if (nh[1] > 0) vote_hits<MODE, ZNEG, 2 * HCAP * 8>(TT[pp][1], hp, (nh[1] + 1) >> 1, r16);
+        if (nh[0] > 0) vote_hits<MODE, ZNEG, FOLD, 0>(TT[pp][0], hp, (nh[0] + 1) >> 1, r16);              // (uniform)
+        if (nh[1] > 0) vote_hits<MODE, ZNEG, FOLD, 2 * HCAP * 8>(TT[pp][1], hp, (nh[1] + 1) >> 1, r16);
         __builtin_amdgcn_s_setprio(0);
         asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
@@ -556,7 +562,9 @@ __device__ __forceinline__ unsigned popc_range(const unsigned* w, int lo, int hi
 template <bool WRITE, int MODE>
 __global__ void __launch_bounds__(LNT)
 tvl_row_kernel(const float* __restrict__ sal, const float* __restrict__ dir, const float* __restrict__ mask_src, ListGeo g,
-               unsigned* __restrict__ rows, float4* __restrict__ ent, unsigned* __restrict__ pos) {
+               unsigned* __restrict__ rows, float4* __restrict__ ent, unsigned* __restrict__ pos,
+               unsigned* __restrict__ neg_flag /* count pass: set if a listed saliency (times its mask value) is not positive */,
+               int fold /* write pass: records {c, a n} instead of {s, n} (vote_fma) */) {
   // ONE WAVE PER IMAGE ROW (no workgroup barrier: a wave's bit mask is its own): its salient flags as a bit mask in LDS,
   // 64 voxels per ballot
   __shared__ unsigned bits_all[LNT / 64][LWORDS_MAX + 4];
@@ -576,6 +584,11 @@ tvl_row_kernel(const float* __restrict__ sal, const float* __restrict__ dir, con
     const unsigned long long bal = __builtin_amdgcn_ballot_w64(f);
     if (lane == 0) { bits[2 * c] = (unsigned)bal; bits[2 * c + 1] = (unsigned)(bal >> 32); }
     any |= (unsigned)bal | (unsigned)(bal >> 32);
+    if (!WRITE && f) {
+      float s = sal[row + x];
+      if (mask_src) s = s * mask_src[row + x];
+      if (!(s > 0.0f)) atomicOr(neg_flag, 1u);   // (rare: negative peak heights, masks with negative values, NaN)
+    }
   }
   __builtin_amdgcn_wave_barrier();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -592,7 +605,12 @@ tvl_row_kernel(const float* __restrict__ sal, const float* __restrict__ dir, con
     if (!((bits[x >> 5] >> (x & 31)) & 1u)) continue;
     float s = sal[row + x] * (MODE == 0 ? 0.25f : 0.5f);
     if (mask_src) s = s * mask_src[row + x];
-    const float4 e = make_float4(s, dir[row + x], dir[nvox + row + x], dir[2 * nvox + row + x]);
+    float4 e = make_float4(s, dir[row + x], dir[nvox + row + x], dir[2 * nvox + row + x]);
+    if (fold) {   // a = s^(1/6) (exponent 4) or s^(1/4) (exponent 2), rounded once from double
+      const double r2 = sqrt((double)s);
+      const float a = (float)(MODE == 0 ? cbrt(r2) : sqrt(r2));
+      e = make_float4(2.0f * a * a, a * e.y, a * e.z, a * e.w);
+    }
     // tile columns whose window holds x: 8 tx - h <= x < 8 tx + 8 + h
     const int t0 = max((x - 8 - g.h) / 8 + ((x - 8 - g.h) >= 0 ? 1 : 0), 0);
     const int t1 = min((x + g.h) / 8, g.ntx - 1);
@@ -694,16 +712,20 @@ int dev_tv_box(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* te
   const unsigned row_blocks = (unsigned)(((i64)g.nzl * ny + LNT / 64 - 1) / (LNT / 64));
 #define VH_TVL_ROWS(WR, ENT, POS)                                                                                         \
   do {                                                                                                                    \
-    if (exponent == 4) tvl_row_kernel<WR, 0><<<dim3(row_blocks), dim3(LNT), 0, st>>>(sal, dir, mask_src, g, rows, ENT, POS); \
-    else tvl_row_kernel<WR, 2><<<dim3(row_blocks), dim3(LNT), 0, st>>>(sal, dir, mask_src, g, rows, ENT, POS);             \
+    if (exponent == 4) tvl_row_kernel<WR, 0><<<dim3(row_blocks), dim3(LNT), 0, st>>>(sal, dir, mask_src, g, rows, ENT, POS, counter + 6, fold); \
+    else tvl_row_kernel<WR, 2><<<dim3(row_blocks), dim3(LNT), 0, st>>>(sal, dir, mask_src, g, rows, ENT, POS, counter + 6, fold);             \
   } while (0)
+  int fold = 0;
   VH_TVL_ROWS(false, nullptr, nullptr);
   tvl_scan_kernel<<<dim3((unsigned)(((size_t)g.nzl * g.ntx + LNT - 1) / LNT)), dim3(LNT), 0, st>>>(g, rows, total_dev);
   VH_HIP(hipGetLastError());
   // the lists' total length decides the size of the entry arrays: the one place this launch waits for the device
-  unsigned long long total = 0;
-  VH_HIP(hipMemcpyAsync(&total, total_dev, sizeof(total), hipMemcpyDeviceToHost, st));
+  unsigned long long tot2[2] = {0, 0};   // {total, (negative flag, -)}: counter words 4..7
+  VH_HIP(hipMemcpyAsync(tot2, total_dev, sizeof(tot2), hipMemcpyDeviceToHost, st));
   VH_HIP(hipStreamSynchronize(st));
+  const unsigned long long total = tot2[0];
+  fold = ((unsigned)tot2[1] & 1u) ? 0 : 1;   // every listed saliency positive: the 18-instruction vote
+  if (ctx->opt.tv_no_fold) fold = 0;         // (tests: the general form on positive saliencies too)
   if (total >= (1ull << 32) - 2048) return VISFD_HIP_OK;   // 32-bit entry indices: the caller falls back
   unsigned char* lists = nullptr;
   if (ws(ctx, WS_TVSCRATCH, (size_t)(total + 16) * 20, &lists) != VISFD_HIP_OK) { set_error(""); (void)hipGetLastError(); return VISFD_HIP_OK; }
@@ -728,14 +750,15 @@ int dev_tv_box(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* te
     VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_poison_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     lds_poison_kernel<<<dim3(1024), dim3(256), 160 * 1024, st>>>(counter + 8);
   }
-#define VH_BOX_LAUNCH(MD)                                                                                              \
+#define VH_BOX_LAUNCH(MD, FD)                                                                                          \
   do {                                                                                                                 \
-    VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tv_box_kernel<MD>),                                      \
+    VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tv_box_kernel<MD, FD>),                                  \
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                 \
-    tv_box_kernel<MD><<<dim3((unsigned)ngrid), dim3(NT), lds, st>>>(ten, mask_dst, dtab_box, p, counter, (unsigned)nblk, \
-                                                                   lst_ent, lst_pos, rows);                            \
+    tv_box_kernel<MD, FD><<<dim3((unsigned)ngrid), dim3(NT), lds, st>>>(ten, mask_dst, dtab_box, p, counter, (unsigned)nblk, \
+                                                                       lst_ent, lst_pos, rows);                        \
   } while (0)
-  if (exponent == 4) VH_BOX_LAUNCH(0); else VH_BOX_LAUNCH(2);
+  if (exponent == 4) { if (fold) VH_BOX_LAUNCH(0, true); else VH_BOX_LAUNCH(0, false); }
+  else               { if (fold) VH_BOX_LAUNCH(2, true); else VH_BOX_LAUNCH(2, false); }
 #undef VH_BOX_LAUNCH
   VH_HIP(hipGetLastError());
 #ifdef VH_TV_COUNT
