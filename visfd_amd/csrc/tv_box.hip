@@ -10,12 +10,14 @@
 // used 49 % of its lanes (ball of radius h against an 8 x 4 x 2 patch) at ~27 issue slots per vote step.
 //
 // This kernel keeps the skeleton (persistent workgroups claiming units from a global counter, packed lists, mirror-paired
-// planes, two receiver pairs per pass), lists the senders ONCE for the whole launch (tvl_* kernels below: the round-3
+// planes), takes a 16 x 32 tile of ONE receiver pair per pass (two lists per step instead of the four of two pairs over an
+// 8-wide tile: 224 instead of 358 list entries per step, so a step is one barrier interval; 313 -> 302 ms), lists the
+// senders ONCE for the whole launch (tvl_* kernels below: the round-3
 // kernels listed every sender plane again in every workgroup that reached it -- 7 region voxels read per receiver column,
 // 12-15 % of a wave's time) and replaces the sweep:
 //
-//   * SUB-PATCHES OF 32 RECEIVERS, TWO SENDER STREAMS PER WAVE.  A wave owns, per receiver pair, two sub-patches of
-//     4 x 4 x 2 receivers (the left and right half of its 8 x 4 rows).  Lanes 0-31 and lanes 32-63 hold the SAME 32
+//   * SUB-PATCHES OF 32 RECEIVERS, TWO SENDER STREAMS PER WAVE.  A wave owns four sub-patches of 4 x 4 x 2 receivers (four rows
+//     of each 8-column half of the tile, two sub-patches per half).  Lanes 0-31 and lanes 32-63 hold the SAME 32
 //     receivers and take DIFFERENT senders: a vote step serves two senders, and the two partial sums of a receiver are
 //     added when the pass stores.  A ball of radius 12 covers 67 % of the lanes of a 4 x 4 x 2 patch it touches (56 % of
 //     an 8 x 4 x 2 one): a sixth fewer vote steps for the same votes.
@@ -27,7 +29,7 @@
 //     reach reads a zero weight (its vote adds 0) instead of being masked off.  The vote loop is branch-free:
 //     1 address subtraction + 19 vote instructions per step, its LDS reads (hit entries, sender, table) requested
 //     ahead of their use.
-//   * 6 WAVES PER SIMD, 80 VGPRs, no spills: the 24 sums of a lane (2 pairs x 2 sub-patches x 6) and the read-ahead
+//   * 6 WAVES PER SIMD, 80 VGPRs: the 24 sums of a lane (2 halves x 2 sub-patches x 6) and the read-ahead
 //     registers of the vote loop stay in registers.  3 workgroups per CU, ~51 KB of LDS each at h = 12.
 //
 // Results differ from the reference's in the last bits (tests/test_tolerance_modes.py: within 1e-5 of the field's
@@ -46,9 +48,9 @@ namespace {
 
 constexpr int NT = 512;
 constexpr int NW = NT / 64;
-constexpr int TX = 8, TY = 4 * NW;     // a workgroup's tile of receivers: 8 x 32 (wave w: rows 4w..4w+3), NP pairs of planes
-constexpr int NP = 2;                  // receiver pairs (z, z+1), (z+2, z+3) per pass: they need the same two slices at step d
-constexpr int NLIST = 2 * NP;          // lists per interval: (A, B) of pair 0, (A, B) of pair 1
+constexpr int TX = 16, TY = 4 * NW;    // a workgroup's tile of receivers: 16 x 32 on ONE pair of planes (z, z+1) per pass
+constexpr int NH = TX / 8;             // 8-column halves of the tile: a wave owns four rows of each (two sub-patches per half)
+constexpr int NLIST = 2;               // lists per interval: the sender plane above (A) and the one below (B) the pair
 constexpr int NSUB = 2;                // sub-patches per wave and pair: x 0..3 and x 4..7
 constexpr int LSLOTS = NT;             // LDS entry slots of an interval: one per thread
 constexpr int HCAP = 36;               // hit entries per (wave, sub-patch, stream): 64 tests per chunk -> <= 32, + null + read-ahead
@@ -186,7 +188,7 @@ tv_box_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
   __shared__ __attribute__((aligned(16))) uint2 l_pos[LSLOTS];
   __shared__ __attribute__((aligned(16))) uint2 l_hit[NW][NSUB][2][HCAP];
   __shared__ unsigned claimed_tile;
-  __shared__ unsigned plane_beg[88];         // per sender plane of a pass (slot = plane - (rz - h), < 2h + 2 NP <= 84): first entry ...
+  __shared__ unsigned plane_beg[88];         // per sender plane of a pass (slot = plane - (rz - h), < 2h + 2 <= 82): first entry ...
   __shared__ int plane_cnt[88];              // ... and number of entries of this tile's rows in the plane's list
   __shared__ int rho_tab[44];                // floor(sqrt(h^2 - j^2)), j = 0..h: the radius of slice j
   extern __shared__ __attribute__((aligned(16))) unsigned char slices[];   // two table slices: S_j (jz = +j) in slot j & 1
@@ -245,10 +247,10 @@ tv_box_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
     const int z_run1 = min(z_run0 + p.zrun, p.z_out1);
     const int x0 = tile_x * TX, y0 = tile_y * TY;
 
-    // MIRRORED ROW BLOCKS.  A wave's receivers of pair pp are the four rows of block w for the first pair, NW - 1 - w for
-    // the second: the sweep of an interval lasts as long as its slowest wave, and which rows are heavy -- those near a
-    // membrane -- is much the same for the two pairs of a pass.
-    auto row_block = [&](int pp) -> int { return (pp & 1) ? NW - 1 - wave : wave; };
+    // MIRRORED ROW BLOCKS.  A wave's receivers in the tile's left half are the four rows of block w, in its right half those
+    // of block NW - 1 - w: the sweep of an interval lasts as long as its slowest wave, and which rows are heavy -- those near
+    // a membrane -- is much the same for the two halves.
+    auto row_block = [&](int hh) -> int { return (hh & 1) ? NW - 1 - wave : wave; };
     // The per-lane constants of a phase are RECOMPUTED from the lane number where the phase starts (the empty asm hides the
     // number's origin from the compiler): hoisted out of the step loop they stay live across the vote loops and are spilled.
     auto fresh_lane = [&]() -> unsigned {
@@ -257,7 +259,7 @@ tv_box_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
       return ln;
     };
 
-    float TT[NP][NSUB][6];
+    float TT[NH][NSUB][6];
 
     // ---- TEST + VOTE: entries [i0, i1) of one list's share of the interval (first LDS slot `base`), 64 at a time.  Lane l
     // tests entry i0 + 64 c + l against the boxes of both sub-patches: with the sender at region position (ex, ey) and a
@@ -266,8 +268,8 @@ tv_box_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
     // receiver planes is d - 1 planes from the sender plane).  All small integers: exact in float.
     auto test_vote = [&](auto ZN, auto PP, int base, int i0, int i1, unsigned r16, float cy, float rr, unsigned null_e16) {
       constexpr bool ZNEG = decltype(ZN)::value;
-      constexpr int pp = decltype(PP)::value;
-      const float cx0 = (float)h + 1.5f;
+      constexpr int pp = decltype(PP)::value;   // the half of the tile
+      const float cx0 = (float)(h + 8 * pp) + 1.5f;
       // this wave's hit entries: sub-patch s, stream t at hb + (2 s + t) * HCAP * 8 (the constants are offset fields)
       const unsigned hb = lds_addr(&l_hit[wave][0][0][0]);
       for (int c = i0; c < i1; c += 64) {   // uniform
@@ -313,10 +315,10 @@ tv_box_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
 
     // rows of the sender lists this tile reaches: [y0 - h, y0 + TY + h) clipped to the image
     const int row_lo = max(y0 - h, 0), row_hi = min(y0 + TY - 1 + h, p.ny - 1);
-    for (int rz = z_run0; rz < z_run1; rz += 2 * NP) {
+    for (int rz = z_run0; rz < z_run1; rz += 2) {
       // sender planes that reach the LIVE receivers of this pass (a run may end inside a pass: nothing above the last
       // live receiver + h is needed -- or, in a slab run, complete -- then)
-      const int sz_hi = min(min(rz + 2 * NP - 1, z_run1 - 1) + h, p.nz - 1), sz_lo = max(rz - h, 0);
+      const int sz_hi = min(min(rz + 1, z_run1 - 1) + h, p.nz - 1), sz_lo = max(rz - h, 0);
       // where this tile's rows start in each of those planes' lists and how many entries they have: the lists are in descending
       // row order, lst_rows[.. y ..] = index of the first entry of a row < y (see tvl_scan_kernel)
       __syncthreads();   // every wave is done with the previous pass's ranges (its trailing steps may have had no barrier)
@@ -329,7 +331,7 @@ tv_box_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
       }
 
 #pragma unroll
-      for (int pp = 0; pp < NP; pp++)
+      for (int pp = 0; pp < NH; pp++)
 #pragma unroll
         for (int s = 0; s < NSUB; s++)
 #pragma unroll
@@ -337,25 +339,19 @@ tv_box_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
       __syncthreads();   // the list ranges of this pass are visible
       VH_STAMP(0);
 
-      // d = 1 .. h+1.  Pair pp (receiver planes z = rz + 2 pp and z + 1): sender planes A = z + d (above: jz = -d for the
+      // d = 1 .. h+1.  Receiver planes z = rz and z + 1: sender planes A = z + d (above: jz = -d for the
       // lower receiver plane, 1-d for the upper one) and B = z + 1 - d (below: jz = d-1 and d).  All of them need the slices
       // S_(d-1) and S_d; the direction of d alternates from pass to pass, so that every step -- the first of a pass
       // included -- finds one of its two slices in LDS already.
       auto plane_slot = [&](int sz) -> int { return sz - (rz - h); };   // (only used for planes in [sz_lo, sz_hi])
       for (int step = 0; step <= h; step++) {
         const int d = up ? step + 1 : h + 1 - step;
-        int lsz[NLIST], lcnt[NLIST];     // list 2 pp: plane A of pair pp; list 2 pp + 1: its plane B
-        int cmax = 0;
-#pragma unroll
-        for (int pp = 0; pp < NP; pp++) {
-          const int z = rz + 2 * pp;
-          const bool pair_live = z < z_run1;                   // (uniform) a pair beyond the end of the run takes no votes
-          lsz[2 * pp] = z + d;
-          lsz[2 * pp + 1] = z + 1 - d;
-          lcnt[2 * pp] = (pair_live && lsz[2 * pp] <= sz_hi) ? __builtin_amdgcn_readfirstlane(plane_cnt[plane_slot(lsz[2 * pp])]) : 0;
-          lcnt[2 * pp + 1] = (pair_live && lsz[2 * pp + 1] >= sz_lo) ? __builtin_amdgcn_readfirstlane(plane_cnt[plane_slot(lsz[2 * pp + 1])]) : 0;
-          cmax = max(cmax, max(lcnt[2 * pp], lcnt[2 * pp + 1]));
-        }
+        int lsz[NLIST], lcnt[NLIST];     // list 0: plane A = rz + d (above the pair), list 1: plane B = rz + 1 - d (below)
+        lsz[0] = rz + d;
+        lsz[1] = rz + 1 - d;
+        lcnt[0] = lsz[0] <= sz_hi ? __builtin_amdgcn_readfirstlane(plane_cnt[plane_slot(lsz[0])]) : 0;
+        lcnt[1] = lsz[1] >= sz_lo ? __builtin_amdgcn_readfirstlane(plane_cnt[plane_slot(lsz[1])]) : 0;
+        const int cmax = max(lcnt[0], lcnt[1]);
         if (cmax == 0) continue;   // uniform
         // slices S_(d-1) and S_d (S_(h+1), which the receiver plane h+1 planes from the sender plane reads at the step
         // d = h+1, is a slice of zeros); lists and slices are free: every interval ends with a barrier
@@ -445,42 +441,44 @@ tv_box_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
           // entries are in descending row order: of list k, this wave needs those from the first one at or below region row
           // 4 wv + h + 3 + rho to the last one at or above row 4 wv + h - rho.  Every wave counts both kinds itself, from the
           // row bytes of the position words in LDS, 64 entries at a time.
-          int i0[NLIST], i1[NLIST];
+          int i0[NLIST][NH], i1[NLIST][NH];
 #pragma unroll
-          for (int k = 0; k < NLIST; k++) {
-            const int wv = row_block(k >> 1);
-            const int hi_row = 4 * wv + h + 3 + rho, lo_row = 4 * wv + h - rho;
-            int above = 0, upto = 0;
-            for (int j = 0; j < len[k]; j += 64) {   // uniform
-              int ey = -1;
-              if (j + lane < len[k]) ey = (int)((l_pos[c[k] + j + lane].x >> 8) & 0xffu);
-              above += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ey > hi_row));
-              upto += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ey >= lo_row));
+          for (int k = 0; k < NLIST; k++)
+#pragma unroll
+            for (int hh = 0; hh < NH; hh++) {
+              const int wv = row_block(hh);
+              const int hi_row = 4 * wv + h + 3 + rho, lo_row = 4 * wv + h - rho;
+              int above = 0, upto = 0;
+              for (int j = 0; j < len[k]; j += 64) {   // uniform
+                int ey = -1;
+                if (j + lane < len[k]) ey = (int)((l_pos[c[k] + j + lane].x >> 8) & 0xffu);
+                above += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ey > hi_row));
+                upto += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ey >= lo_row));
+              }
+              i0[k][hh] = above;
+              i1[k][hh] = upto;
             }
-            i0[k] = above;
-            i1[k] = upto;
-          }
           auto pair_votes = [&](auto PP) {
-            constexpr int pp = decltype(PP)::value;
-            if (i1[2 * pp] <= i0[2 * pp] && i1[2 * pp + 1] <= i0[2 * pp + 1]) return;   // uniform
+            constexpr int pp = decltype(PP)::value;   // the half of the tile
+            if (i1[0][pp] <= i0[0][pp] && i1[1][pp] <= i0[1][pp]) return;   // uniform
             const int rb = row_block(pp);
             const float cy = (float)(4 * rb + h) + 1.5f;
             const unsigned ln = fresh_lane();
             const int fq = (int)((ln & 31u) >> 2);
             const int fcol = (int)(ln & 3u), frow = fq >> 1, fpl = (0x96 >> fq) & 1;
-            // this lane's table entry of a sender at region position (0, 0), sub-patch 0, in slice slot 0:
-            // 4 guard entries, then row (jy + h + YPAD), column (jx + h) with jy = 4 rb + frow + h - ey, jx = fcol + h - ex
-            const unsigned r16_0 = lds_addr(slices) + 16u * (unsigned)(4 + (4 * rb + frow + 2 * h + YPAD) * SP + fcol + 2 * h);
-            const unsigned null_e16 = 16u * (unsigned)((4 * rb + h) * SP + h);
+            // this lane's table entry of a sender at region position (0, 0), sub-patch 0 of this half, in slice slot 0:
+            // 4 guard entries, then row (jy + h + YPAD), column (jx + h) with jy = 4 rb + frow + h - ey, jx = 8 pp + fcol + h - ex
+            const unsigned r16_0 = lds_addr(slices) + 16u * (unsigned)(4 + (4 * rb + frow + 2 * h + YPAD) * SP + 8 * pp + fcol + 2 * h);
+            const unsigned null_e16 = 16u * (unsigned)((4 * rb + h) * SP + h + 8 * pp);
             // plane A (above): the lower receiver plane sees it at jz = -d (slice S_d, rhat_z negated), the upper one at 1-d
-            if (i1[2 * pp] > i0[2 * pp]) {
+            if (i1[0][pp] > i0[0][pp]) {
               const int js = fpl ? d - 1 : d;
-              test_vote(std::true_type{}, PP, c[2 * pp], i0[2 * pp], i1[2 * pp], r16_0 + (unsigned)(16 * nsl) * (unsigned)(js & 1), cy, rr, null_e16);
+              test_vote(std::true_type{}, PP, c[0], i0[0][pp], i1[0][pp], r16_0 + (unsigned)(16 * nsl) * (unsigned)(js & 1), cy, rr, null_e16);
             }
             // plane B (below): jz = d-1 for the lower plane (S_(d-1)), d for the upper one (S_d)
-            if (i1[2 * pp + 1] > i0[2 * pp + 1]) {
+            if (i1[1][pp] > i0[1][pp]) {
               const int js = fpl ? d : d - 1;
-              test_vote(std::false_type{}, PP, c[2 * pp + 1], i0[2 * pp + 1], i1[2 * pp + 1], r16_0 + (unsigned)(16 * nsl) * (unsigned)(js & 1), cy, rr, null_e16);
+              test_vote(std::false_type{}, PP, c[1], i0[1][pp], i1[1][pp], r16_0 + (unsigned)(16 * nsl) * (unsigned)(js & 1), cy, rr, null_e16);
             }
           };
           pair_votes(std::integral_constant<int, 0>{});
@@ -494,9 +492,9 @@ tv_box_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
 
       // ---- the pass's sums: a receiver's two streams are added; lanes 0-31 store sub-patch 0, lanes 32-63 sub-patch 1 ----
 #pragma unroll
-      for (int pp = 0; pp < NP; pp++) {
+      for (int pp = 0; pp < NH; pp++) {
         const int rb = row_block(pp);
-        const int rx = x0 + 4 * strm + lcol, ry = y0 + 4 * rb + lrow, rzl = rz + 2 * pp + lpl;
+        const int rx = x0 + 8 * pp + 4 * strm + lcol, ry = y0 + 4 * rb + lrow, rzl = rz + lpl;
         const bool in = rx < p.nx && ry < p.ny && rzl < z_run1;
         const i64 rc = (i64)rzl * plane + (i64)ry * p.nx + rx;
         const bool live = in && !(mask_dst && mask_dst[in ? rc : 0] == 0.0f);
@@ -531,10 +529,10 @@ tv_box_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
 }
 
 // ---- THE SENDER LISTS, once per launch ---------------------------------------------------------------------------------
-// For every listed plane z and every tile column tx (8 receiver columns), the salient, unmasked senders of the columns
-// [8 tx - h, 8 tx + 8 + h) -- everything a tile of that column can reach in x -- as one list in DESCENDING (y, x) (the order
+// For every listed plane z and every tile column tx (TX = 16 receiver columns), the salient, unmasked senders of the columns
+// [TX tx - h, TX tx + TX + h) -- everything a tile of that column can reach in x -- as one list in DESCENDING (y, x) (the order
 // the vote kernel's row-range culling needs), 20 bytes per entry: float4 {saliency * 1/4 or 1/2 (* mask value), normal} and one
-// word {x - (8 tx - h), y << 8}.  A sender appears in the lists of the (up to 1 + 2h/8 + 1) tile columns that reach it.
+// word {x - (TX tx - h), y << 8}.  A sender appears in the lists of the tile columns that reach it (2.5 on average at h = 12).
 // rows[(zl (ny + 1) + y) ntx + tx]: index (into the global entry arrays) of the first entry of list (zl, tx) with a row
 // below y -- so the entries of the rows [ylo, yhi] are [rows[.. yhi + 1 ..], rows[.. ylo ..]).
 // Three kernels: count per (plane, row, tile column); suffix sums per (plane, tile column) with one atomic add per list for
@@ -595,7 +593,7 @@ tvl_row_kernel(const float* __restrict__ sal, const float* __restrict__ dir, con
   unsigned* const rrow = rows + ((size_t)zl * (size_t)(g.ny + 1) + (size_t)y) * (size_t)g.ntx;
   if (!WRITE) {
     for (int tx = lane; tx < g.ntx; tx += 64)
-      rrow[tx] = any ? popc_range(bits, max(8 * tx - g.h, 0), min(8 * tx + 8 + g.h, g.nx)) : 0u;
+      rrow[tx] = any ? popc_range(bits, max(TX * tx - g.h, 0), min(TX * tx + TX + g.h, g.nx)) : 0u;
     return;
   }
   if (!any) return;   // (uniform)
@@ -611,11 +609,11 @@ tvl_row_kernel(const float* __restrict__ sal, const float* __restrict__ dir, con
       const float a = (float)(MODE == 0 ? cbrt(r2) : sqrt(r2));
       e = make_float4(2.0f * a * a, a * e.y, a * e.z, a * e.w);
     }
-    // tile columns whose window holds x: 8 tx - h <= x < 8 tx + 8 + h
-    const int t0 = max((x - 8 - g.h) / 8 + ((x - 8 - g.h) >= 0 ? 1 : 0), 0);
-    const int t1 = min((x + g.h) / 8, g.ntx - 1);
+    // tile columns whose window holds x: TX tx - h <= x < TX tx + TX + h
+    const int t0 = max((x - TX - g.h) / TX + ((x - TX - g.h) >= 0 ? 1 : 0), 0);
+    const int t1 = min((x + g.h) / TX, g.ntx - 1);
     for (int tx = t0; tx <= t1; tx++) {
-      const int lo = 8 * tx - g.h, hi = min(8 * tx + 8 + g.h, g.nx);
+      const int lo = TX * tx - g.h, hi = min(TX * tx + TX + g.h, g.nx);
       if (x < lo || x >= hi) continue;
       // rows[.. y + 1 ..] = first entry of the rows below y + 1 = first entry of row y; within the row: descending x
       const unsigned idx = rrow[g.ntx + tx] + popc_range(bits, x + 1, hi);
