@@ -247,10 +247,8 @@ tv_box_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
     const int z_run1 = min(z_run0 + p.zrun, p.z_out1);
     const int x0 = tile_x * TX, y0 = tile_y * TY;
 
-    // MIRRORED ROW BLOCKS.  A wave's receivers in the tile's left half are the four rows of block w, in its right half those
-    // of block NW - 1 - w: the sweep of an interval lasts as long as its slowest wave, and which rows are heavy -- those near
-    // a membrane -- is much the same for the two halves.
-    auto row_block = [&](int hh) -> int { return (hh & 1) ? NW - 1 - wave : wave; };
+    // (A wave owns the rows 4 w .. 4 w + 3 of both halves.  Round 3's mirrored row blocks -- the second half's rows dealt to the
+    // waves in reverse order, against the skew of the waves' vote counts -- measured no difference in this kernel.)
     // The per-lane constants of a phase are RECOMPUTED from the lane number where the phase starts (the empty asm hides the
     // number's origin from the compiler): hoisted out of the step loop they stay live across the vote loops and are spilled.
     auto fresh_lane = [&]() -> unsigned {
@@ -266,10 +264,8 @@ tv_box_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
     // sub-patch's receivers at x in [bx, bx + 3], y in [by, by + 3], the nearest receiver is max(|ex - (bx + 1.5)| - 1.5, 0)
     // columns and as many rows (with by) away; it is reached if dx^2 + dy^2 <= rr = h^2 - (d-1)^2 (the nearer of the two
     // receiver planes is d - 1 planes from the sender plane).  All small integers: exact in float.
-    auto test_vote = [&](auto ZN, auto PP, int base, int i0, int i1, unsigned r16, float cy, float rr, unsigned null_e16) {
+    auto test_vote = [&](auto ZN, int base, int i0, int i1, unsigned r16, float cy, float rr, unsigned null_e16) {
       constexpr bool ZNEG = decltype(ZN)::value;
-      constexpr int pp = decltype(PP)::value;   // the half of the tile
-      const float cx0 = (float)(h + 8 * pp) + 1.5f;
       // this wave's hit entries: sub-patch s, stream t at hb + (2 s + t) * HCAP * 8 (the constants are offset fields)
       const unsigned hb = lds_addr(&l_hit[wave][0][0][0]);
       for (int c = i0; c < i1; c += 64) {   // uniform
@@ -281,35 +277,46 @@ tv_box_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
         const float dy = fmaxf(__builtin_fabsf(eyf - cy) - 1.5f, 0.0f);
         const float dy2 = dy * dy;
         const unsigned ent = ent_base + 16u * (unsigned)(base + e);
-        int nh[NSUB];
+        // the two 8-column halves of the tile, one after the other (the hit buffers hold one half's two sub-patches)
+        auto half = [&](auto HH) {
+          constexpr int hh = decltype(HH)::value;
+          const float cx0 = (float)(h + 8 * hh) + 1.5f;
+          int nh[NSUB];
 #pragma unroll
-        for (int s = 0; s < NSUB; s++) {
-          const float dx = fmaxf(__builtin_fabsf(exf - (cx0 + 4.0f * (float)s)) - 1.5f, 0.0f);
-          const bool hit = __builtin_fmaf(dx, dx, dy2) <= rr;
-          const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
-          nh[s] = __builtin_popcountll(bal);
-          const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-          // (sub-patch 1's table entries are 4 columns = 64 bytes further: taken off the sender's offset here, so that the
-          // vote loop has one table base for both sub-patches)
-          if (hit) lds_store_u2(hb + (unsigned)(2 * s * HCAP * 8) + (rank & 1u) * (unsigned)(HCAP * 8) + (rank >> 1) * 8u, ent, pw.y - 64u * (unsigned)s);
-          // the second stream's last step when the count is odd: the null sender (zero saliency, zero normal), placed on the
-          // sub-patch's first receiver so that every lane reads a table entry of the slice (finite; times 0)
-          if (ln == 0) lds_store_u2(hb + (unsigned)((2 * s + 1) * HCAP * 8) + (unsigned)(nh[s] >> 1) * 8u, null_ent, null_e16);
-        }
+          for (int s = 0; s < NSUB; s++) {
+            const float dx = fmaxf(__builtin_fabsf(exf - (cx0 + 4.0f * (float)s)) - 1.5f, 0.0f);
+            const bool hit = __builtin_fmaf(dx, dx, dy2) <= rr;
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
+            nh[s] = __builtin_popcountll(bal);
+            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+            // (the table entries of sub-patch s of half hh are 8 hh + 4 s columns further: taken off the sender's offset here, so
+            // that the vote loops have one table base)
+            if (hit) lds_store_u2(hb + (unsigned)(2 * s * HCAP * 8) + (rank & 1u) * (unsigned)(HCAP * 8) + (rank >> 1) * 8u, ent,
+                                  pw.y - (unsigned)(128 * hh + 64 * s));
+            // the second stream's last step when the count is odd: the null sender (zero saliency, zero normal), placed on the
+            // tile's first receiver of this row block so that every lane reads a table entry of the slice (finite; times 0)
+            // (its offset for sub-patch (hh, s), less that sub-patch's 128 hh + 64 s, is the same for all four)
+            if (ln == 0) lds_store_u2(hb + (unsigned)((2 * s + 1) * HCAP * 8) + (unsigned)(nh[s] >> 1) * 8u, null_ent, null_e16);
+          }
+#ifdef VH_TV_COUNT
+          cnt_hits += (unsigned)(nh[0] + nh[1]);
+          cnt_steps += (unsigned)(((nh[0] + 1) >> 1) + ((nh[1] + 1) >> 1));
+#endif
+          __builtin_amdgcn_wave_barrier();
+          asm volatile("" ::: "memory");
+          const unsigned hp = hb + (fresh_lane() >> 5) * (unsigned)(HCAP * 8);
+          __builtin_amdgcn_s_setprio(1);   // a voting wave is on its workgroup's critical path; waves that fill are not (337 -> 333 ms)
+          if (nh[0] > 0) vote_hits<MODE, ZNEG, FOLD, 0>(TT[hh][0], hp, (nh[0] + 1) >> 1, r16);              // (uniform)
+          if (nh[1] > 0) vote_hits<MODE, ZNEG, FOLD, 2 * HCAP * 8>(TT[hh][1], hp, (nh[1] + 1) >> 1, r16);
+          __builtin_amdgcn_s_setprio(0);
+          asm volatile("" ::: "memory");
+          __builtin_amdgcn_wave_barrier();
+        };
 #ifdef VH_TV_COUNT
         cnt_tested += (unsigned)min(64, i1 - c);
-        cnt_hits += (unsigned)(nh[0] + nh[1]);
-        cnt_steps += (unsigned)(((nh[0] + 1) >> 1) + ((nh[1] + 1) >> 1));
 #endif
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("" ::: "memory");
-        const unsigned hp = hb + (fresh_lane() >> 5) * (unsigned)(HCAP * 8);
-        __builtin_amdgcn_s_setprio(1);   // a voting wave is on its workgroup's critical path; waves that list or fill are not (337 -> 333 ms)
-        if (nh[0] > 0) vote_hits<MODE, ZNEG, FOLD, 0>(TT[pp][0], hp, (nh[0] + 1) >> 1, r16);              // (uniform)
-        if (nh[1] > 0) vote_hits<MODE, ZNEG, FOLD, 2 * HCAP * 8>(TT[pp][1], hp, (nh[1] + 1) >> 1, r16);
-        __builtin_amdgcn_s_setprio(0);
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
+        half(std::integral_constant<int, 0>{});
+        half(std::integral_constant<int, 1>{});
       }
     };
 
@@ -441,13 +448,11 @@ tv_box_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
           // entries are in descending row order: of list k, this wave needs those from the first one at or below region row
           // 4 wv + h + 3 + rho to the last one at or above row 4 wv + h - rho.  Every wave counts both kinds itself, from the
           // row bytes of the position words in LDS, 64 entries at a time.
-          int i0[NLIST][NH], i1[NLIST][NH];
+          int i0[NLIST], i1[NLIST];
+          {
+            const int hi_row = 4 * wave + h + 3 + rho, lo_row = 4 * wave + h - rho;
 #pragma unroll
-          for (int k = 0; k < NLIST; k++)
-#pragma unroll
-            for (int hh = 0; hh < NH; hh++) {
-              const int wv = row_block(hh);
-              const int hi_row = 4 * wv + h + 3 + rho, lo_row = 4 * wv + h - rho;
+            for (int k = 0; k < NLIST; k++) {
               int above = 0, upto = 0;
               for (int j = 0; j < len[k]; j += 64) {   // uniform
                 int ey = -1;
@@ -455,34 +460,30 @@ tv_box_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
                 above += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ey > hi_row));
                 upto += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ey >= lo_row));
               }
-              i0[k][hh] = above;
-              i1[k][hh] = upto;
+              i0[k] = above;
+              i1[k] = upto;
             }
-          auto pair_votes = [&](auto PP) {
-            constexpr int pp = decltype(PP)::value;   // the half of the tile
-            if (i1[0][pp] <= i0[0][pp] && i1[1][pp] <= i0[1][pp]) return;   // uniform
-            const int rb = row_block(pp);
-            const float cy = (float)(4 * rb + h) + 1.5f;
+          }
+          if (i1[0] > i0[0] || i1[1] > i0[1]) {   // uniform
+            const float cy = (float)(4 * wave + h) + 1.5f;
             const unsigned ln = fresh_lane();
             const int fq = (int)((ln & 31u) >> 2);
             const int fcol = (int)(ln & 3u), frow = fq >> 1, fpl = (0x96 >> fq) & 1;
-            // this lane's table entry of a sender at region position (0, 0), sub-patch 0 of this half, in slice slot 0:
-            // 4 guard entries, then row (jy + h + YPAD), column (jx + h) with jy = 4 rb + frow + h - ey, jx = 8 pp + fcol + h - ex
-            const unsigned r16_0 = lds_addr(slices) + 16u * (unsigned)(4 + (4 * rb + frow + 2 * h + YPAD) * SP + 8 * pp + fcol + 2 * h);
-            const unsigned null_e16 = 16u * (unsigned)((4 * rb + h) * SP + h + 8 * pp);
+            // this lane's table entry of a sender at region position (0, 0), sub-patch 0 of the left half, in slice slot 0:
+            // 4 guard entries, then row (jy + h + YPAD), column (jx + h) with jy = 4 w + frow + h - ey, jx = fcol + h - ex
+            const unsigned r16_0 = lds_addr(slices) + 16u * (unsigned)(4 + (4 * wave + frow + 2 * h + YPAD) * SP + fcol + 2 * h);
+            const unsigned null_e16 = 16u * (unsigned)((4 * wave + h) * SP + h);
             // plane A (above): the lower receiver plane sees it at jz = -d (slice S_d, rhat_z negated), the upper one at 1-d
-            if (i1[0][pp] > i0[0][pp]) {
+            if (i1[0] > i0[0]) {
               const int js = fpl ? d - 1 : d;
-              test_vote(std::true_type{}, PP, c[0], i0[0][pp], i1[0][pp], r16_0 + (unsigned)(16 * nsl) * (unsigned)(js & 1), cy, rr, null_e16);
+              test_vote(std::true_type{}, c[0], i0[0], i1[0], r16_0 + (unsigned)(16 * nsl) * (unsigned)(js & 1), cy, rr, null_e16);
             }
             // plane B (below): jz = d-1 for the lower plane (S_(d-1)), d for the upper one (S_d)
-            if (i1[1][pp] > i0[1][pp]) {
+            if (i1[1] > i0[1]) {
               const int js = fpl ? d : d - 1;
-              test_vote(std::false_type{}, PP, c[1], i0[1][pp], i1[1][pp], r16_0 + (unsigned)(16 * nsl) * (unsigned)(js & 1), cy, rr, null_e16);
+              test_vote(std::false_type{}, c[1], i0[1], i1[1], r16_0 + (unsigned)(16 * nsl) * (unsigned)(js & 1), cy, rr, null_e16);
             }
-          };
-          pair_votes(std::integral_constant<int, 0>{});
-          pair_votes(std::integral_constant<int, 1>{});
+          }
           VH_STAMP(3);
           __syncthreads();   // everyone done reading before the lists or the slices are refilled
           VH_STAMP(4);
@@ -493,8 +494,7 @@ tv_box_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
       // ---- the pass's sums: a receiver's two streams are added; lanes 0-31 store sub-patch 0, lanes 32-63 sub-patch 1 ----
 #pragma unroll
       for (int pp = 0; pp < NH; pp++) {
-        const int rb = row_block(pp);
-        const int rx = x0 + 8 * pp + 4 * strm + lcol, ry = y0 + 4 * rb + lrow, rzl = rz + lpl;
+        const int rx = x0 + 8 * pp + 4 * strm + lcol, ry = y0 + 4 * wave + lrow, rzl = rz + lpl;
         const bool in = rx < p.nx && ry < p.ny && rzl < z_run1;
         const i64 rc = (i64)rzl * plane + (i64)ry * p.nx + rx;
         const bool live = in && !(mask_dst && mask_dst[in ? rc : 0] == 0.0f);
