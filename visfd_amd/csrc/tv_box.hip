@@ -564,8 +564,12 @@ tvl_row_kernel(const float* __restrict__ sal, const float* __restrict__ dir, con
                unsigned* __restrict__ neg_flag /* count pass: set if a listed saliency (times its mask value) is not positive */,
                int fold /* write pass: records {c, a n} instead of {s, n} (vote_fma) */) {
   // ONE WAVE PER IMAGE ROW (no workgroup barrier: a wave's bit mask is its own): its salient flags as a bit mask in LDS,
-  // 64 voxels per ballot
+  // 64 voxels per ballot.  A wave is a chain of memory round trips, so every phase requests LB chunks' worth of loads before
+  // it uses the first (the loops are otherwise one round trip per 64 voxels: 8 ms for the write pass at 1024^3)
+  constexpr int LB = 8;
   __shared__ unsigned bits_all[LNT / 64][LWORDS_MAX + 4];
+  __shared__ unsigned base_all[WRITE ? LNT / 64 : 1][WRITE ? LWORDS_MAX * 2 + 4 : 1];   // write pass: the row's first entry per list
+  __shared__ unsigned cum_all[WRITE ? LNT / 64 : 1][WRITE ? LWORDS_MAX / 2 + 4 : 1];    // write pass: salient voxels before chunk c
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
   const i64 r = (i64)blockIdx.x * (LNT / 64) + wave;      // row number among the listed rows
   if (r >= (i64)g.nzl * g.ny) return;                      // (uniform per wave)
@@ -574,51 +578,87 @@ tvl_row_kernel(const float* __restrict__ sal, const float* __restrict__ dir, con
   const i64 plane = (i64)g.nx * g.ny, nvox = plane * g.nz;
   const i64 row = (i64)(g.zl0 + zl) * plane + (i64)y * g.nx;
   const int nchunks = (g.nx + 63) >> 6;
-  unsigned any = 0;
-  for (int c = 0; c < nchunks; c++) {   // uniform
-    const int x = 64 * c + lane;
-    bool f = false;
-    if (x < g.nx) f = sal[row + x] != 0.0f && !(mask_src && mask_src[row + x] == 0.0f);
-    const unsigned long long bal = __builtin_amdgcn_ballot_w64(f);
-    if (lane == 0) { bits[2 * c] = (unsigned)bal; bits[2 * c + 1] = (unsigned)(bal >> 32); }
-    any |= (unsigned)bal | (unsigned)(bal >> 32);
-    if (!WRITE && f) {
-      float s = sal[row + x];
-      if (mask_src) s = s * mask_src[row + x];
-      if (!(s > 0.0f)) atomicOr(neg_flag, 1u);   // (rare: negative peak heights, masks with negative values, NaN)
+  unsigned* const rrow = rows + ((size_t)zl * (size_t)(g.ny + 1) + (size_t)y) * (size_t)g.ntx;
+  if (WRITE) {   // (requested first: used after the flags)
+    unsigned* const base = base_all[WRITE ? wave : 0];
+    for (int tx = lane; tx < g.ntx; tx += 64) base[tx] = rrow[g.ntx + tx];
+  }
+  unsigned any = 0, total = 0;
+  unsigned* const cum = cum_all[WRITE ? wave : 0];
+  for (int c0 = 0; c0 < nchunks; c0 += LB) {   // uniform
+    float v[LB], m[LB];
+#pragma unroll
+    for (int k = 0; k < LB; k++) {
+      const int x = 64 * (c0 + k) + lane;
+      v[k] = x < g.nx ? sal[row + x] : 0.0f;
+      m[k] = (mask_src && x < g.nx) ? mask_src[row + x] : 1.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < LB; k++) {
+      if (c0 + k >= nchunks) break;   // uniform
+      const bool f = v[k] != 0.0f && m[k] != 0.0f;
+      const unsigned long long bal = __builtin_amdgcn_ballot_w64(f);
+      if (lane == 0) {
+        bits[2 * (c0 + k)] = (unsigned)bal;
+        bits[2 * (c0 + k) + 1] = (unsigned)(bal >> 32);
+        if (WRITE) cum[c0 + k] = total;
+      }
+      any |= (unsigned)bal | (unsigned)(bal >> 32);
+      if (WRITE) total += (unsigned)__builtin_popcountll(bal);
+      if (!WRITE && f) {
+        const float s = mask_src ? v[k] * m[k] : v[k];
+        if (!(s > 0.0f)) atomicOr(neg_flag, 1u);   // (rare: negative peak heights, masks with negative values, NaN)
+      }
     }
   }
   __builtin_amdgcn_wave_barrier();
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  unsigned* const rrow = rows + ((size_t)zl * (size_t)(g.ny + 1) + (size_t)y) * (size_t)g.ntx;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   if (!WRITE) {
     for (int tx = lane; tx < g.ntx; tx += 64)
       rrow[tx] = any ? popc_range(bits, max(TX * tx - g.h, 0), min(TX * tx + TX + g.h, g.nx)) : 0u;
     return;
   }
   if (!any) return;   // (uniform)
-  for (int c = 0; c < nchunks; c++) {   // uniform
-    if ((bits[2 * c] | bits[2 * c + 1]) == 0u) continue;   // uniform
-    const int x = 64 * c + lane;
-    if (!((bits[x >> 5] >> (x & 31)) & 1u)) continue;
-    float s = sal[row + x] * (MODE == 0 ? 0.25f : 0.5f);
-    if (mask_src) s = s * mask_src[row + x];
-    float4 e = make_float4(s, dir[row + x], dir[nvox + row + x], dir[2 * nvox + row + x]);
+  const unsigned* const base = base_all[WRITE ? wave : 0];
+  // lane j takes the row's j-th salient voxel (all lanes busy: the fold's double-precision roots at 3 live lanes per chunk
+  // were most of this pass)
+  for (unsigned j0 = 0; j0 < total; j0 += 64) {   // uniform
+    const unsigned j = j0 + lane;
+    if (j >= total) break;
+    int lo = 0, hi = nchunks;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (cum[mid] <= j) lo = mid; else hi = mid;
+    }
+    unsigned k = j - cum[lo];
+    unsigned w = bits[2 * lo];
+    int x = 64 * lo;
+    {
+      const unsigned t = (unsigned)__builtin_popcount(w);
+      if (k >= t) { k -= t; x += 32; w = bits[2 * lo + 1]; }
+    }
+#pragma unroll
+    for (int sft = 16; sft >= 1; sft >>= 1) {
+      const unsigned t = (unsigned)__builtin_popcount(w & ((1u << sft) - 1u));
+      if (k >= t) { k -= t; x += sft; w >>= sft; }
+    }
+    float4 q = make_float4(sal[row + x] * (MODE == 0 ? 0.25f : 0.5f), dir[row + x], dir[nvox + row + x], dir[2 * nvox + row + x]);
+    if (mask_src) q.x = q.x * mask_src[row + x];
     if (fold) {   // a = s^(1/6) (exponent 4) or s^(1/4) (exponent 2), rounded once from double
-      const double r2 = sqrt((double)s);
+      const double r2 = sqrt((double)q.x);
       const float a = (float)(MODE == 0 ? cbrt(r2) : sqrt(r2));
-      e = make_float4(2.0f * a * a, a * e.y, a * e.z, a * e.w);
+      q = make_float4(2.0f * a * a, a * q.y, a * q.z, a * q.w);
     }
     // tile columns whose window holds x: TX tx - h <= x < TX tx + TX + h
     const int t0 = max((x - TX - g.h) / TX + ((x - TX - g.h) >= 0 ? 1 : 0), 0);
     const int t1 = min((x + g.h) / TX, g.ntx - 1);
     for (int tx = t0; tx <= t1; tx++) {
-      const int lo = TX * tx - g.h, hi = min(TX * tx + TX + g.h, g.nx);
-      if (x < lo || x >= hi) continue;
+      const int lo_x = TX * tx - g.h, hi_x = min(TX * tx + TX + g.h, g.nx);
+      if (x < lo_x || x >= hi_x) continue;
       // rows[.. y + 1 ..] = first entry of the rows below y + 1 = first entry of row y; within the row: descending x
-      const unsigned idx = rrow[g.ntx + tx] + popc_range(bits, x + 1, hi);
-      ent[idx] = e;
-      pos[idx] = (unsigned)(x - lo) | ((unsigned)y << 8);
+      const unsigned idx = base[tx] + popc_range(bits, x + 1, hi_x);
+      ent[idx] = q;
+      pos[idx] = (unsigned)(x - lo_x) | ((unsigned)y << 8);
     }
   }
 }
