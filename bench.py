@@ -524,9 +524,14 @@ def main():
         # the ridge stage of the membrane detector: FP64 eigen-decompositions, priced against HBM (20 B/voxel for
         # scores + directions, 28 for the post-vote score) and against the FP64 vector peak
         order = api.DECREASING_EIVALS
-        rs_ms = timed(lambda: ctx.ridge_scores_dev(src, sal, dst, MEMBRANE["sigma"], ratio, order), 3)
-        ctx.threshold_fraction_dev(sal, MEMBRANE["best_fraction"])
-        rd_ms = timed(lambda: ctx.ridge_directions_dev(dst, sal, dirs, MEMBRANE["sigma"], order), 3)
+        # (exact arithmetic first, then with the tolerance mode's single-precision angle: option eig_f32)
+        eig_ms = {}
+        for eig in (1, 0):
+            with ctx.options(eig_f32=eig):
+                rs_ms = timed(lambda: ctx.ridge_scores_dev(src, sal, dst, MEMBRANE["sigma"], ratio, order), 3)
+                ctx.threshold_fraction_dev(sal, MEMBRANE["best_fraction"])
+                rd_ms = timed(lambda: ctx.ridge_directions_dev(dst, sal, dirs, MEMBRANE["sigma"], order), 3)
+            eig_ms[eig] = [rs_ms, rd_ms]
         n_salient = int(torch.count_nonzero(sal).item())
         _, w_tab, _ = api.tv_tables(sigma_tv, math.sqrt(2.0))
         n_taps = int(np.count_nonzero(w_tab))
@@ -559,7 +564,10 @@ def main():
                 "traffic_unit": "bytes per launch, measured OFFLINE (%s), not in this run" % tv_traffic_of[mode][1], "note": note}
         roofline = dict(tv_objs[args.mode])
         roofline["share_of_step"] = round(roofline["ms_per_launch"] / ms_per_step, 3)
-        ts_ms = timed(lambda: ctx.tensor_saliency_dev(ten, sal, order), 3)
+        for eig in (1, 0):
+            with ctx.options(eig_f32=eig):
+                ts_ms = timed(lambda: ctx.tensor_saliency_dev(ten, sal, order), 3)
+            eig_ms[eig].append(ts_ms)
         # FP64 work of the eigen kernels, counted from the compiled code (tools/count_fp64.py): vector FP64 instructions per
         # voxel on the common path x 2 flop for FMA forms; peak 78.6 TFLOP/s FP64 vector (MI355X_MICROARCH.md)
         FP64_PEAK = 78.6
@@ -578,6 +586,10 @@ def main():
                                             987, n_sal, rd_ms),
             "tensor_saliency_kernel": fp64(hbm_obj("eigenvalues of the vote tensor -> lambda0 - lambda1", ts_ms, nv, 28.0),
                                            146, nv, ts_ms),
+            "ms_per_launch_with_eig_f32": {"note": "the same three kernels with the tolerance mode's option eig_f32 = 1 (the solver's "
+                                           "angle in single precision); the objects above are the exact arithmetic",
+                                           "ridge_score_kernel": round(eig_ms[1][0], 4), "ridge_directions_kernel": round(eig_ms[1][1], 4),
+                                           "tensor_saliency_kernel": round(eig_ms[1][2], 4)},
             "note": "fp64_flop_per_voxel: FP64 vector instructions of the compiled kernel per voxel it works on, FMA = 2 (tools/"
                     "count_fp64.py); the kernels issue 2-3 other vector instructions per FP64 one (fp32 Hessian stencil, the angle "
                     "in single precision, selects), so frac_fp64 is what the FP64 pipe sees, not the kernels' issue load; "
