@@ -542,7 +542,8 @@ def main():
         # ignored: < 4 % at this size)
         tv_traffic_of = {"exact": offline_traffic("tv_traffic", shape), "tolerance": offline_traffic("tv_box_traffic", shape)}
         for mode, kname, ops_per_vote, note in (
-                ("exact", "tv_tiled_kernel (bit-exact: the reference's 32 multiplies/adds per vote in its order, no FMA)", 32.0,
+                ("exact", "tv_boxx_kernel (bit-exact: the reference's 32 multiplies/adds per vote in its order, no FMA; the tolerance kernel's "
+                 "lists, box-tested hit lists and zero-padded slices, one sender stream per receiver)", 32.0,
                  "peak = nominal FP32 vector rate, which counts an FMA as 2 flop; the reference's operation order forbids FMA here, "
                  "so the reachable rate is the 70 T lane-operations/s the VALU issues (profiles/r02_microbench_valu.txt)"),
                 ("tolerance", "tv_box_kernel (option tv_fma: 19 fused instructions per vote, 4x4x2 sub-patches with two sender streams per "

@@ -511,8 +511,11 @@ def test_tensor_voting_seeded(ctx, oracle, tag, monkeypatch):
     g = golden("membrane_seeded")
     m = volgen.block_mask(volgen.MEM_SHAPE, seed=302) if tag == "mask" else None
     sal, dirs = g[tag + "_salthr"], g[tag + "_dir"]
-    # both kernels; the tiled one also with a persistent grid of 3 workgroups, so that each claims many units of work
-    for opts in ({"tv_dense": 0}, {"tv_dense": 1}, {"tv_max_wg": 3}, {"tv_max_wg": 1, "tv_zrun": 3}):
+    # all three exact kernels (unmasked surfaces with exponent 2 or 4 take the exact form of tv_box.hip unless tv_exact_tiled
+    # is set; everything else tv_tiled.hip; tv_dense: the baseline kernel); persistent grids of 1-3 workgroups, so that each
+    # claims many units of work; tv_poison: NaN patterns wherever a kernel could read what it has not written
+    for opts in ({"tv_dense": 0}, {"tv_dense": 1}, {"tv_max_wg": 3}, {"tv_max_wg": 1, "tv_zrun": 3}, {"tv_exact_tiled": 1},
+                 {"tv_exact_tiled": 1, "tv_max_wg": 3}, {"tv_poison": 1, "tv_max_wg": 2}):
         with ctx.options(**opts):
             for ex in (4, 2):
                 ten = ctx.tv_dense_stick(sal, dirs, volgen.MEM_TV_SIGMA, ex, 2.0 ** 0.5, m, m)
@@ -624,7 +627,9 @@ def test_tensor_voting_wide_windows(ctx, oracle, sigma_tv, shape, monkeypatch):
     assert np.abs(ref).max() > 0
     # tiled kernel with the chip-filling grid, with 3 and with 1 persistent workgroup (every workgroup then claims
     # many units: ring re-use, per-unit resets), with short runs on top of that, and the baseline kernel
+    ref_d = oracle.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5, None, mask)
     for opts in ({}, {"tv_max_wg": 3}, {"tv_max_wg": 1}, {"tv_max_wg": 2, "tv_zrun": 4}, {"tv_max_wg": 2, "tv_no_replay": 1},
+                 {"tv_exact_tiled": 1}, {"tv_exact_tiled": 1, "tv_max_wg": 2, "tv_zrun": 4}, {"tv_poison": 1, "tv_max_wg": 2, "tv_zrun": 3},
                  {"tv_dense": 1}):
         if opts.get("tv_dense") and sigma_tv > 9:
             continue
@@ -633,6 +638,13 @@ def test_tensor_voting_wide_windows(ctx, oracle, sigma_tv, shape, monkeypatch):
             assert_bits_equal(ten, ref, "tensor sigma_tv=%g %s" % (sigma_tv, opts))
             ten = ctx.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5, mask, mask)
             assert_bits_equal(ten, ref_m, "masked tensor sigma_tv=%g %s" % (sigma_tv, opts))
+            # a destination mask alone (receivers skipped, every sender votes): the exact form of tv_box.hip takes it
+            ten = ctx.tv_dense_stick(sal, dirs, sigma_tv, 2, 2.0 ** 0.5, None, mask)
+            if opts == {}:
+                ref_d2 = oracle.tv_dense_stick(sal, dirs, sigma_tv, 2, 2.0 ** 0.5, None, mask)
+            sel = mask != 0
+            assert_bits_equal(ten[sel], ref_d2[sel], "destination-masked tensor sigma_tv=%g %s" % (sigma_tv, opts))
+    assert np.abs(ref_d).max() > 0
 
 
 @pytest.mark.parametrize("sigma_tv,h", [(19.2, 27), (24.1, 34)])
@@ -645,7 +657,7 @@ def test_tensor_voting_very_wide_windows(ctx, oracle, sigma_tv, h):
     sal, dirs = _sparse_field(shape, seed=h)
     ref = oracle.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5)
     assert np.abs(ref).max() > 0
-    for opts in ({}, {"tv_max_wg": 2, "tv_zrun": 3}):
+    for opts in ({}, {"tv_max_wg": 2, "tv_zrun": 3}, {"tv_exact_tiled": 1}):
         with ctx.options(**opts):
             assert_bits_equal(ctx.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5), ref, "tensor h=%d %s" % (h, opts))
 
@@ -658,8 +670,10 @@ def test_tensor_voting_dense_saliency(ctx, oracle):
     d = rng.standard_normal(shape + (3,)).astype(np.float32)
     d /= np.linalg.norm(d, axis=-1, keepdims=True).astype(np.float32)
     d = np.ascontiguousarray(d, np.float32)
-    ten = ctx.tv_dense_stick(sal, d, 3.0, 2, 2.0 ** 0.5)
-    assert_bits_equal(ten, oracle.tv_dense_stick(sal, d, 3.0, 2, 2.0 ** 0.5), "dense-saliency tensor")
+    want = oracle.tv_dense_stick(sal, d, 3.0, 2, 2.0 ** 0.5)
+    for opts in ({}, {"tv_exact_tiled": 1}, {"tv_poison": 1}):
+        with ctx.options(**opts):
+            assert_bits_equal(ctx.tv_dense_stick(sal, d, 3.0, 2, 2.0 ** 0.5), want, "dense-saliency tensor %s" % opts)
 
 
 
@@ -702,7 +716,8 @@ def test_tensor_voting_unit_shapes_agree(ctx, oracle, monkeypatch):
     want = oracle.tv_dense_stick(sal, dirs, 3.0, 4, 2.0 ** 0.5)
     want_m = oracle.tv_dense_stick(sal, dirs, 3.0, 4, 2.0 ** 0.5, mask, mask)
     for opts in ({}, {"tv_zrun": 1}, {"tv_zrun": 5}, {"tv_no_replay": 1}, {"tv_max_wg": 3}, {"tv_max_wg": 3, "tv_zrun": 1},
-                 {"tv_max_wg": 2, "tv_zrun": 5}, {"tv_max_wg": 1, "tv_no_replay": 1}, {"tv_zrun": 2, "tv_max_wg": 5}):
+                 {"tv_max_wg": 2, "tv_zrun": 5}, {"tv_max_wg": 1, "tv_no_replay": 1}, {"tv_zrun": 2, "tv_max_wg": 5},
+                 {"tv_zrun": 3, "tv_poison": 1}, {"tv_zrun": 6, "tv_max_wg": 2}, {"tv_exact_tiled": 1}, {"tv_exact_tiled": 1, "tv_zrun": 5}):
         with ctx.options(**opts):
             assert_bits_equal(ctx.tv_dense_stick(sal, dirs, 3.0, 4, 2.0 ** 0.5), want, "tensor %s" % opts)
             assert_bits_equal(ctx.tv_dense_stick(sal, dirs, 3.0, 4, 2.0 ** 0.5, mask, mask), want_m, "masked tensor %s" % opts)

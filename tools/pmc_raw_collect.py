@@ -5,7 +5,7 @@ import os
 import sys
 from collections import defaultdict
 
-KEYS = ("tv_box_kernel", "tvl_row_kernel", "tvl_scan_kernel", "tv_tiled_kernel", "gauss_fused_kernel", "ridge_score_kernel", "ridge_directions_kernel", "ridge_fused_kernel",
+KEYS = ("tv_boxx_kernel", "tv_box_kernel", "tvl_row_kernel", "tvl_scan_kernel", "tv_tiled_kernel", "gauss_fused_kernel", "ridge_score_kernel", "ridge_directions_kernel", "ridge_fused_kernel",
         "blob_candidates_kernel", "blob_verify_kernel", "tensor_saliency_kernel", "conv_march_kernel", "conv_row_kernel")
 
 

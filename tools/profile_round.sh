@@ -37,6 +37,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python3 tools/pmc_traffic_collect.py $out/g_FETCH_SIZE $out/g_WRITE_SIZE gauss_fused_kernel $out/gauss_traffic.json 8 $n "sigma=2 h=5, exact"
 python3 tools/pmc_traffic_collect.py $out/gf_FETCH_SIZE $out/gf_WRITE_SIZE gauss_fused_kernel $out/gauss_fma_traffic.json 8 $n "sigma=2 h=5, tolerance mode (gauss_fma)"
-python3 tools/pmc_traffic_collect.py $out/t_FETCH_SIZE $out/t_WRITE_SIZE tv_tiled_kernel $out/tv_traffic.json 40 $n "sigma_tv=8.66 h=12, 5 % salient, bench synthetic volume, exact kernel"
+python3 tools/pmc_traffic_collect.py $out/t_FETCH_SIZE $out/t_WRITE_SIZE tv_boxx_kernel $out/tv_traffic.json 40 $n "sigma_tv=8.66 h=12, 5 % salient, bench synthetic volume, exact kernel (exact form of tv_box.hip)"
 python3 tools/pmc_traffic_collect.py $out/tp_FETCH_SIZE $out/tp_WRITE_SIZE tv_box_kernel $out/tv_box_traffic.json 40 $n "sigma_tv=8.66 h=12, 5 % salient, bench synthetic volume, tolerance mode (tv_fma)"
 rm -rf $out/g_FETCH_SIZE $out/g_WRITE_SIZE $out/gf_FETCH_SIZE $out/gf_WRITE_SIZE $out/t_FETCH_SIZE $out/t_WRITE_SIZE $out/tp_FETCH_SIZE $out/tp_WRITE_SIZE

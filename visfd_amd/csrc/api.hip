@@ -259,7 +259,7 @@ const OptionDesc kOptions[] = {
     {"tv_zrun", &visfd_hip_options::tv_zrun, nullptr}, {"tv_fma", &visfd_hip_options::tv_fma, nullptr},
     {"gauss_fma", &visfd_hip_options::gauss_fma, nullptr}, {"eig_f32", &visfd_hip_options::eig_f32, nullptr},
     {"tv_no_replay", &visfd_hip_options::tv_no_replay, nullptr}, {"tv_max_wg", &visfd_hip_options::tv_max_wg, nullptr},
-    {"tv_poison", &visfd_hip_options::tv_poison, nullptr}, {"tv_no_fold", &visfd_hip_options::tv_no_fold, nullptr}, {"tv_reserve_wg", &visfd_hip_options::tv_reserve_wg, nullptr},
+    {"tv_poison", &visfd_hip_options::tv_poison, nullptr}, {"tv_no_fold", &visfd_hip_options::tv_no_fold, nullptr}, {"tv_exact_tiled", &visfd_hip_options::tv_exact_tiled, nullptr}, {"tv_reserve_wg", &visfd_hip_options::tv_reserve_wg, nullptr},
     {"blob_test_cap", nullptr, &visfd_hip_options::blob_test_cap}, {"debug", &visfd_hip_options::debug, nullptr},
 };
 bool set_option(visfd_hip_options* o, const char* name, int64_t value) {

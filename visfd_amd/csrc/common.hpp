@@ -70,6 +70,7 @@ struct visfd_hip_options {
                             //    eigenvalues and scores move by ~1 float ulp (eigen3.hpp); 0: the reference's double-precision angle
   int tv_zrun = 0;          // receiver planes per unit of work (0: default)
   int tv_no_replay = 0;     // 1: list every sender plane again for every receiver plane (nothing reused from the rings)
+  int tv_exact_tiled = 0;   // 1: exact tensor voting always on tv_tiled.hip (the round-2 kernel), never on the exact form of tv_box.hip
   int tv_no_fold = 0;       // tests: tolerance-mode voting never folds the saliency into the listed normals (tv_box.hip: vote_fma)
   int tv_poison = 0;        // tests: NaN bit patterns in LDS, ring memory and the output before tensor voting runs (tv_box.hip)
   int tv_reserve_wg = 0;    // workgroup slots the persistent voting grid leaves free (slab runs: the halo transport's kernels)

@@ -129,7 +129,7 @@ int dev_tv_tiled(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* 
 // declared in tv_box.hip
 int dev_tv_box(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* ten, const float* mask_src,
                const float* mask_dst, i64 nx, i64 ny, i64 nz, i64 z_out0, i64 z_out1, int h, const float4* dtab_box,
-               int exponent, bool* handled);
+               int exponent, bool* handled, bool exact);
 
 
 // The vote table of (sigma_tv, cutoff) on the device: float4 {w, rhat_x, rhat_y, rhat_z} per offset j in z, y, x order
@@ -149,19 +149,21 @@ static int tv_table_device(visfd_hip_ctx* ctx, float sigma_tv, float cutoff, int
   // tv_padded_row(h) entries (tiled kernel: LDS banks; pad entries are never read); then the tolerance mode's
   // {w, sqrt(2) rhat} in the slice layout of tv_box.hip (zero rows and zero row tails, which ARE read: common.hpp)
   const size_t sp = (size_t)tv_padded_row(h), m2 = n * n * sp;
+  // ... and the reference's {w, rhat} once more in that slice layout (the exact form of tv_box.hip)
   const size_t spb = (size_t)tv_box_row(h), nslb = (size_t)tv_box_slice(h), m3 = n * nslb;
-  std::vector<float4> tab(m + m2 + m3, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+  std::vector<float4> tab(m + m2 + 2 * m3, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
   const float rt2 = 1.41421356237309504880f;
   for (size_t k = 0; k < m; k++) {
     tab[k] = make_float4(w[k], rh[3 * k], rh[3 * k + 1], rh[3 * k + 2]);
     tab[m + (k / n) * sp + (k % n)] = tab[k];
-    tab[m + m2 + (k / (n * n)) * nslb + 4 + ((k / n) % n + 3) * spb + (k % n)] =
-        make_float4(w[k], rt2 * rh[3 * k], rt2 * rh[3 * k + 1], rt2 * rh[3 * k + 2]);
+    const size_t kb = (k / (n * n)) * nslb + 4 + ((k / n) % n + 3) * spb + (k % n);
+    tab[m + m2 + kb] = make_float4(w[k], rt2 * rh[3 * k], rt2 * rh[3 * k + 1], rt2 * rh[3 * k + 2]);
+    tab[m + m2 + m3 + kb] = tab[k];
   }
   float4* dtab = nullptr;
   ctx->tv_table_dev = nullptr;
-  VH_TRY(ws(ctx, WS_TVTAB, m + m2 + m3, &dtab));
-  VH_HIP(hipMemcpyAsync(dtab, tab.data(), sizeof(float4) * (m + m2 + m3), hipMemcpyHostToDevice, ctx->stream));
+  VH_TRY(ws(ctx, WS_TVTAB, m + m2 + 2 * m3, &dtab));
+  VH_HIP(hipMemcpyAsync(dtab, tab.data(), sizeof(float4) * (m + m2 + 2 * m3), hipMemcpyHostToDevice, ctx->stream));
   VH_HIP(hipStreamSynchronize(ctx->stream));
   ctx->tv_table_dev = reinterpret_cast<float*>(dtab);
   ctx->tv_table_h = h;
@@ -191,7 +193,13 @@ int dev_tv_dense_stick(visfd_hip_ctx* ctx, const float* sal, const float* dir, f
   // (tv_box.hip); windows and vote forms it does not take fall through to the exact kernels
   if (!ctx->opt.tv_dense && ctx->opt.tv_fma && !curves)
     VH_TRY(dev_tv_box(ctx, sal, dir, ten, mask_src, mask_dst, nx, ny, nz, z_out0, z_out1, h, dtab + m_packed + m_padded, exponent,
-                      &handled));
+                      &handled, false));
+  if (handled) return VISFD_HIP_OK;
+  // exact arithmetic in the same kernel structure (surfaces, exponent 2 or 4, no source mask, finite saliencies; option
+  // tv_exact_tiled = 1 keeps the round-2 kernel)
+  if (!ctx->opt.tv_dense && !ctx->opt.tv_exact_tiled && !curves)
+    VH_TRY(dev_tv_box(ctx, sal, dir, ten, mask_src, mask_dst, nx, ny, nz, z_out0, z_out1, h,
+                      dtab + m_packed + m_padded + (size_t)(2 * h + 1) * (size_t)tv_box_slice(h), exponent, &handled, true));
   if (handled) return VISFD_HIP_OK;
   if (!ctx->opt.tv_dense)
     VH_TRY(dev_tv_tiled(ctx, sal, dir, ten, mask_src, mask_dst, nx, ny, nz, z_out0, z_out1, h, dtab + m_packed, exponent, curves,

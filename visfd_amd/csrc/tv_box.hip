@@ -1,5 +1,7 @@
 // tv_box.hip -- dense stick tensor voting in TOLERANCE MODE (context option tv_fma) for gfx950
-// (reference lib/visfd/feature.hpp:1914-2037 and :2217-2384; surfaces with angular exponent 2 or 4).
+// (reference lib/visfd/feature.hpp:1914-2037 and :2217-2384; surfaces with angular exponent 2 or 4) -- and, further down,
+// the EXACT form of the same kernel structure (tv_boxx_kernel: bit-identical to tv_tiled.hip, the default exact route for
+// surfaces without a source mask).
 //
 // BASELINE.json's north_star asks for vote tensors within 1e-5 relative, not for the reference's bits.  Giving up the
 // bits buys fused multiply-adds (a vote is 19 vector instructions, vote_fma below) and a free order of accumulation.
@@ -528,6 +530,375 @@ tv_box_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
 #endif
 }
 
+// =================================================================================================================
+// The EXACT form of the same kernel structure (round 4): the reference's 32 multiplies and adds per vote in its order
+// (feature.hpp:2312-2377, no FMA), every receiver taking its votes in the reference's order (sender planes z+h .. z-h, rows and
+// columns descending), bit-identical to csrc/tv_tiled.hip -- which stays the general exact kernel (source masks, curve mode,
+// odd exponents, weight sums, non-finite saliencies) -- for the common case: surfaces, exponent 2 or 4, no source mask.
+// What carries over from the tolerance kernel: the launch-wide sender lists (already in vote order), the box-tested hit lists,
+// the zero-padded slices (a zero-weight tap votes (s * 0) * dec = +-0 times finite numbers: adding it leaves a sum's bits,
+// as the rim taps of tv_tiled's superset test already do), the branch-free pipelined vote loop.  What cannot: the order
+// of accumulation is fixed, so
+//   * a receiver has ONE stream: lanes 0-31 are the sub-patch x 0..3 and lanes 32-63 the sub-patch x 4..7 of a half, each
+//     with its own hit list; a step serves the k-th hit of both (the shorter list is padded with null senders);
+//   * sender planes come one at a time with jz ascending (2h+2 steps per receiver pair, no mirror pairing), each needing the
+//     slices jz and jz+1 -- one new slice per step; TWO receiver pairs (z, z+1) and (z+2, z+3) share a step's two slices
+//     (their sender planes differ by two), which gives a step two lists, as in the tolerance kernel.
+constexpr int NPAIR = 2;
+constexpr int HX = 72;    // hit entries per (wave, sub-patch): <= 64 hits of a chunk + the read-ahead of the vote loop
+
+template <int MODE>
+__device__ __forceinline__ void vote_exact(float (&T)[6], const f4v& snd /* sal, n */, const f4v& tw /* w, rhat */) {
+  const float u = (tw.y * snd.y + tw.z * snd.z) + tw.w * snd.w;
+  const float ux2 = u * 2.0f;
+  const float u2 = u * u;
+  const float c2 = 1.0f - u2;
+  const float dec = (MODE == 0) ? c2 * c2 : c2;
+  const float m0 = ux2 * tw.y - snd.y, m1 = ux2 * tw.z - snd.z, m2 = ux2 * tw.w - snd.w;
+  const float bse = (snd.x * tw.x) * dec;
+  const float b0 = bse * m0, b1 = bse * m1, b2 = bse * m2;
+  const float p00 = b0 * m0, p01 = b0 * m1, p02 = b0 * m2, p11 = b1 * m1, p12 = b1 * m2, p22 = b2 * m2;
+  asm("v_add_f32 %0, %0, %1" : "+v"(T[0]) : "v"(p00));
+  asm("v_add_f32 %0, %0, %1" : "+v"(T[3]) : "v"(p01));
+  asm("v_add_f32 %0, %0, %1" : "+v"(T[5]) : "v"(p02));
+  asm("v_add_f32 %0, %0, %1" : "+v"(T[1]) : "v"(p11));
+  asm("v_add_f32 %0, %0, %1" : "+v"(T[4]) : "v"(p12));
+  asm("v_add_f32 %0, %0, %1" : "+v"(T[2]) : "v"(p22));
+}
+
+// (the vote loop of vote_hits with the exact vote; one list per half wave, entries at hp)
+template <int MODE>
+__device__ __forceinline__ void vote_hits_exact(float (&T)[6], unsigned hp, int nst, unsigned r16) {
+  u4v h0 = lds_u4(hp), h1 = lds_u4(hp + 16u);
+  f4v sa = lds_f4(h0.x), ta = lds_f4(r16 - h0.y);
+  f4v sb, tb;
+  int k = 0;
+  for (;;) {   // uniform
+    sb = lds_f4(h0.z);
+    tb = lds_f4(r16 - h0.w);
+    vote_exact<MODE>(T, sa, ta);
+    if (++k >= nst) break;
+    sa = lds_f4(h1.x);
+    ta = lds_f4(r16 - h1.y);
+    h0 = lds_u4(hp + 32u);
+    vote_exact<MODE>(T, sb, tb);
+    if (++k >= nst) break;
+    sb = lds_f4(h1.z);
+    tb = lds_f4(r16 - h1.w);
+    vote_exact<MODE>(T, sa, ta);
+    if (++k >= nst) break;
+    sa = lds_f4(h0.x);
+    ta = lds_f4(r16 - h0.y);
+    h1 = lds_u4(hp + 48u);
+    hp += 32u;
+    vote_exact<MODE>(T, sb, tb);
+    if (++k >= nst) break;
+  }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6)))
+tv_boxx_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
+               const float4* __restrict__ table /* [2h+1] slices of nsl entries: w, rhat at j, zero padding */,
+               BoxParams p, unsigned* __restrict__ tile_counter, unsigned ntiles,
+               const float4* __restrict__ lst_ent, const unsigned* __restrict__ lst_pos, const unsigned* __restrict__ lst_rows) {
+  __shared__ __attribute__((aligned(16))) float4 l_ent[LSLOTS + 1];
+  __shared__ __attribute__((aligned(16))) uint2 l_pos[LSLOTS];
+  __shared__ __attribute__((aligned(16))) uint2 l_hit[NW][NSUB][HX];
+  __shared__ unsigned claimed_tile;
+  __shared__ unsigned plane_beg[88];         // per sender plane of a pass (slot = plane - (rz - h), < 2h + 4 <= 84)
+  __shared__ int plane_cnt[88];
+  __shared__ int rho_tab[44];
+  extern __shared__ __attribute__((aligned(16))) unsigned char slices[];   // two table slices: jz in slot (jz + h + 1) & 1
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = p.h;
+  const int SP = p.sp;
+  const int nsl = p.nsl;
+  const i64 plane = (i64)p.nx * p.ny;
+  const i64 nvox = plane * p.nz;
+  int slot_has[2] = {-1, -1};                // which slice (as jz + h + 1 = 0 .. 2h+2; 0 and 2h+2: zeros) each LDS slot holds
+  float4* const sl4 = reinterpret_cast<float4*>(slices);
+  const unsigned ent_base = lds_addr(l_ent);
+  const unsigned null_ent = ent_base + 16u * (unsigned)LSLOTS;
+
+#ifdef VH_TV_STAMPS
+  unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef VH_TV_COUNT
+  unsigned cnt_tested = 0, cnt_hits = 0, cnt_steps = 0;
+#endif
+  // lane -> receiver: sub-patch = lane >> 5 (x 0..3 or 4..7 of a half); within it as in the tolerance kernel
+  const int sub = lane >> 5;
+  const int qd = (lane & 31) >> 2;
+  const int lcol = lane & 3, lrow = qd >> 1, lpl = (0x96 >> qd) & 1;
+
+  if (tid == 0) l_ent[LSLOTS] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (tid <= h) {
+    const int r2 = h * h - tid * tid;
+    int rho = (int)__builtin_sqrtf((float)r2);
+    while (rho * rho > r2) rho--;
+    while ((rho + 1) * (rho + 1) <= r2) rho++;
+    rho_tab[tid] = rho;
+  }
+  for (int i = tid; i < NW * NSUB * HX; i += NT) (&l_hit[0][0][0])[i] = make_uint2(null_ent, 0u);
+
+  for (;;) {
+    if (tid == 0) claimed_tile = atomicAdd(tile_counter, 1u);
+    __syncthreads();
+    unsigned b = claimed_tile;
+    __syncthreads();
+    if (b >= ntiles) break;
+    const int tile_x = b % p.tiles_x;
+    b /= p.tiles_x;
+    const int tile_y = b % p.tiles_y;
+    const int z_run0 = p.z_out0 + (int)(b / p.tiles_y) * p.zrun;
+    const int z_run1 = min(z_run0 + p.zrun, p.z_out1);
+    const int x0 = tile_x * TX, y0 = tile_y * TY;
+
+    auto fresh_lane = [&]() -> unsigned {
+      unsigned ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+      asm volatile("" : "+v"(ln));
+      return ln;
+    };
+
+    float TT[NPAIR][NH][6];
+
+    // TEST + VOTE of entries [i0, i1) of one list (LDS slots from `base`) for the receiver pair whose sums are T2: 64 entries
+    // at a time, each tested against the boxes of the two sub-patches of a half; the hits of sub-patch s go, in list order, to
+    // l_hit[wave][s][0..]; lanes 32 s .. 32 s + 31 then vote them in that order.
+    auto test_vote = [&](float (&T2)[NH][6], int base, int i0, int i1, unsigned r16, float cy, float rr, unsigned null_e16) {
+      const unsigned hb = lds_addr(&l_hit[wave][0][0]);
+      for (int c = i0; c < i1; c += 64) {   // uniform
+        const int ln = (int)fresh_lane();
+        const int e = c + ln;
+        uint2 pw = make_uint2(0xffffffffu, 0u);
+        if (e < i1) pw = l_pos[base + e];
+        const float exf = (float)(pw.x & 0xffu), eyf = (float)((pw.x >> 8) & 0xffu);
+        const float dy = fmaxf(__builtin_fabsf(eyf - cy) - 1.5f, 0.0f);
+        const float dy2 = dy * dy;
+        const unsigned ent = ent_base + 16u * (unsigned)(base + e);
+        auto half = [&](auto HH) {
+          constexpr int hh = decltype(HH)::value;
+          const float cx0 = (float)(h + 8 * hh) + 1.5f;
+          int nh[NSUB];
+#pragma unroll
+          for (int s = 0; s < NSUB; s++) {
+            const float dx = fmaxf(__builtin_fabsf(exf - (cx0 + 4.0f * (float)s)) - 1.5f, 0.0f);
+            const bool hit = __builtin_fmaf(dx, dx, dy2) <= rr;     // (small integers and halves: exact either way)
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
+            nh[s] = __builtin_popcountll(bal);
+            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+            // every slot a step may vote holds the null sender first (the two lists of a half are voted to the longer one's
+            // length); the hits then overwrite their slots: LDS operations of a wave execute in order
+            lds_store_u2(hb + (unsigned)(s * HX * 8) + (unsigned)ln * 8u, null_ent, null_e16);
+            if (hit) lds_store_u2(hb + (unsigned)(s * HX * 8) + rank * 8u, ent, pw.y - (unsigned)(128 * hh));
+          }
+          __builtin_amdgcn_wave_barrier();
+          asm volatile("" ::: "memory");
+          const int nst = max(nh[0], nh[1]);
+#ifdef VH_TV_COUNT
+          cnt_hits += (unsigned)(nh[0] + nh[1]);
+          cnt_steps += (unsigned)nst;
+#endif
+          if (nst > 0) {   // uniform
+            const unsigned hp = hb + (fresh_lane() >> 5) * (unsigned)(HX * 8);
+            __builtin_amdgcn_s_setprio(1);
+            vote_hits_exact<MODE>(T2[hh], hp, nst, r16);
+            __builtin_amdgcn_s_setprio(0);
+          }
+          asm volatile("" ::: "memory");
+          __builtin_amdgcn_wave_barrier();
+        };
+#ifdef VH_TV_COUNT
+        cnt_tested += (unsigned)min(64, i1 - c);
+#endif
+        half(std::integral_constant<int, 0>{});
+        half(std::integral_constant<int, 1>{});
+      }
+    };
+
+    const int row_lo = max(y0 - h, 0), row_hi = min(y0 + TY - 1 + h, p.ny - 1);
+    for (int rz = z_run0; rz < z_run1; rz += 2 * NPAIR) {
+      // sender planes that reach the LIVE receivers of this pass
+      const int sz_hi = min(min(rz + 2 * NPAIR - 1, z_run1 - 1) + h, p.nz - 1), sz_lo = max(rz - h, 0);
+      __syncthreads();
+      if (tid < sz_hi - sz_lo + 1) {
+        const size_t r0 = ((size_t)(sz_lo + tid - p.zl0) * (size_t)(p.ny + 1)) * (size_t)p.tiles_x + (size_t)tile_x;
+        const unsigned beg = lst_rows[r0 + (size_t)(row_hi + 1) * (size_t)p.tiles_x];
+        const unsigned end = lst_rows[r0 + (size_t)row_lo * (size_t)p.tiles_x];
+        plane_beg[sz_lo + tid - (rz - h)] = beg;
+        plane_cnt[sz_lo + tid - (rz - h)] = (int)(end - beg);
+      }
+#pragma unroll
+      for (int q = 0; q < NPAIR; q++)
+#pragma unroll
+        for (int pp = 0; pp < NH; pp++)
+#pragma unroll
+          for (int k = 0; k < 6; k++) TT[q][pp][k] = 0.0f;
+      __syncthreads();
+      VH_STAMP(0);
+
+      // step t = 0 .. 2h+1: pair q (receiver planes rz + 2q, rz + 2q + 1) meets sender plane rz + 2q + 1 + h - t at
+      // jz = t - h - 1 (lower plane) and t - h (upper plane), ascending as in the reference.  Slice key = jz + h + 1.
+      auto plane_slot = [&](int sz) -> int { return sz - (rz - h); };
+      for (int t = 0; t <= 2 * h + 1; t++) {
+        int lsz[NLIST], lcnt[NLIST];
+#pragma unroll
+        for (int q = 0; q < NPAIR; q++) {
+          lsz[q] = rz + 2 * q + 1 + h - t;
+          lcnt[q] = (lsz[q] <= sz_hi && lsz[q] >= sz_lo) ? __builtin_amdgcn_readfirstlane(plane_cnt[plane_slot(lsz[q])]) : 0;
+        }
+        if (max(lcnt[0], lcnt[1]) == 0) continue;   // uniform
+        int need[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          const int j = t + k;             // key of the lower (k = 0) / upper (k = 1) receiver plane's slice
+          need[k] = (slot_has[j & 1] != j) ? j : -1;
+          if (need[k] >= 0) slot_has[j & 1] = j;
+        }
+        // the nearer of a pair's two receiver planes: |t - h - 1| or |t - h| planes away
+        const int dmin = min(abs(t - h - 1), abs(t - h));
+        const int rho = __builtin_amdgcn_readfirstlane(rho_tab[dmin]);
+        const float rr = (float)(h * h - dmin * dmin);
+        int pre[NLIST + 1];
+        pre[0] = 0;
+#pragma unroll
+        for (int k = 0; k < NLIST; k++) pre[k + 1] = pre[k] + lcnt[k];
+        const int total = pre[NLIST];
+        unsigned pl[NLIST];
+#pragma unroll
+        for (int k = 0; k < NLIST; k++) pl[k] = lcnt[k] > 0 ? __builtin_amdgcn_readfirstlane(plane_beg[plane_slot(lsz[k])]) : 0u;
+        for (int done = 0; done < total; done += NT) {   // uniform
+          int c[NLIST], len[NLIST];
+#pragma unroll
+          for (int k = 0; k < NLIST; k++) {
+            const int lo = min(max(pre[k], done), done + NT), hi = min(pre[k + 1], done + NT);
+            c[k] = lo - done;
+            len[k] = max(hi - lo, 0);
+          }
+          const int g = done + tid;
+          int k_me = 0;
+#pragma unroll
+          for (int k = 1; k < NLIST; k++) k_me += (g >= pre[k]) ? 1 : 0;
+          const bool have = g < total;
+          unsigned idx = pl[0] + (unsigned)g;
+#pragma unroll
+          for (int k = 1; k < NLIST; k++)
+            if (k_me == k) idx = pl[k] + (unsigned)(g - pre[k]);
+          float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          unsigned m = 0u;
+          if (have) {
+            a = lst_ent[idx];
+            m = lst_pos[idx];
+          }
+          const int ft = wave * 64 + (int)fresh_lane();
+          const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          float4 s00 = z4, s01 = z4, s10 = z4, s11 = z4;
+          // (keys 0 and 2h+2 are the slices beyond the window: zeros)
+          const bool ld0 = done == 0 && need[0] >= 1 && need[0] <= 2 * h + 1, ld1 = done == 0 && need[1] >= 1 && need[1] <= 2 * h + 1;
+          if (ld0) {
+            const float4* src4 = table + (i64)(need[0] - 1) * nsl;
+            if (ft < nsl) s00 = src4[ft];
+            if (ft + NT < nsl) s01 = src4[ft + NT];
+          }
+          if (ld1) {
+            const float4* src4 = table + (i64)(need[1] - 1) * nsl;
+            if (ft < nsl) s10 = src4[ft];
+            if (ft + NT < nsl) s11 = src4[ft + NT];
+          }
+          if (done == 0) {
+            if (need[0] >= 0) {
+              float4* dst4 = sl4 + (need[0] & 1) * nsl;
+              if (ft < nsl) dst4[ft] = s00;
+              if (ft + NT < nsl) dst4[ft + NT] = s01;
+              const float4* src4 = table + (i64)(need[0] - 1) * nsl;
+              for (int i = ft + 2 * NT; i < nsl; i += NT) dst4[i] = ld0 ? src4[i] : z4;
+            }
+            if (need[1] >= 0) {
+              float4* dst4 = sl4 + (need[1] & 1) * nsl;
+              if (ft < nsl) dst4[ft] = s10;
+              if (ft + NT < nsl) dst4[ft + NT] = s11;
+              const float4* src4 = table + (i64)(need[1] - 1) * nsl;
+              for (int i = ft + 2 * NT; i < nsl; i += NT) dst4[i] = ld1 ? src4[i] : z4;
+            }
+          }
+          if (have) {
+            l_ent[tid] = a;
+            const unsigned ex = m & 0xffu, ey = (m >> 8) - (unsigned)(y0 - h);
+            l_pos[tid] = make_uint2(ex | (ey << 8), 16u * (ey * (unsigned)SP + ex));
+          }
+          VH_STAMP(1);
+          __syncthreads();   // lists (and slices) complete
+          VH_STAMP(2);
+          int i0[NLIST], i1[NLIST];
+          {
+            const int hi_row = 4 * wave + h + 3 + rho, lo_row = 4 * wave + h - rho;
+#pragma unroll
+            for (int k = 0; k < NLIST; k++) {
+              int above = 0, upto = 0;
+              for (int j = 0; j < len[k]; j += 64) {   // uniform
+                int ey = -1;
+                if (j + lane < len[k]) ey = (int)((l_pos[c[k] + j + lane].x >> 8) & 0xffu);
+                above += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ey > hi_row));
+                upto += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ey >= lo_row));
+              }
+              i0[k] = above;
+              i1[k] = upto;
+            }
+          }
+          if (i1[0] > i0[0] || i1[1] > i0[1]) {   // uniform
+            const float cy = (float)(4 * wave + h) + 1.5f;
+            const unsigned ln = fresh_lane();
+            const int fq = (int)((ln & 31u) >> 2);
+            const int fcol = (int)(ln & 3u) + 4 * (int)(ln >> 5), frow = fq >> 1, fpl = (0x96 >> fq) & 1;
+            // this lane's table entry of a sender at region position (0, 0), left half (its sub-patch's 4 columns are in fcol)
+            const unsigned r16_0 = lds_addr(slices) + 16u * (unsigned)(4 + (4 * wave + frow + 2 * h + YPAD) * SP + fcol + 2 * h);
+            const unsigned null_e16 = 16u * (unsigned)((4 * wave + h) * SP + h);
+            const unsigned r16 = r16_0 + (unsigned)(16 * nsl) * (unsigned)((t + fpl) & 1);
+            if (i1[0] > i0[0]) test_vote(TT[0], c[0], i0[0], i1[0], r16, cy, rr, null_e16);
+            if (i1[1] > i0[1]) test_vote(TT[1], c[1], i0[1], i1[1], r16, cy, rr, null_e16);
+          }
+          VH_STAMP(3);
+          __syncthreads();   // everyone done reading before the lists or the slices are refilled
+          VH_STAMP(4);
+        }
+      }
+
+      // ---- the pass's sums ----
+#pragma unroll
+      for (int q = 0; q < NPAIR; q++)
+#pragma unroll
+        for (int pp = 0; pp < NH; pp++) {
+          const int rx = x0 + 8 * pp + 4 * sub + lcol, ry = y0 + 4 * wave + lrow, rzl = rz + 2 * q + lpl;
+          const bool in = rx < p.nx && ry < p.ny && rzl < z_run1;
+          const i64 rc = (i64)rzl * plane + (i64)ry * p.nx + rx;
+          const bool live = in && !(mask_dst && mask_dst[in ? rc : 0] == 0.0f);
+          if (live) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) __builtin_nontemporal_store(TT[q][pp][k], &ten[k * nvox + rc]);
+          }
+        }
+    }   // next pass of the run
+  }   // next unit
+#ifdef VH_TV_STAMPS
+  VH_STAMP(5);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) atomicAdd(&g_box_stamps[i], st_acc[i]);
+  }
+#endif
+#ifdef VH_TV_COUNT
+  if (lane == 0) {
+    atomicAdd(&g_box_counts[0], (unsigned long long)cnt_tested);
+    atomicAdd(&g_box_counts[1], (unsigned long long)cnt_hits);
+    atomicAdd(&g_box_counts[2], (unsigned long long)cnt_steps);
+  }
+#endif
+}
+
 // ---- THE SENDER LISTS, once per launch ---------------------------------------------------------------------------------
 // For every listed plane z and every tile column tx (TX = 16 receiver columns), the salient, unmasked senders of the columns
 // [TX tx - h, TX tx + TX + h) -- everything a tile of that column can reach in x -- as one list in DESCENDING (y, x) (the order
@@ -608,6 +979,7 @@ tvl_row_kernel(const float* __restrict__ sal, const float* __restrict__ dir, con
       if (!WRITE && f) {
         const float s = mask_src ? v[k] * m[k] : v[k];
         if (!(s > 0.0f)) atomicOr(neg_flag, 1u);   // (rare: negative peak heights, masks with negative values, NaN)
+        if (!(__builtin_fabsf(s) <= 3.402823466e38f)) atomicOr(neg_flag, 2u);   // non-finite: the exact form declines
       }
     }
   }
@@ -642,7 +1014,8 @@ tvl_row_kernel(const float* __restrict__ sal, const float* __restrict__ dir, con
       const unsigned t = (unsigned)__builtin_popcount(w & ((1u << sft) - 1u));
       if (k >= t) { k -= t; x += sft; w >>= sft; }
     }
-    float4 q = make_float4(sal[row + x] * (MODE == 0 ? 0.25f : 0.5f), dir[row + x], dir[nvox + row + x], dir[2 * nvox + row + x]);
+    // (MODE 1: the exact form's lists carry the saliency itself)
+    float4 q = make_float4(sal[row + x] * (MODE == 0 ? 0.25f : (MODE == 2 ? 0.5f : 1.0f)), dir[row + x], dir[nvox + row + x], dir[2 * nvox + row + x]);
     if (mask_src) q.x = q.x * mask_src[row + x];
     if (fold) {   // a = s^(1/6) (exponent 4) or s^(1/4) (exponent 2), rounded once from double
       const double r2 = sqrt((double)q.x);
@@ -701,11 +1074,14 @@ __global__ void __launch_bounds__(256) lds_poison_kernel(unsigned* sink) {
 
 // Tolerance-mode tensor voting (surfaces, exponent 2 or 4).  dtab_box: the {w, sqrt(2) rhat} table on the device in this
 // kernel's slice layout (tv.hip: tv_table_device).
+// exact != 0: the exact form (tv_boxx_kernel) with dtab_box = the reference's {w, rhat} in the same slice layout; it declines
+// source masks and non-finite saliencies (the caller falls back to tv_tiled.hip).
 int dev_tv_box(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* ten, const float* mask_src,
                const float* mask_dst, i64 nx, i64 ny, i64 nz, i64 z_out0, i64 z_out1, int h, const float4* dtab_box,
-               int exponent, bool* handled) {
+               int exponent, bool* handled, bool exact) {
   *handled = false;
   if (exponent != 2 && exponent != 4) return VISFD_HIP_OK;
+  if (exact && mask_src) return VISFD_HIP_OK;
   if (h < 1 || h > 40) return VISFD_HIP_OK;
   if (nx * ny >= (1LL << 29) || nx > 32 * LWORDS_MAX || ny >= (1 << 24)) return VISFD_HIP_OK;
   hipStream_t st = ctx->stream;
@@ -731,6 +1107,7 @@ int dev_tv_box(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* te
   if (nblk <= 0) { *handled = true; return VISFD_HIP_OK; }
   const size_t lds = 2 * slice_bytes;
   const size_t lds_static = sizeof(float4) * (LSLOTS + 1) + sizeof(uint2) * LSLOTS + sizeof(uint2) * NW * NSUB * 2 * HCAP + 1536;
+  static_assert(2 * HCAP == HX, "the two kernels' hit lists take the same LDS");
   if (lds + lds_static > 150 * 1024) return VISFD_HIP_OK;   // window too wide: the caller falls back
 
   // ---- the sender lists of the planes the receiver planes [z_out0, z_out1) reach -------------------------------------------
@@ -750,7 +1127,8 @@ int dev_tv_box(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* te
   const unsigned row_blocks = (unsigned)(((i64)g.nzl * ny + LNT / 64 - 1) / (LNT / 64));
 #define VH_TVL_ROWS(WR, ENT, POS)                                                                                         \
   do {                                                                                                                    \
-    if (exponent == 4) tvl_row_kernel<WR, 0><<<dim3(row_blocks), dim3(LNT), 0, st>>>(sal, dir, mask_src, g, rows, ENT, POS, counter + 6, fold); \
+    if (exact) tvl_row_kernel<WR, 1><<<dim3(row_blocks), dim3(LNT), 0, st>>>(sal, dir, mask_src, g, rows, ENT, POS, counter + 6, 0);             \
+    else if (exponent == 4) tvl_row_kernel<WR, 0><<<dim3(row_blocks), dim3(LNT), 0, st>>>(sal, dir, mask_src, g, rows, ENT, POS, counter + 6, fold); \
     else tvl_row_kernel<WR, 2><<<dim3(row_blocks), dim3(LNT), 0, st>>>(sal, dir, mask_src, g, rows, ENT, POS, counter + 6, fold);             \
   } while (0)
   int fold = 0;
@@ -764,6 +1142,7 @@ int dev_tv_box(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* te
   const unsigned long long total = tot2[0];
   fold = ((unsigned)tot2[1] & 1u) ? 0 : 1;   // every listed saliency positive: the 18-instruction vote
   if (ctx->opt.tv_no_fold) fold = 0;         // (tests: the general form on positive saliencies too)
+  if (exact && ((unsigned)tot2[1] & 2u)) return VISFD_HIP_OK;   // a non-finite saliency: the zero-padded slices would spread it
   if (total >= (1ull << 32) - 2048) return VISFD_HIP_OK;   // 32-bit entry indices: the caller falls back
   unsigned char* lists = nullptr;
   if (ws(ctx, WS_TVSCRATCH, (size_t)(total + 16) * 20, &lists) != VISFD_HIP_OK) { set_error(""); (void)hipGetLastError(); return VISFD_HIP_OK; }
@@ -795,9 +1174,18 @@ int dev_tv_box(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* te
     tv_box_kernel<MD, FD><<<dim3((unsigned)ngrid), dim3(NT), lds, st>>>(ten, mask_dst, dtab_box, p, counter, (unsigned)nblk, \
                                                                        lst_ent, lst_pos, rows);                        \
   } while (0)
-  if (exponent == 4) { if (fold) VH_BOX_LAUNCH(0, true); else VH_BOX_LAUNCH(0, false); }
-  else               { if (fold) VH_BOX_LAUNCH(2, true); else VH_BOX_LAUNCH(2, false); }
+#define VH_BOXX_LAUNCH(MD)                                                                                             \
+  do {                                                                                                                 \
+    VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tv_boxx_kernel<MD>),                                     \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                 \
+    tv_boxx_kernel<MD><<<dim3((unsigned)ngrid), dim3(NT), lds, st>>>(ten, mask_dst, dtab_box, p, counter, (unsigned)nblk, \
+                                                                    lst_ent, lst_pos, rows);                           \
+  } while (0)
+  if (exact)              { if (exponent == 4) VH_BOXX_LAUNCH(0); else VH_BOXX_LAUNCH(2); }
+  else if (exponent == 4) { if (fold) VH_BOX_LAUNCH(0, true); else VH_BOX_LAUNCH(0, false); }
+  else                    { if (fold) VH_BOX_LAUNCH(2, true); else VH_BOX_LAUNCH(2, false); }
 #undef VH_BOX_LAUNCH
+#undef VH_BOXX_LAUNCH
   VH_HIP(hipGetLastError());
 #ifdef VH_TV_COUNT
   {
