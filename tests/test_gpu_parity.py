@@ -282,6 +282,21 @@ def test_blob_many_candidates(ctx, oracle):
     assert_bits_equal(volgen.sort_blobs(a[1], False), volgen.sort_blobs(b[1], False), "noise maxima")
 
 
+def test_blob_pure_noise_fine_scales(ctx, oracle):
+    """Pure noise at scales below a voxel: about one voxel in thirty passes the scan's 3x3x3 pre-test (its candidate buffer
+    is flushed many times per march); masked and unmasked, rows that span several 64-wide tiles with a ragged last one."""
+    shape = (24, 21, 300)
+    src = volgen.noise_volume(shape, seed=77)
+    mask = volgen.block_mask(shape, seed=78)
+    sig = np.array([0.6, 0.7, 0.8], np.float32)
+    for m in (None, mask):
+        b = oracle.blob_dog(src, sig, m, None, 0.02, 2.5)
+        a = ctx.blob_dog(src, sig, m, None, 0.02, 2.5)
+        assert len(b[0]) + len(b[1]) > 100
+        assert_bits_equal(volgen.sort_blobs(a[0], True), volgen.sort_blobs(b[0], True), "minima")
+        assert_bits_equal(volgen.sort_blobs(a[1], False), volgen.sort_blobs(b[1], False), "maxima")
+
+
 def test_blob_tiny_images(ctx, oracle):
     src = volgen.noise_volume((2, 9, 9), seed=3)
     a = ctx.blob_dog(src, np.array([1, 1.3, 1.7], np.float32), None, None, 0.02, 2.5)

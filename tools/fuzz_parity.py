@@ -99,13 +99,21 @@ def main():
                     opts = {"tv_max_wg": int(rng.integers(1, 5)), "tv_zrun": int(rng.integers(1, 9))}
                     if rng.random() < 0.3:
                         opts["tv_no_replay"] = 1
+                if rng.random() < 0.3:     # the general exact kernel instead of the box kernel's exact form
+                    opts["tv_exact_tiled"] = 1
+                if rng.random() < 0.3:
+                    opts["tv_poison"] = 1
+                # a source mask sends the exact run to tv_tiled.hip: half of the masked cases mask the receivers only
+                msrc = mask if (mask is None or rng.random() < 0.5) else None
                 with ctx.options(**opts):
-                    got = ctx.tv_dense_stick(sal, d, sigma_tv, ex, 2.0 ** 0.5, mask, mask)
-                want = O.tv_dense_stick(sal, d, sigma_tv, ex, 2.0 ** 0.5, mask, mask)
-                ok = bits_equal(got, want)
-                desc = "tv shape=%s sigma_tv=%g exponent=%d mask=%s opts=%s" % (shape, sigma_tv, ex, mask is not None, opts)
+                    got = ctx.tv_dense_stick(sal, d, sigma_tv, ex, 2.0 ** 0.5, msrc, mask)
+                want = O.tv_dense_stick(sal, d, sigma_tv, ex, 2.0 ** 0.5, msrc, mask)
+                ok = bits_equal(got, want) if mask is None else bits_equal(got[mask != 0], want[mask != 0])
+                desc = "tv shape=%s sigma_tv=%g exponent=%d mask=%s source mask=%s opts=%s" % (shape, sigma_tv, ex, mask is not None,
+                                                                                        msrc is not None, opts)
                 with ctx.options(tv_fma=1, **opts):     # the tolerance kernel on the same case
-                    okf = close_rel(ctx.tv_dense_stick(sal, d, sigma_tv, ex, 2.0 ** 0.5, mask, mask), want)
+                    gotf = ctx.tv_dense_stick(sal, d, sigma_tv, ex, 2.0 ** 0.5, msrc, mask)
+                    okf = close_rel(gotf, want) if mask is None else close_rel(gotf[mask != 0], want[mask != 0])
                 counts["tv_fma"] += 1
                 if not okf:
                     bad.append("tv_fma " + desc)
