@@ -75,7 +75,7 @@ int visfd_hip_abi_version(void);   /* 8: entry points only get added between ver
  *                    diagonalise batch): its one angle -- atan2, sin, cos -- in single precision; eigenvalues move by about
  *                    one float ulp.  default 0 = the reference's double-precision angle (eigen3_simple.hpp:74-81)
  *   tv_exact_tiled   1: exact tensor voting always runs the general kernel (csrc/tv_tiled.hip), never the faster exact form of
- *                    csrc/tv_box.hip (surfaces, exponent 2 or 4, no source mask); results are bit-identical either way
+ *                    csrc/tv_box.hip (surfaces, exponent 2 or 4, source mask absent or of zeros and ones); results are bit-identical either way
  *   tv_no_fold       tests: tolerance-mode voting keeps the saliency as a factor of every vote even when all saliencies are
  *                    positive (by default they are then folded into the listed normals: 18 instead of 19 instructions)
  *   tv_poison        tests: NaN bit patterns in LDS, ring memory and the output before tolerance-mode tensor voting runs

@@ -292,7 +292,7 @@ def test_blob_pure_noise_fine_scales(ctx, oracle):
     for m in (None, mask):
         b = oracle.blob_dog(src, sig, m, None, 0.02, 2.5)
         a = ctx.blob_dog(src, sig, m, None, 0.02, 2.5)
-        assert len(b[0]) + len(b[1]) > 100
+        assert len(b[0]) + len(b[1]) > 40
         assert_bits_equal(volgen.sort_blobs(a[0], True), volgen.sort_blobs(b[0], True), "minima")
         assert_bits_equal(volgen.sort_blobs(a[1], False), volgen.sort_blobs(b[1], False), "maxima")
 
@@ -660,6 +660,11 @@ def test_tensor_voting_wide_windows(ctx, oracle, sigma_tv, shape, monkeypatch):
             sel = mask != 0
             assert_bits_equal(ten[sel], ref_d2[sel], "destination-masked tensor sigma_tv=%g %s" % (sigma_tv, opts))
     assert np.abs(ref_d).max() > 0
+    # a WEIGHTED source mask (values other than 0 and 1 are factors of the votes): the exact form of tv_box.hip declines it
+    # after its count pass, tv_tiled.hip takes over
+    wmask = (mask * np.random.default_rng(5).choice([0.5, 1.0, 2.0], size=shape)).astype(np.float32)
+    assert_bits_equal(ctx.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5, wmask, wmask),
+                      oracle.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5, wmask, wmask), "weighted-mask tensor sigma_tv=%g" % sigma_tv)
 
 
 @pytest.mark.parametrize("sigma_tv,h", [(19.2, 27), (24.1, 34)])

@@ -195,7 +195,7 @@ int dev_tv_dense_stick(visfd_hip_ctx* ctx, const float* sal, const float* dir, f
     VH_TRY(dev_tv_box(ctx, sal, dir, ten, mask_src, mask_dst, nx, ny, nz, z_out0, z_out1, h, dtab + m_packed + m_padded, exponent,
                       &handled, false));
   if (handled) return VISFD_HIP_OK;
-  // exact arithmetic in the same kernel structure (surfaces, exponent 2 or 4, no source mask, finite saliencies; option
+  // exact arithmetic in the same kernel structure (surfaces, exponent 2 or 4, source mask absent or binary, finite saliencies; option
   // tv_exact_tiled = 1 keeps the round-2 kernel)
   if (!ctx->opt.tv_dense && !ctx->opt.tv_exact_tiled && !curves)
     VH_TRY(dev_tv_box(ctx, sal, dir, ten, mask_src, mask_dst, nx, ny, nz, z_out0, z_out1, h,

@@ -534,7 +534,8 @@ tv_box_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
 // The EXACT form of the same kernel structure (round 4): the reference's 32 multiplies and adds per vote in its order
 // (feature.hpp:2312-2377, no FMA), every receiver taking its votes in the reference's order (sender planes z+h .. z-h, rows and
 // columns descending), bit-identical to csrc/tv_tiled.hip -- which stays the general exact kernel (source masks, curve mode,
-// odd exponents, weight sums, non-finite saliencies) -- for the common case: surfaces, exponent 2 or 4, no source mask.
+// odd exponents, weight sums, non-finite saliencies, WEIGHTED source masks) -- for the common case: surfaces, exponent 2 or
+// 4, no source mask or one of zeros and ones.
 // What carries over from the tolerance kernel: the launch-wide sender lists (already in vote order), the box-tested hit lists,
 // the zero-padded slices (a zero-weight tap votes (s * 0) * dec = +-0 times finite numbers: adding it leaves a sum's bits,
 // as the rim taps of tv_tiled's superset test already do), the branch-free pipelined vote loop.  What cannot: the order
@@ -980,6 +981,7 @@ tvl_row_kernel(const float* __restrict__ sal, const float* __restrict__ dir, con
         const float s = mask_src ? v[k] * m[k] : v[k];
         if (!(s > 0.0f)) atomicOr(neg_flag, 1u);   // (rare: negative peak heights, masks with negative values, NaN)
         if (!(__builtin_fabsf(s) <= 3.402823466e38f)) atomicOr(neg_flag, 2u);   // non-finite: the exact form declines
+        if (mask_src && m[k] != 1.0f) atomicOr(neg_flag, 4u);   // a weighted source mask: its value is a factor of the exact vote
       }
     }
   }
@@ -1075,13 +1077,14 @@ __global__ void __launch_bounds__(256) lds_poison_kernel(unsigned* sink) {
 // Tolerance-mode tensor voting (surfaces, exponent 2 or 4).  dtab_box: the {w, sqrt(2) rhat} table on the device in this
 // kernel's slice layout (tv.hip: tv_table_device).
 // exact != 0: the exact form (tv_boxx_kernel) with dtab_box = the reference's {w, rhat} in the same slice layout; it declines
-// source masks and non-finite saliencies (the caller falls back to tv_tiled.hip).
+// weighted source masks (values other than 0 and 1) and non-finite saliencies (the caller falls back to tv_tiled.hip).
 int dev_tv_box(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* ten, const float* mask_src,
                const float* mask_dst, i64 nx, i64 ny, i64 nz, i64 z_out0, i64 z_out1, int h, const float4* dtab_box,
                int exponent, bool* handled, bool exact) {
   *handled = false;
   if (exponent != 2 && exponent != 4) return VISFD_HIP_OK;
-  if (exact && mask_src) return VISFD_HIP_OK;
+  // (a source mask of zeros and ones only multiplies the kept senders' weights by 1.0 -- exactly nothing -- so the exact form
+  //  takes it; the count pass of the listing reports any other mask value, see below)
   if (h < 1 || h > 40) return VISFD_HIP_OK;
   if (nx * ny >= (1LL << 29) || nx > 32 * LWORDS_MAX || ny >= (1 << 24)) return VISFD_HIP_OK;
   hipStream_t st = ctx->stream;
@@ -1143,6 +1146,7 @@ int dev_tv_box(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* te
   fold = ((unsigned)tot2[1] & 1u) ? 0 : 1;   // every listed saliency positive: the 18-instruction vote
   if (ctx->opt.tv_no_fold) fold = 0;         // (tests: the general form on positive saliencies too)
   if (exact && ((unsigned)tot2[1] & 2u)) return VISFD_HIP_OK;   // a non-finite saliency: the zero-padded slices would spread it
+  if (exact && ((unsigned)tot2[1] & 4u)) return VISFD_HIP_OK;   // a weighted source mask: fv = w * mask value (feature.hpp:2262-2275)
   if (total >= (1ull << 32) - 2048) return VISFD_HIP_OK;   // 32-bit entry indices: the caller falls back
   unsigned char* lists = nullptr;
   if (ws(ctx, WS_TVSCRATCH, (size_t)(total + 16) * 20, &lists) != VISFD_HIP_OK) { set_error(""); (void)hipGetLastError(); return VISFD_HIP_OK; }
