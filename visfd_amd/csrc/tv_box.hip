@@ -548,7 +548,26 @@ tv_box_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
 constexpr int NPAIR = 2;
 constexpr int HX = 72;    // hit entries per (wave, sub-patch): <= 64 hits of a chunk + the read-ahead of the vote loop
 
-template <int MODE>
+// The six sums of (pair Q, half PP) are PINNED to the vector registers v[56 + 12 Q + 6 PP ...] in every add (a physical-
+// register constraint): the four inlined copies of the vote loop then agree on where the 24 sums live, and the register
+// allocator has nothing to shuffle at the loop boundaries (it moved 20 of them through scratch memory around every step:
+// 650 GB of spill traffic per launch at 1024^3).
+#define VH_PIN_ADD(REG, var, val) asm("v_add_f32 " #REG ", " #REG ", %1" : "+{" #REG "}"(var) : "v"(val))
+template <int BASE>
+__device__ __forceinline__ void acc6_pinned(float (&T)[6], float p00, float p01, float p02, float p11, float p12, float p22) {
+#define VH_PIN6(B, R0, R1, R2, R3, R4, R5)                                                                              \
+  if constexpr (BASE == B) {                                                                                            \
+    VH_PIN_ADD(R0, T[0], p00); VH_PIN_ADD(R3, T[3], p01); VH_PIN_ADD(R5, T[5], p02);                                    \
+    VH_PIN_ADD(R1, T[1], p11); VH_PIN_ADD(R4, T[4], p12); VH_PIN_ADD(R2, T[2], p22);                                    \
+  }
+  VH_PIN6(56, v56, v57, v58, v59, v60, v61)
+  VH_PIN6(62, v62, v63, v64, v65, v66, v67)
+  VH_PIN6(68, v68, v69, v70, v71, v72, v73)
+  VH_PIN6(74, v74, v75, v76, v77, v78, v79)
+#undef VH_PIN6
+}
+
+template <int MODE, int BASE>
 __device__ __forceinline__ void vote_exact(float (&T)[6], const f4v& snd /* sal, n */, const f4v& tw /* w, rhat */) {
   const float u = (tw.y * snd.y + tw.z * snd.z) + tw.w * snd.w;
   const float ux2 = u * 2.0f;
@@ -559,16 +578,11 @@ __device__ __forceinline__ void vote_exact(float (&T)[6], const f4v& snd /* sal,
   const float bse = (snd.x * tw.x) * dec;
   const float b0 = bse * m0, b1 = bse * m1, b2 = bse * m2;
   const float p00 = b0 * m0, p01 = b0 * m1, p02 = b0 * m2, p11 = b1 * m1, p12 = b1 * m2, p22 = b2 * m2;
-  asm("v_add_f32 %0, %0, %1" : "+v"(T[0]) : "v"(p00));
-  asm("v_add_f32 %0, %0, %1" : "+v"(T[3]) : "v"(p01));
-  asm("v_add_f32 %0, %0, %1" : "+v"(T[5]) : "v"(p02));
-  asm("v_add_f32 %0, %0, %1" : "+v"(T[1]) : "v"(p11));
-  asm("v_add_f32 %0, %0, %1" : "+v"(T[4]) : "v"(p12));
-  asm("v_add_f32 %0, %0, %1" : "+v"(T[2]) : "v"(p22));
+  acc6_pinned<BASE>(T, p00, p01, p02, p11, p12, p22);
 }
 
 // (the vote loop of vote_hits with the exact vote; one list per half wave, entries at hp)
-template <int MODE>
+template <int MODE, int BASE>
 __device__ __forceinline__ void vote_hits_exact(float (&T)[6], unsigned hp, int nst, unsigned r16) {
   u4v h0 = lds_u4(hp), h1 = lds_u4(hp + 16u);
   f4v sa = lds_f4(h0.x), ta = lds_f4(r16 - h0.y);
@@ -577,22 +591,22 @@ __device__ __forceinline__ void vote_hits_exact(float (&T)[6], unsigned hp, int 
   for (;;) {   // uniform
     sb = lds_f4(h0.z);
     tb = lds_f4(r16 - h0.w);
-    vote_exact<MODE>(T, sa, ta);
+    vote_exact<MODE, BASE>(T, sa, ta);
     if (++k >= nst) break;
     sa = lds_f4(h1.x);
     ta = lds_f4(r16 - h1.y);
     h0 = lds_u4(hp + 32u);
-    vote_exact<MODE>(T, sb, tb);
+    vote_exact<MODE, BASE>(T, sb, tb);
     if (++k >= nst) break;
     sb = lds_f4(h1.z);
     tb = lds_f4(r16 - h1.w);
-    vote_exact<MODE>(T, sa, ta);
+    vote_exact<MODE, BASE>(T, sa, ta);
     if (++k >= nst) break;
     sa = lds_f4(h0.x);
     ta = lds_f4(r16 - h0.y);
     h1 = lds_u4(hp + 48u);
     hp += 32u;
-    vote_exact<MODE>(T, sb, tb);
+    vote_exact<MODE, BASE>(T, sb, tb);
     if (++k >= nst) break;
   }
 }
@@ -670,9 +684,12 @@ tv_boxx_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
     // TEST + VOTE of entries [i0, i1) of one list (LDS slots from `base`) for the receiver pair whose sums are T2: 64 entries
     // at a time, each tested against the boxes of the two sub-patches of a half; the hits of sub-patch s go, in list order, to
     // l_hit[wave][s][0..]; lanes 32 s .. 32 s + 31 then vote them in that order.
-    auto test_vote = [&](float (&T2)[NH][6], int base, int i0, int i1, unsigned r16, float cy, float rr, unsigned null_e16) {
+    auto test_vote = [&](auto QQ, int base, int i0, int i1, unsigned r16, float cy, float rr, unsigned null_e16) {
+      constexpr int qq = decltype(QQ)::value;
+      float (&T2)[NH][6] = TT[qq];
       const unsigned hb = lds_addr(&l_hit[wave][0][0]);
-      for (int c = i0; c < i1; c += 64) {   // uniform
+      int c = i0;
+      do {   // uniform; i1 > i0 at every call
         const int ln = (int)fresh_lane();
         const int e = c + ln;
         uint2 pw = make_uint2(0xffffffffu, 0u);
@@ -707,7 +724,7 @@ tv_boxx_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
           if (nst > 0) {   // uniform
             const unsigned hp = hb + (fresh_lane() >> 5) * (unsigned)(HX * 8);
             __builtin_amdgcn_s_setprio(1);
-            vote_hits_exact<MODE>(T2[hh], hp, nst, r16);
+            vote_hits_exact<MODE, 56 + 12 * qq + 6 * hh>(T2[hh], hp, nst, r16);
             __builtin_amdgcn_s_setprio(0);
           }
           asm volatile("" ::: "memory");
@@ -718,7 +735,8 @@ tv_boxx_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
 #endif
         half(std::integral_constant<int, 0>{});
         half(std::integral_constant<int, 1>{});
-      }
+        c += 64;
+      } while (c < i1);
     };
 
     const int row_lo = max(y0 - h, 0), row_hi = min(y0 + TY - 1 + h, p.ny - 1);
@@ -752,7 +770,8 @@ tv_boxx_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
           lsz[q] = rz + 2 * q + 1 + h - t;
           lcnt[q] = (lsz[q] <= sz_hi && lsz[q] >= sz_lo) ? __builtin_amdgcn_readfirstlane(plane_cnt[plane_slot(lsz[q])]) : 0;
         }
-        if (max(lcnt[0], lcnt[1]) == 0) continue;   // uniform
+        // (a step without entries -- sender planes outside the volume -- still runs its interval: skipping it would give the
+        //  24 sums a second path through the step, which the register allocator pays for with copies through scratch memory)
         int need[2];
 #pragma unroll
         for (int k = 0; k < 2; k++) {
@@ -772,7 +791,8 @@ tv_boxx_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
         unsigned pl[NLIST];
 #pragma unroll
         for (int k = 0; k < NLIST; k++) pl[k] = lcnt[k] > 0 ? __builtin_amdgcn_readfirstlane(plane_beg[plane_slot(lsz[k])]) : 0u;
-        for (int done = 0; done < total; done += NT) {   // uniform
+        int done = 0;
+        do {   // uniform; at least one interval (a zero-trip path would make the 24 sums a merge of two register sets)
           int c[NLIST], len[NLIST];
 #pragma unroll
           for (int k = 0; k < NLIST; k++) {
@@ -797,34 +817,31 @@ tv_boxx_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
           }
           const int ft = wave * 64 + (int)fresh_lane();
           const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-          float4 s00 = z4, s01 = z4, s10 = z4, s11 = z4;
-          // (keys 0 and 2h+2 are the slices beyond the window: zeros)
-          const bool ld0 = done == 0 && need[0] >= 1 && need[0] <= 2 * h + 1, ld1 = done == 0 && need[1] >= 1 && need[1] <= 2 * h + 1;
-          if (ld0) {
-            const float4* src4 = table + (i64)(need[0] - 1) * nsl;
-            if (ft < nsl) s00 = src4[ft];
-            if (ft + NT < nsl) s01 = src4[ft + NT];
+          // A step normally needs ONE new slice (the upper plane's; the lower plane's was the previous step's upper one): that
+          // one shares the entries' round trip.  The first step of a pass -- and a step behind skipped ones -- needs both: the
+          // second is then copied by a plain loop with a round trip of its own (holding two slices' loads in registers beside
+          // the 24 sums spilled those sums around every step).  Keys 0 and 2h+2 are the slices beyond the window: zeros.
+          const int nk = done == 0 ? (need[1] >= 0 ? need[1] : need[0]) : -1;   // uniform
+          const int nk2 = (done == 0 && need[1] >= 0) ? need[0] : -1;
+          const bool ld = nk >= 1 && nk <= 2 * h + 1;
+          float4 s0 = z4, s1 = z4;
+          if (ld) {
+            const float4* src4 = table + (i64)(nk - 1) * nsl;
+            if (ft < nsl) s0 = src4[ft];
+            if (ft + NT < nsl) s1 = src4[ft + NT];
           }
-          if (ld1) {
-            const float4* src4 = table + (i64)(need[1] - 1) * nsl;
-            if (ft < nsl) s10 = src4[ft];
-            if (ft + NT < nsl) s11 = src4[ft + NT];
+          if (nk >= 0) {
+            float4* dst4 = sl4 + (nk & 1) * nsl;
+            if (ft < nsl) dst4[ft] = s0;
+            if (ft + NT < nsl) dst4[ft + NT] = s1;
+            const float4* src4 = table + (i64)(nk - 1) * nsl;
+            for (int i = ft + 2 * NT; i < nsl; i += NT) dst4[i] = ld ? src4[i] : z4;   // (windows wider than h = 12)
           }
-          if (done == 0) {
-            if (need[0] >= 0) {
-              float4* dst4 = sl4 + (need[0] & 1) * nsl;
-              if (ft < nsl) dst4[ft] = s00;
-              if (ft + NT < nsl) dst4[ft + NT] = s01;
-              const float4* src4 = table + (i64)(need[0] - 1) * nsl;
-              for (int i = ft + 2 * NT; i < nsl; i += NT) dst4[i] = ld0 ? src4[i] : z4;
-            }
-            if (need[1] >= 0) {
-              float4* dst4 = sl4 + (need[1] & 1) * nsl;
-              if (ft < nsl) dst4[ft] = s10;
-              if (ft + NT < nsl) dst4[ft + NT] = s11;
-              const float4* src4 = table + (i64)(need[1] - 1) * nsl;
-              for (int i = ft + 2 * NT; i < nsl; i += NT) dst4[i] = ld1 ? src4[i] : z4;
-            }
+          if (nk2 >= 0) {
+            const bool ld2 = nk2 >= 1 && nk2 <= 2 * h + 1;
+            float4* dst4 = sl4 + (nk2 & 1) * nsl;
+            const float4* src4 = table + (i64)(nk2 - 1) * nsl;
+            for (int i = ft; i < nsl; i += NT) dst4[i] = ld2 ? src4[i] : z4;
           }
           if (have) {
             l_ent[tid] = a;
@@ -859,13 +876,14 @@ tv_boxx_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
             const unsigned r16_0 = lds_addr(slices) + 16u * (unsigned)(4 + (4 * wave + frow + 2 * h + YPAD) * SP + fcol + 2 * h);
             const unsigned null_e16 = 16u * (unsigned)((4 * wave + h) * SP + h);
             const unsigned r16 = r16_0 + (unsigned)(16 * nsl) * (unsigned)((t + fpl) & 1);
-            if (i1[0] > i0[0]) test_vote(TT[0], c[0], i0[0], i1[0], r16, cy, rr, null_e16);
-            if (i1[1] > i0[1]) test_vote(TT[1], c[1], i0[1], i1[1], r16, cy, rr, null_e16);
+            if (i1[0] > i0[0]) test_vote(std::integral_constant<int, 0>{}, c[0], i0[0], i1[0], r16, cy, rr, null_e16);
+            if (i1[1] > i0[1]) test_vote(std::integral_constant<int, 1>{}, c[1], i0[1], i1[1], r16, cy, rr, null_e16);
           }
           VH_STAMP(3);
           __syncthreads();   // everyone done reading before the lists or the slices are refilled
           VH_STAMP(4);
-        }
+          done += NT;
+        } while (done < total);
       }
 
       // ---- the pass's sums ----
