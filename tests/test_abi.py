@@ -94,3 +94,12 @@ def test_development_builds_cross_compile(src, flags, tmp_path):
     cmd = [B.HIPCC] + B.FLAGS + ["-fno-slp-vectorize"] + flags + ["-x", "hip", "-c", os.path.join(B.CSRC, src), "-o", str(tmp_path / "o.o")]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_graft_entry_expects_the_library_abi(lib):
+    """__graft_entry__.build() asserts the ABI version of the library it has just built: the number written there must be
+    the library's (it was left behind once when the ABI moved on)."""
+    L = ctypes.CDLL(lib.LIB_PATH)
+    src = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    m = re.search(r"visfd_hip_abi_version\(\) == (\d+)", src)
+    assert m and int(m.group(1)) == L.visfd_hip_abi_version()
