@@ -46,7 +46,8 @@ blob_candidates_kernel(const float* __restrict__ mid, const float* __restrict__ 
                        float min_thr, float max_thr, int zchunk, int tiles_x, int tiles_y,
                        unsigned long long* __restrict__ out, unsigned long long capacity,
                        unsigned long long* __restrict__ counter) {
-  __shared__ float tile[PZ][LH * LW];
+  constexpr int NLD = (LH * LW + BLOCK - 1) / BLOCK;
+  __shared__ float tile[PZ][NLD * BLOCK];   // (LH * LW used; padded so that every thread's stores are unconditional)
   // candidates are collected per workgroup and written out with ONE global atomic per flush
   __shared__ unsigned int buf[BUFCAP];   // (z - zs) << 9 | thread index: one voxel of this workgroup's column
   __shared__ unsigned int buf_n;
@@ -70,23 +71,29 @@ blob_candidates_kernel(const float* __restrict__ mid, const float* __restrict__ 
   // face voxels, which can never be blobs, feature.hpp:245-252).  Split in two so that the global loads
   // of plane z+2 are in flight while plane z+1 is being compared (the march is latency-bound otherwise):
   // fetch() reads this thread's (up to NLD) tile elements into registers, stash() writes them to LDS.
-  constexpr int NLD = (LH * LW + BLOCK - 1) / BLOCK;
-  i64 ld_off[NLD];   // offset inside a plane, -1: outside the image or beyond the tile
+  // Raw buffer loads through one descriptor per plane (planes below 2 GiB: the host checks): an element outside the image
+  // or the tile has an out-of-range offset, a plane outside the volume a zero-length descriptor -- the hardware returns
+  // 0.0 and the loads need no branches.  (Conditional loads are each closed by a full s_waitcnt at their join: the eight
+  // loads of a step then went out in three or four dependent groups, and the sweep ran at memory latency.)
+  unsigned ld_off[NLD];   // BYTE offset inside a plane
 #pragma unroll
   for (int k = 0; k < NLD; k++) {
     const int i = tid + k * BLOCK;
     const int r = i / LW, c = i - r * LW;
     const int sx = x0 - 1 + c, sy = y0 - 1 + r;
-    ld_off[k] = (i < LH * LW && sx >= 0 && sx < nx && sy >= 0 && sy < ny) ? ((i64)sy * nx + sx) : -1;
+    ld_off[k] = (i < LH * LW && sx >= 0 && sx < nx && sy >= 0 && sy < ny) ? (unsigned)(sy * nx + sx) * 4u : 0x7ffffff0u;
   }
+  const int plane_bytes = (int)(plane * 4);
   auto fetch = [&](int z, float v[NLD]) {
+    const bool zin = z < nz;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(mid + (zin ? (i64)z * plane : 0)), 0,
+                                                                        zin ? plane_bytes : 0, 0x00020000);
 #pragma unroll
-    for (int k = 0; k < NLD; k++) v[k] = (ld_off[k] >= 0 && z < nz) ? mid[(i64)z * plane + ld_off[k]] : 0.0f;
+    for (int k = 0; k < NLD; k++) v[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)ld_off[k], 0, 0));
   };
   auto stash = [&](const float v[NLD], float* dst) {
 #pragma unroll
-    for (int k = 0; k < NLD; k++)
-      if (tid + k * BLOCK < LH * LW) dst[tid + k * BLOCK] = v[k];
+    for (int k = 0; k < NLD; k++) dst[tid + k * BLOCK] = v[k];
   };
   // min and max over the 3x3 neighbourhood of (lx, ly) in an LDS plane, plus the centre value
   auto minmax9 = [&](const float* t, float& mn, float& mx, float& centre) {
@@ -104,22 +111,27 @@ blob_candidates_kernel(const float* __restrict__ mid, const float* __restrict__ 
   // per step instead of one per plane) while the global loads of the following PZ planes are already in
   // flight in registers, so the HBM latency is covered by PZ planes of comparisons.
   float mn_prev, mx_prev, c_prev, mn_cur, mx_cur, c_cur;
-  float pre[PZ][NLD];
-  fetch(zs - 1, pre[0]);
-  fetch(zs, pre[1]);
-  stash(pre[0], tile[0]);
-  stash(pre[1], tile[1]);
+  // TWO steps of planes in flight, in two register sets used alternately (a step's loads are requested two steps before
+  // they are stashed: one step of comparisons does not cover a loaded HBM round trip)
+  float preA[PZ][NLD], preB[PZ][NLD];
+  fetch(zs - 1, preA[0]);
+  fetch(zs, preA[1]);
+  stash(preA[0], tile[0]);
+  stash(preA[1], tile[1]);
 #pragma unroll
-  for (int k = 0; k < PZ; k++) fetch(zs + 1 + k, pre[k]);
+  for (int k = 0; k < PZ; k++) fetch(zs + 1 + k, preA[k]);
+#pragma unroll
+  for (int k = 0; k < PZ; k++) fetch(zs + PZ + 1 + k, preB[k]);
   __syncthreads();
   minmax9(tile[0], mn_prev, mx_prev, c_prev);
   minmax9(tile[1], mn_cur, mx_cur, c_cur);
   __syncthreads();   // both tiles free again
-  for (int z0 = zs; z0 < ze; z0 += PZ) {
+  // one step: planes z0 .. z0+PZ-1 are compared; `pre` holds planes z0+1 .. z0+PZ and is refilled with z0+2PZ+1 ..
+  auto step = [&](float (&pre)[PZ][NLD], int z0) {
 #pragma unroll
-    for (int k = 0; k < PZ; k++) stash(pre[k], tile[k]);                   // planes z0+1 .. z0+PZ
+    for (int k = 0; k < PZ; k++) stash(pre[k], tile[k]);                      // planes z0+1 .. z0+PZ
 #pragma unroll
-    for (int k = 0; k < PZ; k++) fetch(z0 + PZ + 1 + k, pre[k]);           // the next step's planes
+    for (int k = 0; k < PZ; k++) fetch(z0 + 2 * PZ + 1 + k, pre[k]);          // the planes of the step after the next
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < PZ; k++) {
@@ -170,6 +182,11 @@ blob_candidates_kernel(const float* __restrict__ mid, const float* __restrict__ 
       __syncthreads();
       if (tid == 0) buf_n = 0;   // ordered before the next appends by the next step's barrier
     }
+  };
+  for (int z0 = zs; z0 < ze; z0 += 2 * PZ) {
+    step(preA, z0);
+    step(preB, z0 + PZ);   // (unconditional -- a second step past the end compares nothing: with a branch here the wait counts
+                           //  at the loop head must assume the shorter path and drain the younger set's loads as well)
   }
 }
 
@@ -315,6 +332,7 @@ static void sort_and_append(std::vector<Cand>& h, i64 nx, i64 ny, int scale_inde
 static int scan_enqueue(visfd_hip_ctx* ctx, const ScanBufs& B, const float* lo, const float* mid, const float* hi,
                         const float* mask, i64 nx, i64 ny, i64 nz, float min_thr, float max_thr) {
   hipStream_t st = ctx->stream;
+  if (nx * ny >= (1LL << 29)) return fail(VISFD_HIP_EINVAL, "planes of 2 GiB and more are not supported by the blob scan");
   const int tiles_x = (int)((nx + TX - 1) / TX), tiles_y = (int)((ny + TY - 1) / TY);
   const i64 tiles = (i64)tiles_x * tiles_y;
   i64 want_chunks = ((i64)ctx->num_cus * 16 + tiles - 1) / tiles;
