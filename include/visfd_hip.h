@@ -78,9 +78,11 @@ int visfd_hip_abi_version(void);   /* 8: entry points only get added between ver
  *                    csrc/tv_box.hip (surfaces, exponent 2 or 4, source mask absent or of zeros and ones); results are bit-identical either way
  *   tv_no_fold       tests: tolerance-mode voting keeps the saliency as a factor of every vote even when all saliencies are
  *                    positive (by default they are then folded into the listed normals: 18 instead of 19 instructions)
- *   tv_poison        tests: NaN bit patterns in LDS, ring memory and the output before tolerance-mode tensor voting runs
+ *   tv_poison        tests: NaN bit patterns in LDS, list memory and the output before the kernels of csrc/tv_box.hip run (both forms)
+ *   tv_reserve_wg    workgroup slots a voting kernel leaves free of its chip-filling grid (slab runs set it while a halo is in
+ *                    flight, so that the transport's kernels find room; default 0)
  *   tv_zrun          receiver planes per unit of work (default 32)
- *   tv_no_replay     1: every sender plane is listed again for every receiver plane (no reuse within a run)
+ *   tv_no_replay     csrc/tv_tiled.hip only: every sender plane is listed again for every receiver plane (no reuse within a run)
  *   tv_max_wg        cap on the number of persistent workgroups (tests: forces many units of work per workgroup)
  *   blob_test_cap    tests: capacity the pipelined blob scan pretends to have (exercises its overflow path)
  *   gauss_cfg, debug development aids */
