@@ -180,10 +180,9 @@ def cpu_baseline_child(argv):
     # (team, edge of its sample): the reference's OpenMP loops get SLOWER beyond a few dozen threads (measured on the 256-thread
     # GPU box: 0.60 Mvoxels/s with 16, 0.42 with 64, 0.05 with 256), so the large teams get smaller samples to keep the
     # whole leg at 15-20 s
-    # (a team of more than 128 threads runs at ~0.01 Mvoxels/s -- the reference's loops are parallel over z planes only -- and
-    #  gets a quarter of the edge: its 72^3 sample alone took 34 of the bench command's 57 seconds)
-    teams = sorted({(nproc, max(32, sample // 4 if nproc > 128 else sample // 2)), (min(64, nproc), max(32, sample * 8 // 9)),
-                    (min(CPU_SHARE_THREADS, nproc), sample)},
+    # (the team of every host thread costs ~25-35 s whatever its sample -- 34 s at 72^3, 24 s at 36^3 on a 256-thread box: thousands
+    #  of parallel regions, each a fork and join of 256 threads -- so shrinking its sample further buys nothing)
+    teams = sorted({(nproc, max(32, sample // 2)), (min(64, nproc), max(32, sample * 8 // 9)), (min(CPU_SHARE_THREADS, nproc), sample)},
                    reverse=True)
     if nproc <= CPU_SHARE_THREADS:
         teams = [(nproc, sample)]
