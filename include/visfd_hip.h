@@ -175,7 +175,8 @@ typedef struct visfd_hip_blob {
  * NaN / Inf voxels propagate as in the reference (every comparison with a NaN is false in its scan, feature.hpp:245-304):
  * same lists (tests/test_gpu_parity.py::test_blob_detection_with_non_finite_voxels).
  * src and mask are HOST pointers in the first form, DEVICE pointers in the _dev form; the blob lists are always host
- * arrays of the given capacities. */
+ * arrays of the given capacities.  Planes (nx * ny) of 2^29 voxels and more are VISFD_HIP_EINVAL (the scan addresses a
+ * plane through one 2 GiB buffer descriptor). */
 int visfd_hip_blob_dog(visfd_hip_ctx*, const float* src, const float* mask,
                        int64_t nx, int64_t ny, int64_t nz, const float* blob_sigma, int n_sigma,
                        const float* aspect_ratio, float delta_sigma_over_sigma,
