@@ -150,7 +150,7 @@ static int tv_table_device(visfd_hip_ctx* ctx, float sigma_tv, float cutoff, int
   // {w, sqrt(2) rhat} in the slice layout of tv_box.hip (zero rows and zero row tails, which ARE read: common.hpp)
   const size_t sp = (size_t)tv_padded_row(h), m2 = n * n * sp;
   // ... and the reference's {w, rhat} once more in that slice layout (the exact form of tv_box.hip)
-  const size_t spb = (size_t)tv_box_row(h), nslb = (size_t)tv_box_slice(h), m3 = n * nslb;
+  const size_t spb = (size_t)tv_box_row(h), nslb = (size_t)tv_box_slice(h), m3 = (n + 1) * nslb;   // (+ one slice of zeros)
   std::vector<float4> tab(m + m2 + 2 * m3, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
   const float rt2 = 1.41421356237309504880f;
   for (size_t k = 0; k < m; k++) {
@@ -199,7 +199,7 @@ int dev_tv_dense_stick(visfd_hip_ctx* ctx, const float* sal, const float* dir, f
   // tv_exact_tiled = 1 keeps the round-2 kernel)
   if (!ctx->opt.tv_dense && !ctx->opt.tv_exact_tiled && !curves)
     VH_TRY(dev_tv_box(ctx, sal, dir, ten, mask_src, mask_dst, nx, ny, nz, z_out0, z_out1, h,
-                      dtab + m_packed + m_padded + (size_t)(2 * h + 1) * (size_t)tv_box_slice(h), exponent, &handled, true));
+                      dtab + m_packed + m_padded + (size_t)(2 * h + 2) * (size_t)tv_box_slice(h), exponent, &handled, true));
   if (handled) return VISFD_HIP_OK;
   if (!ctx->opt.tv_dense)
     VH_TRY(dev_tv_tiled(ctx, sal, dir, ten, mask_src, mask_dst, nx, ny, nz, z_out0, z_out1, h, dtab + m_packed, exponent, curves,

@@ -401,42 +401,35 @@ tv_box_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
 #pragma unroll
           for (int k = 1; k < NLIST; k++)
             if (k_me == k) idx = pl[k] + (unsigned)(g - pre[k]);
-          float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-          unsigned m = 0u;
-          if (have) {
-            a = lst_ent[idx];
-            m = lst_pos[idx];
-          }
+          // (unconditional loads from clamped indices: a load inside a branch is closed by a full s_waitcnt at the join, and
+          //  the entries' round trip then ended before the slice loads below were even issued)
+          const unsigned idxc = have ? idx : 0u;
+          const float4 a = lst_ent[idxc];
+          const unsigned m = lst_pos[idxc];
           // the new slice(s) of this step: every load is requested BEFORE the first LDS store waits for one (entries and slice
           // share one round trip; a copy loop that loads and stores element by element is three)
           const int ft = wave * 64 + (int)fresh_lane();     // (this thread's index again: addresses hoisted out of the step loop are spilled)
-          const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-          float4 s00 = z4, s01 = z4, s10 = z4, s11 = z4;
+          // Both slots' loads are ALWAYS issued, from clamped indices: a slice the step does not need, and the slice of zeros
+          // beyond the window (S_(h+1)), are read from the zero slice that follows the table's 2h+1 -- a float4 selected
+          // between a load and a constant makes the compiler park the constant in scratch memory, and loads inside branches
+          // are closed by full waits at their joins.
           const bool ld0 = done == 0 && need[0] >= 0 && need[0] <= h, ld1 = done == 0 && need[1] >= 0 && need[1] <= h;   // uniform
-          if (ld0) {
-            const float4* src4 = table + (i64)(need[0] + h) * nsl;
-            if (ft < nsl) s00 = src4[ft];
-            if (ft + NT < nsl) s01 = src4[ft + NT];
-          }
-          if (ld1) {
-            const float4* src4 = table + (i64)(need[1] + h) * nsl;
-            if (ft < nsl) s10 = src4[ft];
-            if (ft + NT < nsl) s11 = src4[ft + NT];
-          }
+          const float4* const srcA = table + (i64)(ld0 ? need[0] + h : 2 * h + 1) * nsl;
+          const float4* const srcB = table + (i64)(ld1 ? need[1] + h : 2 * h + 1) * nsl;
+          const int f0 = min(ft, nsl - 1), f1 = min(ft + NT, nsl - 1);
+          const float4 s00 = srcA[f0], s01 = srcA[f1], s10 = srcB[f0], s11 = srcB[f1];
           if (done == 0) {
-            if (need[0] >= 0) {   // uniform; slice h + 1 is zeros (s00, s01 still are)
+            if (need[0] >= 0) {   // uniform
               float4* dst4 = sl4 + (need[0] & 1) * nsl;
               if (ft < nsl) dst4[ft] = s00;
               if (ft + NT < nsl) dst4[ft + NT] = s01;
-              const float4* src4 = table + (i64)(need[0] + h) * nsl;
-              for (int i = ft + 2 * NT; i < nsl; i += NT) dst4[i] = ld0 ? src4[i] : z4;   // (windows wider than h = 12)
+              for (int i = ft + 2 * NT; i < nsl; i += NT) dst4[i] = srcA[i];   // (windows wider than h = 12)
             }
             if (need[1] >= 0) {
               float4* dst4 = sl4 + (need[1] & 1) * nsl;
               if (ft < nsl) dst4[ft] = s10;
               if (ft + NT < nsl) dst4[ft + NT] = s11;
-              const float4* src4 = table + (i64)(need[1] + h) * nsl;
-              for (int i = ft + 2 * NT; i < nsl; i += NT) dst4[i] = ld1 ? src4[i] : z4;
+              for (int i = ft + 2 * NT; i < nsl; i += NT) dst4[i] = srcB[i];
             }
           }
           if (have) {   // list entries carry {column within the tile column's window, image row}: the region row here
@@ -809,39 +802,32 @@ tv_boxx_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
 #pragma unroll
           for (int k = 1; k < NLIST; k++)
             if (k_me == k) idx = pl[k] + (unsigned)(g - pre[k]);
-          float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-          unsigned m = 0u;
-          if (have) {
-            a = lst_ent[idx];
-            m = lst_pos[idx];
-          }
+          const unsigned idxc = have ? idx : 0u;   // (unconditional loads from a clamped index: see the tolerance kernel)
+          const float4 a = lst_ent[idxc];
+          const unsigned m = lst_pos[idxc];
           const int ft = wave * 64 + (int)fresh_lane();
-          const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
           // A step normally needs ONE new slice (the upper plane's; the lower plane's was the previous step's upper one): that
           // one shares the entries' round trip.  The first step of a pass -- and a step behind skipped ones -- needs both: the
           // second is then copied by a plain loop with a round trip of its own (holding two slices' loads in registers beside
           // the 24 sums spilled those sums around every step).  Keys 0 and 2h+2 are the slices beyond the window: zeros.
           const int nk = done == 0 ? (need[1] >= 0 ? need[1] : need[0]) : -1;   // uniform
           const int nk2 = (done == 0 && need[1] >= 0) ? need[0] : -1;
+          // (the slices of zeros beyond the window, and the load of a step that needs no slice, read the zero slice that follows
+          //  the table's 2h+1: always a load from a clamped index, never a branch or a select against a constant)
           const bool ld = nk >= 1 && nk <= 2 * h + 1;
-          float4 s0 = z4, s1 = z4;
-          if (ld) {
-            const float4* src4 = table + (i64)(nk - 1) * nsl;
-            if (ft < nsl) s0 = src4[ft];
-            if (ft + NT < nsl) s1 = src4[ft + NT];
-          }
+          const float4* const src4 = table + (i64)(ld ? nk - 1 : 2 * h + 1) * nsl;
+          const float4 s0 = src4[min(ft, nsl - 1)], s1 = src4[min(ft + NT, nsl - 1)];
           if (nk >= 0) {
             float4* dst4 = sl4 + (nk & 1) * nsl;
             if (ft < nsl) dst4[ft] = s0;
             if (ft + NT < nsl) dst4[ft + NT] = s1;
-            const float4* src4 = table + (i64)(nk - 1) * nsl;
-            for (int i = ft + 2 * NT; i < nsl; i += NT) dst4[i] = ld ? src4[i] : z4;   // (windows wider than h = 12)
+            for (int i = ft + 2 * NT; i < nsl; i += NT) dst4[i] = src4[i];   // (windows wider than h = 12)
           }
           if (nk2 >= 0) {
             const bool ld2 = nk2 >= 1 && nk2 <= 2 * h + 1;
             float4* dst4 = sl4 + (nk2 & 1) * nsl;
-            const float4* src4 = table + (i64)(nk2 - 1) * nsl;
-            for (int i = ft; i < nsl; i += NT) dst4[i] = ld2 ? src4[i] : z4;
+            const float4* src2 = table + (i64)(ld2 ? nk2 - 1 : 2 * h + 1) * nsl;
+            for (int i = ft; i < nsl; i += NT) dst4[i] = src2[i];
           }
           if (have) {
             l_ent[tid] = a;
