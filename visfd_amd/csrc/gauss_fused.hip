@@ -437,6 +437,35 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
 #pragma unroll
         for (int r = 0; r < C::XROUNDS; r++) {
           float v[C::XV * C::XWINV];
+          typedef float v4f __attribute__((ext_vector_type(4)));
+          typedef unsigned v4u __attribute__((ext_vector_type(4)));
+          typedef float v2f __attribute__((ext_vector_type(2)));
+          typedef unsigned v2u __attribute__((ext_vector_type(2)));
+          // one output group of another volume (its minuend or numerator), with the same row-end handling
+          auto load_group = [&](const float* vol, float m[C::XV]) {
+            const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(vol + (i64)z * plane), 0, plane_bytes, 0x00020000);
+            if (C::XV == 4) {
+              const v4f mv = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rm, (int)o_off[r], 0, 0));
+#pragma unroll
+              for (int k = 0; k < 4; k++) m[k] = mv[k];
+            } else {
+              const v2f mv = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rm, (int)o_off[r], 0, 0));
+              m[0] = mv[0]; m[1] = mv[1];
+            }
+            if (RAGGED) {
+#pragma unroll
+              for (int k = 0; k < C::XV - 1; k++) {
+                const float e = buf_load(rm, k < e_n[r] ? e_off[r] + 4u * k : OOB);
+                if (k < e_n[r]) m[k] = e;
+              }
+            }
+          };
+          // the minuend of a DoG/LoG second Gaussian is REQUESTED HERE, at the top of the round, and used at its end: asked for
+          // where it is subtracted, every X round waited for a memory round trip (the minuend is the previous launch's
+          // output, 4 GiB away in HBM) before it could store
+          float mnd[C::XV];
+          if (minuend) load_group(minuend, mnd);   // (wave-uniform)
           float dxy[C::XV], rcp_int[C::XV];   // requested together with the window (only this thread touches these LDS words)
           if (NORMALIZE) {   // one vector read each (XV consecutive floats per thread, 16-byte aligned for XV = 4)
             if constexpr (C::XV == 4) {
@@ -531,30 +560,6 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
               for (int k = 0; k < C::XV; k++) a[k] = a[k] / d[k];
             }
           }
-          typedef float v4f __attribute__((ext_vector_type(4)));
-          typedef unsigned v4u __attribute__((ext_vector_type(4)));
-          typedef float v2f __attribute__((ext_vector_type(2)));
-          typedef unsigned v2u __attribute__((ext_vector_type(2)));
-          // one output group of another volume (its minuend or numerator), with the same row-end handling
-          auto load_group = [&](const float* vol, float m[C::XV]) {
-            const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)(vol + (i64)z * plane), 0, plane_bytes, 0x00020000);
-            if (C::XV == 4) {
-              const v4f mv = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rm, (int)o_off[r], 0, 0));
-#pragma unroll
-              for (int k = 0; k < 4; k++) m[k] = mv[k];
-            } else {
-              const v2f mv = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rm, (int)o_off[r], 0, 0));
-              m[0] = mv[0]; m[1] = mv[1];
-            }
-            if (RAGGED) {
-#pragma unroll
-              for (int k = 0; k < C::XV - 1; k++) {
-                const float e = buf_load(rm, k < e_n[r] ? e_off[r] + 4u * k : OOB);
-                if (k < e_n[r]) m[k] = e;
-              }
-            }
-          };
           if (DENOM) {
             // masked normalisation (filter3d.hpp:986-996): this kernel filtered the mask denominator; the
             // output is numer / denominator where the denominator is positive, numer elsewhere
@@ -566,11 +571,9 @@ gauss_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, TapsH
           if (minuend) {
             // DoG/LoG epilogue fused into the second Gaussian: out = (G_a - G_b) * scale with the two
             // roundings of filter3d.hpp:1387-1390 and :1495-1498 (wave-uniform branch)
-            float m[C::XV];
-            load_group(minuend, m);
 #pragma unroll
             for (int k = 0; k < C::XV; k++) {
-              const float dd = m[k] - a[k];
+              const float dd = mnd[k] - a[k];
               a[k] = dd * log_scale;
             }
           }
