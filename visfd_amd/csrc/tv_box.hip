@@ -193,7 +193,7 @@ tv_box_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
   __shared__ unsigned plane_beg[88];         // per sender plane of a pass (slot = plane - (rz - h), < 2h + 2 <= 82): first entry ...
   __shared__ int plane_cnt[88];              // ... and number of entries of this tile's rows in the plane's list
   __shared__ int rho_tab[44];                // floor(sqrt(h^2 - j^2)), j = 0..h: the radius of slice j
-  extern __shared__ __attribute__((aligned(16))) unsigned char slices[];   // two table slices: S_j (jz = +j) in slot j & 1
+  extern __shared__ __attribute__((aligned(16))) unsigned char slices[];   // two table slices: S_j (jz = +j) in slot j & 1; then l_rng
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -209,6 +209,8 @@ tv_box_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
   int slot_has[2] = {-1, -1};                // which slice S_j each LDS slot holds (uniform)
   bool up = false;                           // direction of d for the next pass (flips after every pass)
   float4* const sl4 = reinterpret_cast<float4*>(slices);
+  // per sender plane of a pass and wave: the stretch [i0, i1) of the plane's list the wave's rows can reach, i0 | i1 << 16
+  unsigned* const l_rng = reinterpret_cast<unsigned*>(slices + 2 * (size_t)p.nsl * sizeof(float4));
   const unsigned ent_base = lds_addr(l_ent);
   const unsigned null_ent = ent_base + 16u * (unsigned)LSLOTS;
 #ifdef VH_TV_STAMPS
@@ -338,6 +340,25 @@ tv_box_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
         plane_beg[sz_lo + tid - (rz - h)] = beg;
         plane_cnt[sz_lo + tid - (rz - h)] = (int)(end - beg);
       }
+      // ... and, per plane and wave, which of those entries the wave's four rows can reach: the lists are in descending row
+      // order with per-row offsets, so the stretch [i0, i1) follows from two of them (the waves used to count it from the
+      // position words of every interval: ~100 vector instructions, 8 LDS reads and 16 ballots per wave and step)
+      if (tid < (sz_hi - sz_lo + 1) * NW) {
+        const int pl_i = tid / NW, w = tid - pl_i * NW;
+        const int sz = sz_lo + pl_i;
+        const int d = sz > rz ? sz - rz : rz + 1 - sz;          // plane A at z + d, plane B at z + 1 - d
+        const int rho = rho_tab[d - 1];
+        const int yhi = min(y0 + 4 * w + 3 + rho, row_hi), ylo = max(y0 + 4 * w - rho, row_lo);
+        unsigned rg = 0u;
+        if (yhi >= ylo) {
+          const size_t r0 = ((size_t)(sz - p.zl0) * (size_t)(p.ny + 1)) * (size_t)p.tiles_x + (size_t)tile_x;
+          const unsigned beg = lst_rows[r0 + (size_t)(row_hi + 1) * (size_t)p.tiles_x];
+          const unsigned a0 = lst_rows[r0 + (size_t)(yhi + 1) * (size_t)p.tiles_x] - beg;
+          const unsigned a1 = lst_rows[r0 + (size_t)ylo * (size_t)p.tiles_x] - beg;
+          rg = a0 | (a1 << 16);
+        }
+        l_rng[(sz - (rz - h)) * NW + w] = rg;
+      }
 
 #pragma unroll
       for (int pp = 0; pp < NH; pp++)
@@ -372,7 +393,6 @@ tv_box_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
           if (need[k] >= 0) slot_has[j & 1] = j;
         }
         // rows a wave can reach: the nearer of its two receiver planes is |jz| = d-1 away from either sender plane
-        const int rho = __builtin_amdgcn_readfirstlane(rho_tab[d - 1]);
         const float rr = (float)(h * h - (d - 1) * (d - 1));
         int pre[NLIST + 1];                                    // (uniform) first position of list k in the step's sequence
         pre[0] = 0;
@@ -444,19 +464,14 @@ tv_box_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
           // 4 wv + h + 3 + rho to the last one at or above row 4 wv + h - rho.  Every wave counts both kinds itself, from the
           // row bytes of the position words in LDS, 64 entries at a time.
           int i0[NLIST], i1[NLIST];
-          {
-            const int hi_row = 4 * wave + h + 3 + rho, lo_row = 4 * wave + h - rho;
 #pragma unroll
-            for (int k = 0; k < NLIST; k++) {
-              int above = 0, upto = 0;
-              for (int j = 0; j < len[k]; j += 64) {   // uniform
-                int ey = -1;
-                if (j + lane < len[k]) ey = (int)((l_pos[c[k] + j + lane].x >> 8) & 0xffu);
-                above += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ey > hi_row));
-                upto += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ey >= lo_row));
-              }
-              i0[k] = above;
-              i1[k] = upto;
+          for (int k = 0; k < NLIST; k++) {   // the wave's stretch of list k (l_rng, list positions) cut to this interval's share
+            i0[k] = i1[k] = 0;
+            if (len[k] > 0) {   // uniform
+              const unsigned rg = __builtin_amdgcn_readfirstlane(l_rng[plane_slot(lsz[k]) * NW + wave]);
+              const int off = c[k] + done - pre[k];     // list position of the share's first LDS slot
+              i0[k] = min(max((int)(rg & 0xffffu) - off, 0), len[k]);
+              i1[k] = min(max((int)(rg >> 16) - off, 0), len[k]);
             }
           }
           if (i1[0] > i0[0] || i1[1] > i0[1]) {   // uniform
@@ -628,6 +643,7 @@ tv_boxx_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
   const i64 nvox = plane * p.nz;
   int slot_has[2] = {-1, -1};                // which slice (as jz + h + 1 = 0 .. 2h+2; 0 and 2h+2: zeros) each LDS slot holds
   float4* const sl4 = reinterpret_cast<float4*>(slices);
+  unsigned* const l_rng = reinterpret_cast<unsigned*>(slices + 2 * (size_t)p.nsl * sizeof(float4));   // [plane][pair][wave]: i0 | i1 << 16
   const unsigned ent_base = lds_addr(l_ent);
   const unsigned null_ent = ent_base + 16u * (unsigned)LSLOTS;
 
@@ -744,6 +760,27 @@ tv_boxx_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
         plane_beg[sz_lo + tid - (rz - h)] = beg;
         plane_cnt[sz_lo + tid - (rz - h)] = (int)(end - beg);
       }
+      // per plane, receiver pair and wave: the stretch of the plane's list the wave's rows can reach (see the tolerance kernel)
+      if (tid < (sz_hi - sz_lo + 1) * NW * NPAIR) {
+        const int pl_i = tid / (NW * NPAIR), rem = tid - pl_i * (NW * NPAIR);
+        const int q = rem / NW, w = rem - q * NW;
+        const int sz = sz_lo + pl_i;
+        const int t = rz + 2 * q + 1 + h - sz;                  // the step at which pair q meets this plane
+        unsigned rg = 0u;
+        if (t >= 0 && t <= 2 * h + 1) {
+          const int dmin = min(abs(t - h - 1), abs(t - h));
+          const int rho = rho_tab[dmin];
+          const int yhi = min(y0 + 4 * w + 3 + rho, row_hi), ylo = max(y0 + 4 * w - rho, row_lo);
+          if (yhi >= ylo) {
+            const size_t r0 = ((size_t)(sz - p.zl0) * (size_t)(p.ny + 1)) * (size_t)p.tiles_x + (size_t)tile_x;
+            const unsigned beg = lst_rows[r0 + (size_t)(row_hi + 1) * (size_t)p.tiles_x];
+            const unsigned a0 = lst_rows[r0 + (size_t)(yhi + 1) * (size_t)p.tiles_x] - beg;
+            const unsigned a1 = lst_rows[r0 + (size_t)ylo * (size_t)p.tiles_x] - beg;
+            rg = a0 | (a1 << 16);
+          }
+        }
+        l_rng[((sz - (rz - h)) * NPAIR + q) * NW + w] = rg;
+      }
 #pragma unroll
       for (int q = 0; q < NPAIR; q++)
 #pragma unroll
@@ -774,7 +811,6 @@ tv_boxx_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
         }
         // the nearer of a pair's two receiver planes: |t - h - 1| or |t - h| planes away
         const int dmin = min(abs(t - h - 1), abs(t - h));
-        const int rho = __builtin_amdgcn_readfirstlane(rho_tab[dmin]);
         const float rr = (float)(h * h - dmin * dmin);
         int pre[NLIST + 1];
         pre[0] = 0;
@@ -838,19 +874,14 @@ tv_boxx_kernel(float* __restrict__ ten, const float* __restrict__ mask_dst,
           __syncthreads();   // lists (and slices) complete
           VH_STAMP(2);
           int i0[NLIST], i1[NLIST];
-          {
-            const int hi_row = 4 * wave + h + 3 + rho, lo_row = 4 * wave + h - rho;
 #pragma unroll
-            for (int k = 0; k < NLIST; k++) {
-              int above = 0, upto = 0;
-              for (int j = 0; j < len[k]; j += 64) {   // uniform
-                int ey = -1;
-                if (j + lane < len[k]) ey = (int)((l_pos[c[k] + j + lane].x >> 8) & 0xffu);
-                above += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ey > hi_row));
-                upto += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ey >= lo_row));
-              }
-              i0[k] = above;
-              i1[k] = upto;
+          for (int k = 0; k < NLIST; k++) {   // (list k = pair k) the wave's stretch cut to this interval's share of the list
+            i0[k] = i1[k] = 0;
+            if (len[k] > 0) {   // uniform
+              const unsigned rg = __builtin_amdgcn_readfirstlane(l_rng[(plane_slot(lsz[k]) * NPAIR + k) * NW + wave]);
+              const int off = c[k] + done - pre[k];
+              i0[k] = min(max((int)(rg & 0xffffu) - off, 0), len[k]);
+              i1[k] = min(max((int)(rg >> 16) - off, 0), len[k]);
             }
           }
           if (i1[0] > i0[0] || i1[1] > i0[1]) {   // uniform
@@ -1112,7 +1143,8 @@ int dev_tv_box(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* te
   const i64 nblk = (i64)p.tiles_x * p.tiles_y * nruns;
   if (nblk > 0x7fffffffLL) return fail(VISFD_HIP_EINVAL, "volume too large for one launch");
   if (nblk <= 0) { *handled = true; return VISFD_HIP_OK; }
-  const size_t lds = 2 * slice_bytes;
+  // two slices + the per-pass table of row stretches ([2h + 4 planes][pairs][waves] words)
+  const size_t lds = 2 * slice_bytes + sizeof(unsigned) * (size_t)(2 * h + 4) * NW * (exact ? NPAIR : 1);
   const size_t lds_static = sizeof(float4) * (LSLOTS + 1) + sizeof(uint2) * LSLOTS + sizeof(uint2) * NW * NSUB * 2 * HCAP + 1536;
   static_assert(2 * HCAP == HX, "the two kernels' hit lists take the same LDS");
   if (lds + lds_static > 150 * 1024) return VISFD_HIP_OK;   // window too wide: the caller falls back
