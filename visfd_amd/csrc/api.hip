@@ -153,21 +153,24 @@ int blob_dog_dev(visfd_hip_ctx* ctx, const float* src, const float* mask, i64 nx
   const float scan_min = use_ratios ? inf : min_thr;
   const float scan_max = use_ratios ? -inf : max_thr;
   // The scan of scale k-1 is queued right behind the filters of scale k, and its list is fetched (auxiliary stream)
-  // and sorted on the host while the GPU already filters scale k+1: the device never waits for the host.
+  // and sorted on the host while the GPU already filters scales k+1 and k+2 (three buffer sets: the host may fall two scales
+  // -- ~20 ms of device work at 1024^3 -- behind before the device runs dry; with two sets a host that needed more than
+  // one scale's time per list stalled the stage: 118 ms on one box, 142 ms on another).
   const bool can_scan = nx >= 3 && ny >= 3 && nz >= 3;
   if (can_scan && (nx >= (1LL << 31) || ny >= (1LL << 31) || nz >= (1LL << 31))) return fail(VISFD_HIP_EINVAL, "dimension too large");
   if (!ctx->aux_stream) VH_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
-  hipEvent_t ev[2] = {nullptr, nullptr};
-  for (int k = 0; k < 2; k++) VH_HIP(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+  constexpr int NSET = 3;
+  hipEvent_t ev[NSET] = {nullptr, nullptr, nullptr};
+  for (int k = 0; k < NSET; k++) VH_HIP(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
   int rc_loop = VISFD_HIP_OK;
   // lists per middle scale (output order is scale order, feature.hpp:236-358); scales whose buffers overflowed in the
   // pipelined scan are repeated on their own afterwards
   std::vector<std::vector<visfd_hip_blob>> smin((size_t)std::max(n_sigma, 1)), smax((size_t)std::max(n_sigma, 1));
   std::vector<int> redo;
-  int pending = -1;   // middle scale whose scan is queued but not collected yet (buffer set: pending & 1)
+  int pending_first = 0, pending_n = 0;   // middle scales whose scans are queued but not collected yet (buffer set: scale % NSET)
   auto collect = [&](int scale) -> int {
     bool overflow = false;
-    VH_TRY(blob_scan_collect(ctx, scale & 1, ev[scale & 1], ctx->aux_stream, nx, ny, n, scale, blob_sigma[scale],
+    VH_TRY(blob_scan_collect(ctx, scale % NSET, ev[scale % NSET], ctx->aux_stream, nx, ny, n, scale, blob_sigma[scale],
                              &smin[(size_t)scale], &smax[(size_t)scale], &overflow));
     if (overflow) redo.push_back(scale);
     return VISFD_HIP_OK;
@@ -176,14 +179,23 @@ int blob_dog_dev(visfd_hip_ctx* ctx, const float* src, const float* mask, i64 nx
     const float sg[3] = {blob_sigma[ir] * asp[0], blob_sigma[ir] * asp[1], blob_sigma[ir] * asp[2]};
     rc_loop = log_dev(ctx, src, vol[ir % 3], tmp, mask, nx, ny, nz, sg, delta, ratio, nullptr, nullptr);
     if (rc_loop != VISFD_HIP_OK || ir < 2 || !can_scan) continue;
-    rc_loop = blob_scan_launch(ctx, (ir - 1) & 1, ev[(ir - 1) & 1], vol[(ir - 2) % 3], vol[(ir - 1) % 3], vol[ir % 3], mask,
+    rc_loop = blob_scan_launch(ctx, (ir - 1) % NSET, ev[(ir - 1) % NSET], vol[(ir - 2) % 3], vol[(ir - 1) % 3], vol[ir % 3], mask,
                                nx, ny, nz, scan_min, scan_max);
     if (rc_loop != VISFD_HIP_OK) continue;
-    if (pending >= 0) rc_loop = collect(pending);
-    pending = ir - 1;
+    if (pending_n == 0) pending_first = ir - 1;
+    pending_n++;
+    if (pending_n == NSET) {   // every buffer set is in use: the oldest list now (its scan was queued two scales ago)
+      rc_loop = collect(pending_first);
+      pending_first++;
+      pending_n--;
+    }
   }
-  if (rc_loop == VISFD_HIP_OK && pending >= 0) rc_loop = collect(pending);
-  for (int k = 0; k < 2; k++) (void)hipEventDestroy(ev[k]);
+  while (rc_loop == VISFD_HIP_OK && pending_n > 0) {
+    rc_loop = collect(pending_first);
+    pending_first++;
+    pending_n--;
+  }
+  for (int k = 0; k < NSET; k++) (void)hipEventDestroy(ev[k]);
   VH_TRY(rc_loop);
   // a candidate or survivor buffer overflowed (dense extrema): those scales again, one at a time, with buffers that grow
   // (the three LoG volumes of the scale are filtered again; the other scales keep their lists)

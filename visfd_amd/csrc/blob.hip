@@ -264,18 +264,19 @@ struct ScanBufs {
 static int scan_bufs(visfd_hip_ctx* ctx, int set, ScanBufs* B, bool pipelined, i64 nvox) {
   // at least 4 M candidates / 1 M survivors, and room for 1 voxel in 32 / 128 (noise volumes at 1024^3 give ~1 in
   // 100 / 1 in 4000 per scale): the pipelined scan then does not overflow on its first call
-  size_t cap_idx = ctx->slot_bytes[WS_TVAUX] / sizeof(unsigned long long) / 2;
+  constexpr size_t NSET = 3;   // buffer sets of the pipelined scan (api.hip: blob_dog_dev)
+  size_t cap_idx = ctx->slot_bytes[WS_TVAUX] / sizeof(unsigned long long) / NSET;
   if (cap_idx < (1u << 22)) cap_idx = 1u << 22;
   if (cap_idx < (size_t)(nvox / 32)) cap_idx = (size_t)(nvox / 32);
-  size_t cap_out = ctx->slot_bytes[WS_CAND] / sizeof(Cand) / 2;
+  size_t cap_out = ctx->slot_bytes[WS_CAND] / sizeof(Cand) / NSET;
   if (cap_out < (1u << 20)) cap_out = 1u << 20;
   if (cap_out < (size_t)(nvox / 128)) cap_out = (size_t)(nvox / 128);
   unsigned long long* idx = nullptr;
   Cand* cand = nullptr;
   unsigned long long* counters = nullptr;
-  VH_TRY(ws(ctx, WS_TVAUX, 2 * cap_idx, &idx));
-  VH_TRY(ws(ctx, WS_CAND, 2 * cap_out, &cand));
-  VH_TRY(ws(ctx, WS_COUNTER, 8, &counters));
+  VH_TRY(ws(ctx, WS_TVAUX, NSET * cap_idx, &idx));
+  VH_TRY(ws(ctx, WS_CAND, NSET * cap_out, &cand));
+  VH_TRY(ws(ctx, WS_COUNTER, 8, &counters));   // (2 words per set)
   B->idx = idx + (size_t)set * cap_idx;
   B->cand = cand + (size_t)set * cap_out;
   B->counters = counters + 2 * set;
@@ -407,12 +408,12 @@ int dev_blob_scan(visfd_hip_ctx* ctx, const float* lo, const float* mid, const f
     if (ctx->opt.debug) fprintf(stderr, "[blob scan] scale %d: %llu candidates\n", scale_index, c2[0]);
     if (c2[0] > B.cap_idx) {   // rare: grow and rescan
       unsigned long long* p = nullptr;
-      VH_TRY(ws(ctx, WS_TVAUX, 2 * (size_t)c2[0] + 16, &p));
+      VH_TRY(ws(ctx, WS_TVAUX, 3 * (size_t)c2[0] + 16, &p));   // (a third of the slot per buffer set: scan_bufs)
       continue;
     }
     if (c2[1] > B.cap_out) {
       Cand* p = nullptr;
-      VH_TRY(ws(ctx, WS_CAND, 2 * (size_t)c2[1] + 16, &p));
+      VH_TRY(ws(ctx, WS_CAND, 3 * (size_t)c2[1] + 16, &p));
       continue;
     }
     std::vector<Cand> h((size_t)c2[1]);
