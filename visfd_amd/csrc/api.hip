@@ -154,8 +154,7 @@ int blob_dog_dev(visfd_hip_ctx* ctx, const float* src, const float* mask, i64 nx
   const float scan_max = use_ratios ? -inf : max_thr;
   // The scan of scale k-1 is queued right behind the filters of scale k, and its list is fetched (auxiliary stream)
   // and sorted on the host while the GPU already filters scales k+1 and k+2 (three buffer sets: the host may fall two scales
-  // -- ~20 ms of device work at 1024^3 -- behind before the device runs dry; with two sets a host that needed more than
-  // one scale's time per list stalled the stage: 118 ms on one box, 142 ms on another).
+  // -- ~20 ms of device work at 1024^3 -- behind before the device runs dry).
   const bool can_scan = nx >= 3 && ny >= 3 && nz >= 3;
   if (can_scan && (nx >= (1LL << 31) || ny >= (1LL << 31) || nz >= (1LL << 31))) return fail(VISFD_HIP_EINVAL, "dimension too large");
   if (!ctx->aux_stream) VH_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
