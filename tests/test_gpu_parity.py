@@ -682,6 +682,21 @@ def test_tensor_voting_very_wide_windows(ctx, oracle, sigma_tv, h):
             assert_bits_equal(ctx.tv_dense_stick(sal, dirs, sigma_tv, 4, 2.0 ** 0.5), ref, "tensor h=%d %s" % (h, opts))
 
 
+@pytest.mark.parametrize("nz", [1, 2, 3, 5])
+def test_tensor_voting_thin_volumes(ctx, oracle, nz):
+    """Volumes of one to five planes (fewer than a pass of the box kernels takes, fewer than the window's reach): both exact
+    kernels bit for bit, the tolerance kernel within its contract; odd row and column counts."""
+    shape = (nz, 21, 35)
+    sal, dirs = _sparse_field(shape, seed=700 + nz, fraction=0.2)
+    want = oracle.tv_dense_stick(sal, dirs, 3.0, 4, 2.0 ** 0.5)
+    assert np.abs(want).max() > 0
+    for opts in ({}, {"tv_exact_tiled": 1}, {"tv_poison": 1, "tv_zrun": 1}):
+        with ctx.options(**opts):
+            assert_bits_equal(ctx.tv_dense_stick(sal, dirs, 3.0, 4, 2.0 ** 0.5), want, "thin-volume tensor nz=%d %s" % (nz, opts))
+    with ctx.options(tv_fma=1, tv_poison=1):
+        assert_close_rel(ctx.tv_dense_stick(sal, dirs, 3.0, 4, 2.0 ** 0.5), want, 1e-5, "thin-volume tensor, tolerance mode nz=%d" % nz)
+
+
 def test_tensor_voting_dense_saliency(ctx, oracle):
     """Every voxel salient: the per-band list overflows one 64-entry chunk many times over."""
     shape = (7, 24, 28)
