@@ -697,6 +697,22 @@ def test_tensor_voting_thin_volumes(ctx, oracle, nz):
         assert_close_rel(ctx.tv_dense_stick(sal, dirs, 3.0, 4, 2.0 ** 0.5), want, 1e-5, "thin-volume tensor, tolerance mode nz=%d" % nz)
 
 
+@pytest.mark.parametrize("shape,sigma_tv", [((6, 5, 7), 3.0), ((4, 40, 9), 8.66), ((3, 3, 50), 8.66), ((10, 33, 17), 1.0)])
+def test_tensor_voting_narrow_volumes(ctx, oracle, shape, sigma_tv):
+    """Volumes narrower than a tile (16 x 32) and than the window: every sender list is shorter than a row of the tile."""
+    sal, dirs = _sparse_field(shape, seed=sum(shape), fraction=0.3)
+    mask = (np.random.default_rng(5).random(shape) > 0.3).astype(np.float32)
+    for m in (None, mask):
+        want = oracle.tv_dense_stick(sal, dirs, sigma_tv, 2, 2.0 ** 0.5, m, m)
+        for opts in ({}, {"tv_exact_tiled": 1}, {"tv_poison": 1}):
+            with ctx.options(**opts):
+                assert_bits_equal(ctx.tv_dense_stick(sal, dirs, sigma_tv, 2, 2.0 ** 0.5, m, m), want,
+                                  "narrow-volume tensor %s %s mask=%s" % (shape, opts, m is not None))
+        with ctx.options(tv_fma=1, tv_poison=1):
+            assert_close_rel(ctx.tv_dense_stick(sal, dirs, sigma_tv, 2, 2.0 ** 0.5, m, m), want, 1e-5,
+                             "narrow-volume tensor, tolerance mode %s" % (shape,))
+
+
 def test_tensor_voting_dense_saliency(ctx, oracle):
     """Every voxel salient: the per-band list overflows one 64-entry chunk many times over."""
     shape = (7, 24, 28)
