@@ -728,6 +728,31 @@ def test_tensor_voting_dense_saliency(ctx, oracle):
 
 
 
+@pytest.mark.parametrize("n", [5, 7, 8, 315, 4096, 70001])
+def test_threshold_fraction_sizes_and_alignment(ctx, oracle, n):
+    """The radix select's histogram reads four values per load where the volume is 16-byte aligned and one by one elsewhere
+    (tails, unaligned device pointers, masks): the selected threshold and the thresholded field equal the oracle's for sizes
+    around those boundaries, aligned and unaligned, masked and unmasked."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(n)
+    vals = (rng.standard_normal(n) ** 2).astype(np.float32)
+    vals[rng.random(n) < 0.1] = 0.0
+    mask = (rng.random(n) > 0.2).astype(np.float32)
+    for m in (None, mask):
+        want = vals.reshape(1, 1, n).copy()
+        thr_o = oracle.threshold_fraction(want, 0.25, None if m is None else m.reshape(1, 1, n))
+        for offset in (0, 1):   # a device pointer 4 bytes past a 16-byte boundary
+            buf = torch.zeros(n + 4, device=dev)
+            sal = buf[offset:offset + n].view(1, 1, n)
+            sal.copy_(torch.from_numpy(vals).to(dev).view(1, 1, n))
+            dm = None if m is None else torch.from_numpy(m).to(dev).view(1, 1, n)
+            thr = ctx.threshold_fraction_dev(sal, 0.25, dm)
+            ctx.synchronize()
+            assert thr == thr_o, (n, offset, m is not None, thr, thr_o)
+            assert_bits_equal(sal.cpu().numpy(), want, "thresholded field n=%d offset=%d" % (n, offset))
+
+
 def test_ridge_two_step_equals_fused(ctx, oracle):
     """Scores for every voxel + directions of the thresholded survivors (what the pipeline runs) against the fused
     kernel that computes both everywhere: identical scores, identical directions where the score survives, nothing
