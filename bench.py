@@ -32,6 +32,7 @@ gives the per-stage split of the step; `cpu_baseline` is the real reference (or 
 absent) timed on this box's host cores on a sample of the same synthetic workload.
 """
 import argparse
+import gc
 import json
 import math
 import os
@@ -401,15 +402,23 @@ def main():
             for _ in range(warmup):
                 step(False, stage_ms)
             torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                step(True, stage_ms)
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-            elapsed = time.perf_counter() - t0
+            # the interpreter's cyclic garbage collector stays out of the timed steps (as timeit does it): with torch loaded a
+            # full collection takes 20-30 ms and showed up as 117 vs 146 ms blob stages from one run to the next
+            # (tools/blob_tail_time.py); everything the steps allocate is freed by reference counts
+            gc.collect()
+            gc.disable()
+            try:
+                if world > 1:
+                    dist.barrier()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    step(True, stage_ms)
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                elapsed = time.perf_counter() - t0
+            finally:
+                gc.enable()
         if world > 1:
             t = torch.tensor([elapsed], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

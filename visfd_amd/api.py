@@ -564,8 +564,12 @@ class Context:
         sig = np.ascontiguousarray(sigmas, np.float32)
         asp = _f3(aspect) if aspect is not None else None
         for attempt in (0, 1):
-            amin = np.empty(cap, _BLOB_DTYPE)   # visfd_hip_blob records
-            amax = np.empty(cap, _BLOB_DTYPE)
+            # the record arrays are kept by the context between calls (a pipeline asks for millions of records of capacity:
+            # mapping and unmapping 2 x 100 MB per call cost 1-25 ms of host time, depending on the state of the machine)
+            bufs = getattr(self, "_blob_bufs", None)
+            if bufs is None or len(bufs[0]) < cap:
+                bufs = self._blob_bufs = (np.empty(cap, _BLOB_DTYPE), np.empty(cap, _BLOB_DTYPE))   # visfd_hip_blob records
+            amin, amax = bufs   # (at least `cap` records; the call is still told `cap`)
             nmin, nmax = _i64(), _i64()
             rc = fn(self._h, psrc, pmask, nx, ny, nz, sig.ctypes.data_as(_fp), len(sig), asp, float(delta),
                     float(ratio), float(minima_threshold), float(maxima_threshold), int(use_ratios),

@@ -1,6 +1,7 @@
 // api.hip -- the extern "C" surface declared in include/visfd_hip.h.
 // Device-pointer entry points orchestrate the stage functions; host-pointer entry points stage the
 // caller's volumes through the context workspace (H2D, run, D2H) and are synchronous.
+#include <chrono>
 #include <cmath>
 #include <cctype>
 #include <cstdlib>
@@ -161,6 +162,8 @@ int blob_dog_dev(visfd_hip_ctx* ctx, const float* src, const float* mask, i64 nx
   constexpr int NSET = 3;
   hipEvent_t ev[NSET] = {nullptr, nullptr, nullptr};
   for (int k = 0; k < NSET; k++) VH_HIP(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+  const auto t_start = std::chrono::steady_clock::now();
+  auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
   int rc_loop = VISFD_HIP_OK;
   // lists per middle scale (output order is scale order, feature.hpp:236-358); scales whose buffers overflowed in the
   // pipelined scan are repeated on their own afterwards
@@ -189,11 +192,13 @@ int blob_dog_dev(visfd_hip_ctx* ctx, const float* src, const float* mask, i64 nx
       pending_n--;
     }
   }
+  if (ctx->opt.debug) fprintf(stderr, "[blob_dog] everything queued at %.1f ms\n", since());
   while (rc_loop == VISFD_HIP_OK && pending_n > 0) {
     rc_loop = collect(pending_first);
     pending_first++;
     pending_n--;
   }
+  if (ctx->opt.debug) fprintf(stderr, "[blob_dog] last list collected at %.1f ms\n", since());
   for (int k = 0; k < NSET; k++) (void)hipEventDestroy(ev[k]);
   VH_TRY(rc_loop);
   // a candidate or survivor buffer overflowed (dense extrema): those scales again, one at a time, with buffers that grow
@@ -229,6 +234,7 @@ int blob_dog_dev(visfd_hip_ctx* ctx, const float* src, const float* mask, i64 nx
     mins.swap(a);
     maxs.swap(b);
   }
+  if (ctx->opt.debug) fprintf(stderr, "[blob_dog] lists merged at %.1f ms\n", since());
   *n_min = (int64_t)mins.size();
   *n_max = (int64_t)maxs.size();
   int rc = VISFD_HIP_OK;
@@ -236,6 +242,7 @@ int blob_dog_dev(visfd_hip_ctx* ctx, const float* src, const float* mask, i64 nx
     rc = fail(VISFD_HIP_ECAPACITY, "blob list capacity too small");
   for (int64_t i = 0; i < (int64_t)mins.size() && i < min_cap; i++) minima[i] = mins[i];
   for (int64_t i = 0; i < (int64_t)maxs.size() && i < max_cap; i++) maxima[i] = maxs[i];
+  if (ctx->opt.debug) fprintf(stderr, "[blob_dog] lists copied out at %.1f ms\n", since());
   return rc;
 }
 
