@@ -211,6 +211,29 @@ def cpu_baseline_child(argv):
 STAGE_BYTES_PER_VOXEL = {"gauss": 8.0, "blob_dog": 216.0, "membrane_tv": 112.0}
 
 
+def bind_to_gpu_numa_node(torch, dev_index):
+    """One process per GPU, its host thread on the GPU's own socket: the box has two NUMA nodes and eight GPUs, and a host thread
+    that lands on the other socket stages its device-to-host copies and sorts its blob lists through remote memory (the blob
+    stage's host tail then took 25 ms instead of 4).  Returns the node bound to, or None (no such information: nothing done)."""
+    try:
+        p = torch.cuda.get_device_properties(dev_index)
+        bus = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bus).read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return node
+    except Exception:
+        return None
+
+
 def offline_traffic(stem, shape):
     """HBM bytes per launch from PMC counters, measured offline (tools/profile_round.sh) and committed under profiles/:
     the newest round's file for this shape, or (None, None)."""
@@ -298,6 +321,7 @@ def main():
     dev_index = local_rank if own_gpu else 0
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    host_numa_node = bind_to_gpu_numa_node(torch, dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if own_gpu:
@@ -378,10 +402,14 @@ def main():
         pipeline.gauss(ctx, src, dst, GAUSS_SIGMA)
         if record:
             ev[1].record()
+        job = None
         if world > 1:
             mins, maxs = slab.blob_detect_slab(ctx, layout, src, sig, src_halo_ready=True)
         else:
-            mins, maxs = pipeline.blob_detect(ctx, src, sig)
+            # blob detection in two halves (visfd_hip_blob_dog_begin_dev / _end): its last lists are fetched, merged and converted
+            # while the device already runs the membrane stage -- the device goes from the last scan straight into the ridge
+            # kernels (an idle MI355X took 5-25 ms to start the next kernel after the 6-9 ms of host work that used to sit here)
+            job = pipeline.blob_detect_begin(ctx, src, sig)
         if record:
             ev[2].record()
         if world > 1:
@@ -390,6 +418,9 @@ def main():
             thr = pipeline.membrane_detect(ctx, src, sal, dirs, ten, scratch=dst, **MEMBRANE)
         if record:
             ev[3].record()
+        if job is not None:
+            mins, maxs = pipeline.blob_detect_end(ctx, job)
+        if record:
             torch.cuda.synchronize()
             for i in range(3):
                 stage_ms[i] += ev[i].elapsed_time(ev[i + 1])
@@ -656,6 +687,7 @@ def main():
                        "mode_note": "tolerance: tensor voting and the stage-1 Gaussian use fused multiply-adds (float outputs, "
                                     "1e-5 of the field's scale, tests/test_tolerance_modes.py); every LoG, the non-max scan and "
                                     "the radix select stay bit-exact.  exact: bit-exact kernels everywhere",
+                       "host_numa_node": host_numa_node,
                        "per_gpu_voxels": nvox_rank, "decomposition": "z-slabs, ghost %d" % layout.ghost,
                        "halo_transport": halo_transport},
             "stages_ms": headline["stages_ms"],

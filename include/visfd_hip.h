@@ -59,7 +59,7 @@ void* visfd_hip_get_stream(visfd_hip_ctx* ctx);
 /* release the cached workspace (it otherwise persists between calls) */
 int visfd_hip_trim(visfd_hip_ctx* ctx);
 const char* visfd_hip_last_error(void);
-int visfd_hip_abi_version(void);   /* 8: entry points only get added between versions */
+int visfd_hip_abi_version(void);   /* 9: entry points only get added between versions */
 /* Tuning and test switches of a context (integers; unknown names are VISFD_HIP_EINVAL).  A new context starts from the
  * environment (VISFD_HIP_<NAME>, read once in visfd_hip_create); nothing reads the environment afterwards.
  *   gauss_3pass      1: the separable filter always takes its three single-axis passes
@@ -191,6 +191,23 @@ int visfd_hip_blob_dog_dev(visfd_hip_ctx*, const float* src, const float* mask,
                            int use_threshold_ratios,
                            visfd_hip_blob* minima, int64_t minima_capacity, int64_t* n_minima,
                            visfd_hip_blob* maxima, int64_t maxima_capacity, int64_t* n_maxima);
+/* The same detector in two halves, for hosts that have more work for the context's stream (ABI >= 9; no reference counterpart:
+ * BlobDog is one call there).  `begin` queues every filter and scan and fetches the lists of all scales but the last few; `end`
+ * fetches those, repeats scales whose buffers overflowed, merges, and hands the lists over exactly as visfd_hip_blob_dog_dev does.
+ * Between the two the caller may queue other calls of the SAME context (a membrane stage): the device then goes from the last
+ * scan straight into that work instead of idling through the host's list handling.  src and mask must stay unchanged until
+ * `end` returns.  VISFD_HIP_ECAPACITY from `end` leaves the job alive and returns the counts: call `end` again with room for
+ * them; every other return value of `end` -- and visfd_hip_blob_dog_abort -- frees the job. */
+typedef struct visfd_hip_blob_job visfd_hip_blob_job;
+int visfd_hip_blob_dog_begin_dev(visfd_hip_ctx*, const float* src, const float* mask,
+                                 int64_t nx, int64_t ny, int64_t nz, const float* blob_sigma,
+                                 int n_sigma, const float* aspect_ratio, float delta_sigma_over_sigma,
+                                 float truncate_ratio, float minima_threshold, float maxima_threshold,
+                                 int use_threshold_ratios, visfd_hip_blob_job** job_out);
+int visfd_hip_blob_dog_end(visfd_hip_blob_job* job,
+                           visfd_hip_blob* minima, int64_t minima_capacity, int64_t* n_minima,
+                           visfd_hip_blob* maxima, int64_t maxima_capacity, int64_t* n_maxima);
+void visfd_hip_blob_dog_abort(visfd_hip_blob_job* job);
 /* BlobDogD's conversions, lib/visfd/feature.hpp:475 and :504 */
 int visfd_hip_blob_diameters_to_sigmas(const float* diameters, int n, float* sigmas);
 int visfd_hip_blob_sigmas_to_diameters(const float* sigmas, int n, float* diameters);

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(lib):
     for n in names:
         assert hasattr(L, n), "libvisfd_hip.so does not export " + n
     assert sorted(lib.exported_symbols()) == names, "visfd_amd/api.py and include/visfd_hip.h disagree"
-    assert L.visfd_hip_abi_version() == 8
+    assert L.visfd_hip_abi_version() == 9
 
 
 def test_host_arithmetic_matches_oracle(lib, oracle):

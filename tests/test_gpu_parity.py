@@ -297,6 +297,39 @@ def test_blob_pure_noise_fine_scales(ctx, oracle):
         assert_bits_equal(volgen.sort_blobs(a[1], False), volgen.sort_blobs(b[1], False), "maxima")
 
 
+def test_blob_dog_in_two_halves(ctx, oracle):
+    """visfd_hip_blob_dog_begin_dev / _end with other work of the same context queued in between (a Gaussian that reuses the
+    filter workspaces, a radix select, tensor voting: every workspace the detector shares with other stages): the lists of the
+    one-call form, bit for bit; the capacity retry of `end` (the job survives VISFD_HIP_ECAPACITY); abort."""
+    import torch
+    dev = torch.device("cuda:0")
+    shape = (40, 44, 48)
+    src_h = volgen.blob_volume(shape, seed=31, nblobs=60)
+    sig = np.array([1.2, 1.5, 1.9, 2.4, 3.0, 3.7], np.float32)
+    want = oracle.blob_dog(src_h, sig, None, None, 0.02, 2.5)
+    src = torch.from_numpy(src_h).to(dev)
+    for cap in (1 << 16, 3):
+        job = ctx.blob_dog_begin_dev(src, sig, None, None, 0.02, 2.5)
+        other = torch.empty_like(src)
+        ctx.gauss_dev(src, other, (2.0, 2.0, 2.0), (5, 5, 5))
+        sal = (other - other.min()).contiguous()
+        ctx.threshold_fraction_dev(sal, 0.1)
+        dirs = torch.zeros((3,) + shape, device=dev)
+        dirs[0] = 1.0
+        ten = torch.empty((6,) + shape, device=dev)
+        ctx.tv_dense_stick_dev(sal, dirs, ten, 3.0, 4, 2.0 ** 0.5)
+        got = ctx.blob_dog_end(job, cap)
+        assert_bits_equal(volgen.sort_blobs(got[0], True), volgen.sort_blobs(want[0], True), "minima, two halves, cap %d" % cap)
+        assert_bits_equal(volgen.sort_blobs(got[1], False), volgen.sort_blobs(want[1], False), "maxima, two halves, cap %d" % cap)
+        with pytest.raises(ValueError):
+            ctx.blob_dog_end(job, cap)
+    job = ctx.blob_dog_begin_dev(src, sig, None, None, 0.02, 2.5)
+    ctx.blob_dog_abort(job)
+    ctx.blob_dog_abort(job)     # (a finished job: nothing to do)
+    one = ctx.blob_dog_dev(src, sig, None, None, 0.02, 2.5)
+    assert_bits_equal(volgen.sort_blobs(one[0], True), volgen.sort_blobs(want[0], True), "one call after an abort")
+
+
 def test_blob_tiny_images(ctx, oracle):
     src = volgen.noise_volume((2, 9, 9), seed=3)
     a = ctx.blob_dog(src, np.array([1, 1.3, 1.7], np.float32), None, None, 0.02, 2.5)

@@ -71,6 +71,10 @@ _SIGS = {
     "visfd_hip_blob_dog_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _fp, C.c_int, _fp, C.c_float, C.c_float,
                                          C.c_float, C.c_float, C.c_int, C.POINTER(Blob), _i64, C.POINTER(_i64),
                                          C.POINTER(Blob), _i64, C.POINTER(_i64)]),
+    "visfd_hip_blob_dog_begin_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _fp, C.c_int, _fp, C.c_float, C.c_float,
+                                               C.c_float, C.c_float, C.c_int, C.POINTER(_vp)]),
+    "visfd_hip_blob_dog_end": (C.c_int, [_vp, C.POINTER(Blob), _i64, C.POINTER(_i64), C.POINTER(Blob), _i64, C.POINTER(_i64)]),
+    "visfd_hip_blob_dog_abort": (None, [_vp]),
     "visfd_hip_blob_diameters_to_sigmas": (C.c_int, [_fp, C.c_int, _fp]),
     "visfd_hip_blob_sigmas_to_diameters": (C.c_int, [_fp, C.c_int, _fp]),
     "visfd_hip_calc_hessian": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, C.c_float, C.c_float]),
@@ -581,6 +585,47 @@ class Context:
             self._chk(rc)
             break
         return _blobs_to_rows(amin, nmin.value)[0], _blobs_to_rows(amax, nmax.value)[0]
+
+    def blob_dog_begin_dev(self, src, sigmas, mask=None, aspect=None, delta=0.02, ratio=2.5, minima_threshold=np.inf,
+                           maxima_threshold=-np.inf, use_ratios=False):
+        """First half of blob_dog_dev (visfd_hip_blob_dog_begin_dev): everything queued, most lists fetched; returns a job for
+        blob_dog_end().  Other calls of this context may be queued in between; src and mask must stay as they are until then."""
+        nz, ny, nx = src.shape
+        sig = np.ascontiguousarray(sigmas, np.float32)
+        asp = _f3(aspect) if aspect is not None else None
+        job = _vp()
+        self._chk(self._L.visfd_hip_blob_dog_begin_dev(self._h, _dev(src), _dev(mask), nx, ny, nz, sig.ctypes.data_as(_fp), len(sig),
+                                                       asp, float(delta), float(ratio), float(minima_threshold),
+                                                       float(maxima_threshold), int(use_ratios), C.byref(job)))
+        return [job, src, mask, sig]   # (the tensors and the sigma array live as long as the job)
+
+    def blob_dog_end(self, job, cap=1 << 16):
+        """Second half: -> (minima, maxima) rows x,y,z,sigma,score, as blob_dog_dev returns them."""
+        h = job[0]
+        if h is None:
+            raise ValueError("blob job already finished")
+        for attempt in (0, 1):
+            bufs = getattr(self, "_blob_bufs", None)
+            if bufs is None or len(bufs[0]) < cap:
+                bufs = self._blob_bufs = (np.empty(cap, _BLOB_DTYPE), np.empty(cap, _BLOB_DTYPE))
+            amin, amax = bufs
+            nmin, nmax = _i64(), _i64()
+            rc = self._L.visfd_hip_blob_dog_end(h, amin.ctypes.data_as(C.POINTER(Blob)), cap, C.byref(nmin),
+                                                amax.ctypes.data_as(C.POINTER(Blob)), cap, C.byref(nmax))
+            if rc == 4 and attempt == 0:   # VISFD_HIP_ECAPACITY: the job is still alive, the counts came back
+                cap = max(nmin.value, nmax.value, 1)
+                continue
+            job[0] = None                   # every other outcome has freed the job
+            if rc == 4:
+                self._L.visfd_hip_blob_dog_abort(h)
+            self._chk(rc)
+            break
+        return _blobs_to_rows(amin, nmin.value)[0], _blobs_to_rows(amax, nmax.value)[0]
+
+    def blob_dog_abort(self, job):
+        if job[0] is not None:
+            self._L.visfd_hip_blob_dog_abort(job[0])
+            job[0] = None
 
     def blob_dog(self, src, sigmas, mask=None, aspect=None, delta=0.02, ratio=2.5, minima_threshold=np.inf,
                  maxima_threshold=-np.inf, use_ratios=False, cap=1 << 16):

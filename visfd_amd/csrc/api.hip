@@ -6,6 +6,7 @@
 #include <cctype>
 #include <cstdlib>
 #include <limits>
+#include <memory>
 #include <vector>
 
 #include "common.hpp"
@@ -131,13 +132,48 @@ int log_dev(visfd_hip_ctx* ctx, const float* src, float* dst, float* tmp, const 
   return VISFD_HIP_OK;
 }
 
-int blob_dog_dev(visfd_hip_ctx* ctx, const float* src, const float* mask, i64 nx, i64 ny, i64 nz,
-                 const float* blob_sigma, int n_sigma, const float* aspect, float delta, float ratio,
-                 float min_thr, float max_thr, bool use_ratios, visfd_hip_blob* minima, int64_t min_cap,
-                 int64_t* n_min, visfd_hip_blob* maxima, int64_t max_cap, int64_t* n_max) {
-  VH_REQUIRE(ctx && src && blob_sigma && n_min && n_max, "null argument");
+// BlobDog in two halves (visfd_hip_blob_dog_begin_dev / _end): `begin` queues every filter and scan and collects the lists
+// of all scales but the last few; `end` collects those, repeats overflowed scales, merges and hands the lists over.  A caller
+// that has more device work for the same stream (the membrane stage of a pipeline) queues it between the two: the device
+// then goes from the last scan straight into that work instead of idling through the host's list handling (6-9 ms at
+// 1024^3 -- and an idle MI355X took up to 25 ms more to start the next kernel).
+struct BlobJob {
+  visfd_hip_ctx* ctx = nullptr;
+  const float* src = nullptr;
+  const float* mask = nullptr;
+  i64 nx = 0, ny = 0, nz = 0;
+  std::vector<float> sigma;
+  float asp[3] = {1.0f, 1.0f, 1.0f};
+  float delta = 0, ratio = 0, min_thr = 0, max_thr = 0, scan_min = 0, scan_max = 0;
+  bool use_ratios = false, can_scan = false, merged = false;
+  static constexpr int NSET = 3;
+  hipEvent_t ev[NSET] = {nullptr, nullptr, nullptr};
+  std::vector<std::vector<visfd_hip_blob>> smin, smax;   // lists per middle scale (output order is scale order, feature.hpp:236-358)
+  std::vector<int> redo;                                  // scales whose buffers overflowed in the pipelined scan
+  int pending_first = 0, pending_n = 0;                   // middle scales whose scans are queued but not collected yet (set: scale % NSET)
+  std::vector<visfd_hip_blob> mins, maxs;                 // the merged lists (after `merged`)
+  std::chrono::steady_clock::time_point t_start;
+  double since() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); }
+  ~BlobJob() {
+    for (int k = 0; k < NSET; k++)
+      if (ev[k]) (void)hipEventDestroy(ev[k]);
+  }
+  int collect(int scale) {
+    bool overflow = false;
+    VH_TRY(blob_scan_collect(ctx, scale % NSET, ev[scale % NSET], ctx->aux_stream, nx, ny, nx * ny * nz, scale, sigma[(size_t)scale],
+                             &smin[(size_t)scale], &smax[(size_t)scale], &overflow));
+    if (overflow) redo.push_back(scale);
+    return VISFD_HIP_OK;
+  }
+};
+
+int blob_dog_begin(visfd_hip_ctx* ctx, const float* src, const float* mask, i64 nx, i64 ny, i64 nz,
+                   const float* blob_sigma, int n_sigma, const float* aspect, float delta, float ratio,
+                   float min_thr, float max_thr, bool use_ratios, BlobJob** job_out) {
+  VH_REQUIRE(ctx && src && (blob_sigma || n_sigma == 0) && job_out, "null argument");
   VH_REQUIRE(n_sigma >= 0, "negative scale count");
   VH_TRY(check_dims(nx, ny, nz));
+  *job_out = nullptr;
   const i64 n = nx * ny * nz;
   const float inf = std::numeric_limits<float>::infinity();
   float* vol[3];
@@ -146,103 +182,136 @@ int blob_dog_dev(visfd_hip_ctx* ctx, const float* src, const float* mask, i64 nx
   VH_TRY(ws(ctx, WS_LOG2, (size_t)n, &vol[2]));
   float* tmp = nullptr;
   VH_TRY(ws(ctx, WS_C, (size_t)n, &tmp));
-  float asp[3] = {1.0f, 1.0f, 1.0f};
-  if (aspect) for (int d = 0; d < 3; d++) asp[d] = aspect[d];
-  std::vector<visfd_hip_blob> mins, maxs;
+  std::unique_ptr<BlobJob> J(new BlobJob);
+  J->ctx = ctx; J->src = src; J->mask = mask; J->nx = nx; J->ny = ny; J->nz = nz;
+  J->sigma.assign(blob_sigma, blob_sigma + n_sigma);
+  if (aspect) for (int d = 0; d < 3; d++) J->asp[d] = aspect[d];
+  J->delta = delta; J->ratio = ratio; J->min_thr = min_thr; J->max_thr = max_thr; J->use_ratios = use_ratios;
   // running thresholds: absolute mode applies them in the scan (strict, feature.hpp:270-291);
   // ratio mode keeps every candidate and prunes at the end (feature.hpp:362-417), see header.
-  const float scan_min = use_ratios ? inf : min_thr;
-  const float scan_max = use_ratios ? -inf : max_thr;
+  J->scan_min = use_ratios ? inf : min_thr;
+  J->scan_max = use_ratios ? -inf : max_thr;
+  J->t_start = std::chrono::steady_clock::now();
   // The scan of scale k-1 is queued right behind the filters of scale k, and its list is fetched (auxiliary stream)
   // and sorted on the host while the GPU already filters scales k+1 and k+2 (three buffer sets: the host may fall two scales
   // -- ~20 ms of device work at 1024^3 -- behind before the device runs dry).
-  const bool can_scan = nx >= 3 && ny >= 3 && nz >= 3;
-  if (can_scan && (nx >= (1LL << 31) || ny >= (1LL << 31) || nz >= (1LL << 31))) return fail(VISFD_HIP_EINVAL, "dimension too large");
+  J->can_scan = nx >= 3 && ny >= 3 && nz >= 3;
+  if (J->can_scan && (nx >= (1LL << 31) || ny >= (1LL << 31) || nz >= (1LL << 31))) return fail(VISFD_HIP_EINVAL, "dimension too large");
   if (!ctx->aux_stream) VH_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
-  constexpr int NSET = 3;
-  hipEvent_t ev[NSET] = {nullptr, nullptr, nullptr};
-  for (int k = 0; k < NSET; k++) VH_HIP(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
-  const auto t_start = std::chrono::steady_clock::now();
-  auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
-  int rc_loop = VISFD_HIP_OK;
-  // lists per middle scale (output order is scale order, feature.hpp:236-358); scales whose buffers overflowed in the
-  // pipelined scan are repeated on their own afterwards
-  std::vector<std::vector<visfd_hip_blob>> smin((size_t)std::max(n_sigma, 1)), smax((size_t)std::max(n_sigma, 1));
-  std::vector<int> redo;
-  int pending_first = 0, pending_n = 0;   // middle scales whose scans are queued but not collected yet (buffer set: scale % NSET)
-  auto collect = [&](int scale) -> int {
-    bool overflow = false;
-    VH_TRY(blob_scan_collect(ctx, scale % NSET, ev[scale % NSET], ctx->aux_stream, nx, ny, n, scale, blob_sigma[scale],
-                             &smin[(size_t)scale], &smax[(size_t)scale], &overflow));
-    if (overflow) redo.push_back(scale);
-    return VISFD_HIP_OK;
-  };
-  for (int ir = 0; ir < n_sigma && rc_loop == VISFD_HIP_OK; ir++) {
-    const float sg[3] = {blob_sigma[ir] * asp[0], blob_sigma[ir] * asp[1], blob_sigma[ir] * asp[2]};
-    rc_loop = log_dev(ctx, src, vol[ir % 3], tmp, mask, nx, ny, nz, sg, delta, ratio, nullptr, nullptr);
-    if (rc_loop != VISFD_HIP_OK || ir < 2 || !can_scan) continue;
-    rc_loop = blob_scan_launch(ctx, (ir - 1) % NSET, ev[(ir - 1) % NSET], vol[(ir - 2) % 3], vol[(ir - 1) % 3], vol[ir % 3], mask,
-                               nx, ny, nz, scan_min, scan_max);
-    if (rc_loop != VISFD_HIP_OK) continue;
-    if (pending_n == 0) pending_first = ir - 1;
-    pending_n++;
-    if (pending_n == NSET) {   // every buffer set is in use: the oldest list now (its scan was queued two scales ago)
-      rc_loop = collect(pending_first);
-      pending_first++;
-      pending_n--;
+  for (int k = 0; k < BlobJob::NSET; k++) VH_HIP(hipEventCreateWithFlags(&J->ev[k], hipEventDisableTiming));
+  J->smin.resize((size_t)std::max(n_sigma, 1));
+  J->smax.resize((size_t)std::max(n_sigma, 1));
+  for (int ir = 0; ir < n_sigma; ir++) {
+    const float sg[3] = {blob_sigma[ir] * J->asp[0], blob_sigma[ir] * J->asp[1], blob_sigma[ir] * J->asp[2]};
+    VH_TRY(log_dev(ctx, src, vol[ir % 3], tmp, mask, nx, ny, nz, sg, delta, ratio, nullptr, nullptr));
+    if (ir < 2 || !J->can_scan) continue;
+    VH_TRY(blob_scan_launch(ctx, (ir - 1) % BlobJob::NSET, J->ev[(ir - 1) % BlobJob::NSET], vol[(ir - 2) % 3], vol[(ir - 1) % 3],
+                            vol[ir % 3], mask, nx, ny, nz, J->scan_min, J->scan_max));
+    if (J->pending_n == 0) J->pending_first = ir - 1;
+    J->pending_n++;
+    if (J->pending_n == BlobJob::NSET) {   // every buffer set is in use: the oldest list now (its scan was queued two scales ago)
+      VH_TRY(J->collect(J->pending_first));
+      J->pending_first++;
+      J->pending_n--;
     }
   }
-  if (ctx->opt.debug) fprintf(stderr, "[blob_dog] everything queued at %.1f ms\n", since());
-  while (rc_loop == VISFD_HIP_OK && pending_n > 0) {
-    rc_loop = collect(pending_first);
-    pending_first++;
-    pending_n--;
-  }
-  if (ctx->opt.debug) fprintf(stderr, "[blob_dog] last list collected at %.1f ms\n", since());
-  for (int k = 0; k < NSET; k++) (void)hipEventDestroy(ev[k]);
-  VH_TRY(rc_loop);
-  // a candidate or survivor buffer overflowed (dense extrema): those scales again, one at a time, with buffers that grow
-  // (the three LoG volumes of the scale are filtered again; the other scales keep their lists)
-  for (int sc : redo) {
-    for (int k = 0; k < 3; k++) {
-      const int ir = sc - 1 + k;
-      const float sg[3] = {blob_sigma[ir] * asp[0], blob_sigma[ir] * asp[1], blob_sigma[ir] * asp[2]};
-      VH_TRY(log_dev(ctx, src, vol[k], tmp, mask, nx, ny, nz, sg, delta, ratio, nullptr, nullptr));
+  if (ctx->opt.debug) fprintf(stderr, "[blob_dog] everything queued at %.1f ms\n", J->since());
+  *job_out = J.release();
+  return VISFD_HIP_OK;
+}
+
+// Collects what `begin` left, merges, and copies out.  VISFD_HIP_ECAPACITY leaves the job alive (the counts are returned: call
+// again with room for them); every other outcome frees it.
+int blob_dog_end(BlobJob* job, visfd_hip_blob* minima, int64_t min_cap, int64_t* n_min, visfd_hip_blob* maxima, int64_t max_cap,
+                 int64_t* n_max) {
+  VH_REQUIRE(job && n_min && n_max, "null argument");
+  std::unique_ptr<BlobJob> J(job);
+  visfd_hip_ctx* ctx = J->ctx;
+  const float inf = std::numeric_limits<float>::infinity();
+  if (!J->merged) {
+    while (J->pending_n > 0) {
+      VH_TRY(J->collect(J->pending_first));
+      J->pending_first++;
+      J->pending_n--;
     }
-    smin[(size_t)sc].clear();
-    smax[(size_t)sc].clear();
-    VH_TRY(dev_blob_scan(ctx, vol[0], vol[1], vol[2], mask, nx, ny, nz, sc, blob_sigma[sc], scan_min, scan_max, true, true,
-                         &smin[(size_t)sc], &smax[(size_t)sc]));
-  }
-  for (auto& v : smin) mins.insert(mins.end(), v.begin(), v.end());
-  for (auto& v : smax) maxs.insert(maxs.end(), v.begin(), v.end());
-  // Ratio mode with max_thr = -inf: the reference's scan compares score > (-inf) * (its running best, initially -1) = +inf in
-  // every thread, so it never records a maximum (feature.hpp:286-289) -- deterministically none.
-  if (use_ratios && max_thr == -inf) maxs.clear();
-  if ((min_thr != inf) || (max_thr != -inf)) {
-    float tmin = min_thr, tmax = max_thr;
-    if (use_ratios) {
-      float gmin = 1.0f, gmax = -1.0f;  // feature.hpp:122-123
-      for (auto& b : mins) if (b.score < gmin) gmin = b.score;
-      for (auto& b : maxs) if (b.score > gmax) gmax = b.score;
-      tmin = min_thr * gmin;   // feature.hpp:369-372, unconditionally: +inf * (negative best) = -inf keeps no minimum
-      tmax = max_thr * gmax;
+    if (ctx->opt.debug) fprintf(stderr, "[blob_dog] last list collected at %.1f ms\n", J->since());
+    // a candidate or survivor buffer overflowed (dense extrema): those scales again, one at a time, with buffers that grow
+    // (the three LoG volumes of the scale are filtered again; the other scales keep their lists)
+    if (!J->redo.empty()) {
+      const i64 n = J->nx * J->ny * J->nz;
+      float* vol[3];
+      VH_TRY(ws(ctx, WS_LOG0, (size_t)n, &vol[0]));
+      VH_TRY(ws(ctx, WS_LOG1, (size_t)n, &vol[1]));
+      VH_TRY(ws(ctx, WS_LOG2, (size_t)n, &vol[2]));
+      float* tmp = nullptr;
+      VH_TRY(ws(ctx, WS_C, (size_t)n, &tmp));
+      for (int sc : J->redo) {
+        for (int k = 0; k < 3; k++) {
+          const int ir = sc - 1 + k;
+          const float sg[3] = {J->sigma[(size_t)ir] * J->asp[0], J->sigma[(size_t)ir] * J->asp[1], J->sigma[(size_t)ir] * J->asp[2]};
+          VH_TRY(log_dev(ctx, J->src, vol[k], tmp, J->mask, J->nx, J->ny, J->nz, sg, J->delta, J->ratio, nullptr, nullptr));
+        }
+        J->smin[(size_t)sc].clear();
+        J->smax[(size_t)sc].clear();
+        VH_TRY(dev_blob_scan(ctx, vol[0], vol[1], vol[2], J->mask, J->nx, J->ny, J->nz, sc, J->sigma[(size_t)sc], J->scan_min,
+                             J->scan_max, true, true, &J->smin[(size_t)sc], &J->smax[(size_t)sc]));
+      }
+      J->redo.clear();
     }
-    std::vector<visfd_hip_blob> a, b;
-    for (auto& m : mins) if (m.score <= tmin) a.push_back(m);
-    for (auto& m : maxs) if (m.score >= tmax) b.push_back(m);
-    mins.swap(a);
-    maxs.swap(b);
+    std::vector<visfd_hip_blob>& mins = J->mins;
+    std::vector<visfd_hip_blob>& maxs = J->maxs;
+    for (auto& v : J->smin) mins.insert(mins.end(), v.begin(), v.end());
+    for (auto& v : J->smax) maxs.insert(maxs.end(), v.begin(), v.end());
+    J->smin.clear();
+    J->smax.clear();
+    // Ratio mode with max_thr = -inf: the reference's scan compares score > (-inf) * (its running best, initially -1) = +inf in
+    // every thread, so it never records a maximum (feature.hpp:286-289) -- deterministically none.
+    if (J->use_ratios && J->max_thr == -inf) maxs.clear();
+    if ((J->min_thr != inf) || (J->max_thr != -inf)) {
+      float tmin = J->min_thr, tmax = J->max_thr;
+      if (J->use_ratios) {
+        float gmin = 1.0f, gmax = -1.0f;  // feature.hpp:122-123
+        for (auto& b : mins) if (b.score < gmin) gmin = b.score;
+        for (auto& b : maxs) if (b.score > gmax) gmax = b.score;
+        tmin = J->min_thr * gmin;   // feature.hpp:369-372, unconditionally: +inf * (negative best) = -inf keeps no minimum
+        tmax = J->max_thr * gmax;
+      }
+      std::vector<visfd_hip_blob> a, b;
+      for (auto& m : mins) if (m.score <= tmin) a.push_back(m);
+      for (auto& m : maxs) if (m.score >= tmax) b.push_back(m);
+      mins.swap(a);
+      maxs.swap(b);
+    }
+    J->merged = true;
+    if (ctx->opt.debug) fprintf(stderr, "[blob_dog] lists merged at %.1f ms\n", J->since());
   }
-  if (ctx->opt.debug) fprintf(stderr, "[blob_dog] lists merged at %.1f ms\n", since());
-  *n_min = (int64_t)mins.size();
-  *n_max = (int64_t)maxs.size();
-  int rc = VISFD_HIP_OK;
-  if ((int64_t)mins.size() > min_cap || (int64_t)maxs.size() > max_cap)
-    rc = fail(VISFD_HIP_ECAPACITY, "blob list capacity too small");
-  for (int64_t i = 0; i < (int64_t)mins.size() && i < min_cap; i++) minima[i] = mins[i];
-  for (int64_t i = 0; i < (int64_t)maxs.size() && i < max_cap; i++) maxima[i] = maxs[i];
-  if (ctx->opt.debug) fprintf(stderr, "[blob_dog] lists copied out at %.1f ms\n", since());
+  *n_min = (int64_t)J->mins.size();
+  *n_max = (int64_t)J->maxs.size();
+  if ((int64_t)J->mins.size() > min_cap || (int64_t)J->maxs.size() > max_cap) {
+    J.release();   // kept: the caller comes back with room for the counts just returned
+    return fail(VISFD_HIP_ECAPACITY, "blob list capacity too small");
+  }
+  VH_REQUIRE((minima || J->mins.empty()) && (maxima || J->maxs.empty()), "null list array");
+  for (size_t i = 0; i < J->mins.size(); i++) minima[i] = J->mins[i];
+  for (size_t i = 0; i < J->maxs.size(); i++) maxima[i] = J->maxs[i];
+  if (ctx->opt.debug) fprintf(stderr, "[blob_dog] lists copied out at %.1f ms\n", J->since());
+  return VISFD_HIP_OK;
+}
+
+int blob_dog_dev(visfd_hip_ctx* ctx, const float* src, const float* mask, i64 nx, i64 ny, i64 nz,
+                 const float* blob_sigma, int n_sigma, const float* aspect, float delta, float ratio,
+                 float min_thr, float max_thr, bool use_ratios, visfd_hip_blob* minima, int64_t min_cap,
+                 int64_t* n_min, visfd_hip_blob* maxima, int64_t max_cap, int64_t* n_max) {
+  VH_REQUIRE(ctx && src && blob_sigma && n_min && n_max, "null argument");
+  BlobJob* job = nullptr;
+  VH_TRY(blob_dog_begin(ctx, src, mask, nx, ny, nz, blob_sigma, n_sigma, aspect, delta, ratio, min_thr, max_thr, use_ratios, &job));
+  const int rc = blob_dog_end(job, minima, min_cap, n_min, maxima, max_cap, n_max);
+  if (rc == VISFD_HIP_ECAPACITY) {   // (the one-call form has no second chance: as before, the counts come back with the error
+    //  and, as before, the lists' first min_cap / max_cap records)
+    for (int64_t i = 0; i < (int64_t)job->mins.size() && i < min_cap; i++) minima[i] = job->mins[i];
+    for (int64_t i = 0; i < (int64_t)job->maxs.size() && i < max_cap; i++) maxima[i] = job->maxs[i];
+    delete job;
+  }
   return rc;
 }
 
@@ -305,7 +374,7 @@ void options_from_environment(visfd_hip_options* o) {
 }
 }  // namespace
 
-int visfd_hip_abi_version(void) { return 8; }   // 8: + the peak-height factor (`-membrane-background`): visfd_hip_peak_background_dev, _ridge_scores_bg_dev, _tensor_saliency_bg_dev, _membrane_detect_bg[_dev], _membrane_detect_slab_bg[_dev]; slab Gaussian / blob entry points of the program; 7: + visfd_hip_membrane_detect_slab (host-memory face of the slab stage); 6: + visfd_hip_get_option, tolerance modes (tv_fma, gauss_fma), slab entry points; 5: + visfd_hip_set_option, CompactMultiChannelImage3D/TVDenseStick normalisation in the shim; 2: + blob post-processing, binning, LabelConnected and its host helpers; 3: + host DiagonalizeFlatSym3 / ConvertFlatSym2Evects3; 4: + LocalFluctuations, two-step ridge (scores / directions)
+int visfd_hip_abi_version(void) { return 9; }   // 9: + visfd_hip_blob_dog_begin_dev / _end / _abort (BlobDog in two halves); 8: + the peak-height factor (`-membrane-background`): visfd_hip_peak_background_dev, _ridge_scores_bg_dev, _tensor_saliency_bg_dev, _membrane_detect_bg[_dev], _membrane_detect_slab_bg[_dev]; slab Gaussian / blob entry points of the program; 7: + visfd_hip_membrane_detect_slab (host-memory face of the slab stage); 6: + visfd_hip_get_option, tolerance modes (tv_fma, gauss_fma), slab entry points; 5: + visfd_hip_set_option, CompactMultiChannelImage3D/TVDenseStick normalisation in the shim; 2: + blob post-processing, binning, LabelConnected and its host helpers; 3: + host DiagonalizeFlatSym3 / ConvertFlatSym2Evects3; 4: + LocalFluctuations, two-step ridge (scores / directions)
 const char* visfd_hip_last_error(void) { return g_last_error.c_str(); }
 
 int visfd_hip_create(int device, void* stream, visfd_hip_ctx** out) {
@@ -578,6 +647,32 @@ int visfd_hip_blob_dog_dev(visfd_hip_ctx* ctx, const float* src, const float* ma
   VH_HIP(hipSetDevice(ctx->device));
   return blob_dog_dev(ctx, src, mask, nx, ny, nz, blob_sigma, n_sigma, aspect, delta, ratio, min_thr,
                       max_thr, use_ratios != 0, minima, min_cap, n_min, maxima, max_cap, n_max);
+}
+
+int visfd_hip_blob_dog_begin_dev(visfd_hip_ctx* ctx, const float* src, const float* mask, int64_t nx, int64_t ny, int64_t nz,
+                                 const float* blob_sigma, int n_sigma, const float* aspect, float delta, float ratio,
+                                 float min_thr, float max_thr, int use_ratios, visfd_hip_blob_job** job) {
+  VH_REQUIRE(ctx && job, "null argument");
+  VH_HIP(hipSetDevice(ctx->device));
+  BlobJob* j = nullptr;
+  VH_TRY(blob_dog_begin(ctx, src, mask, nx, ny, nz, blob_sigma, n_sigma, aspect, delta, ratio, min_thr, max_thr, use_ratios != 0, &j));
+  *job = reinterpret_cast<visfd_hip_blob_job*>(j);
+  return VISFD_HIP_OK;
+}
+int visfd_hip_blob_dog_end(visfd_hip_blob_job* job, visfd_hip_blob* minima, int64_t min_cap, int64_t* n_min,
+                           visfd_hip_blob* maxima, int64_t max_cap, int64_t* n_max) {
+  VH_REQUIRE(job, "null job");
+  BlobJob* j = reinterpret_cast<BlobJob*>(job);
+  VH_HIP(hipSetDevice(j->ctx->device));
+  return blob_dog_end(j, minima, min_cap, n_min, maxima, max_cap, n_max);
+}
+void visfd_hip_blob_dog_abort(visfd_hip_blob_job* job) {
+  BlobJob* j = reinterpret_cast<BlobJob*>(job);
+  if (!j) return;
+  (void)hipSetDevice(j->ctx->device);
+  if (j->ctx->aux_stream) (void)hipStreamSynchronize(j->ctx->aux_stream);
+  (void)hipStreamSynchronize(j->ctx->stream);   // nothing of the job is in flight when its events go
+  delete j;
 }
 
 int visfd_hip_blob_dog(visfd_hip_ctx* ctx, const float* src, const float* mask, int64_t nx, int64_t ny,

@@ -276,7 +276,7 @@ static int scan_bufs(visfd_hip_ctx* ctx, int set, ScanBufs* B, bool pipelined, i
   unsigned long long* counters = nullptr;
   VH_TRY(ws(ctx, WS_TVAUX, NSET * cap_idx, &idx));
   VH_TRY(ws(ctx, WS_CAND, NSET * cap_out, &cand));
-  VH_TRY(ws(ctx, WS_COUNTER, 8, &counters));   // (2 words per set)
+  VH_TRY(ws(ctx, WS_SCANCNT, 8, &counters));   // (2 words per set)
   B->idx = idx + (size_t)set * cap_idx;
   B->cand = cand + (size_t)set * cap_out;
   B->counters = counters + 2 * set;

@@ -45,6 +45,8 @@ enum Slot {
   WS_NORM,                         // Dx|Dy|Dz normaliser lines
   WS_LOG0, WS_LOG1, WS_LOG2,       // rolling LoG volumes of the blob detector
   WS_CAND, WS_COUNTER,             // candidate list + counters
+  WS_SCANCNT,                      // counters of the pipelined blob scan: theirs alone (a scan's counts are read by the host after later stages
+                                   // may have been queued, visfd_hip_blob_dog_begin_dev / _end)
   WS_HIST,                         // radix-select histograms
   WS_TVTAB,                        // tensor-voting lookup table
   WS_TVAUX,                        // tensor-voting auxiliaries

@@ -45,6 +45,18 @@ def blob_detect(ctx, src, sigmas, truncate_threshold=TRUNCATE_THRESHOLD, delta=0
                             use_ratios, cap)
 
 
+def blob_detect_begin(ctx, src, sigmas, truncate_threshold=TRUNCATE_THRESHOLD, delta=0.02, mask=None,
+                      minima_threshold=np.inf, maxima_threshold=-np.inf, use_ratios=False):
+    """blob_detect in two halves: everything is queued here; blob_detect_end() hands the lists over.  Device work queued on
+    the same context in between (the membrane stage) runs right behind the last scan, while the host still handles lists."""
+    ratio = api.ratio_from_threshold(truncate_threshold)
+    return ctx.blob_dog_begin_dev(src, sigmas, mask, None, delta, ratio, minima_threshold, maxima_threshold, use_ratios)
+
+
+def blob_detect_end(ctx, job, cap=1 << 22):
+    return ctx.blob_dog_end(job, cap)
+
+
 def membrane_detect(ctx, src, sal, dirs, tensor, sigma, tv_sigma_ratio, tv_exponent=4, best_fraction=0.05,
                     truncate_threshold=TRUNCATE_THRESHOLD, tv_truncate_ratio=math.sqrt(2.0), minima=True,
                     mask=None, scratch=None, sigma_background=0.0, background=None):
