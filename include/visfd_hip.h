@@ -81,7 +81,7 @@ int visfd_hip_abi_version(void);   /* 9: entry points only get added between ver
  *   tv_poison        tests: NaN bit patterns in LDS, list memory and the output before the kernels of csrc/tv_box.hip run (both forms)
  *   tv_reserve_wg    workgroup slots a voting kernel leaves free of its chip-filling grid (slab runs set it while a halo is in
  *                    flight, so that the transport's kernels find room; default 0)
- *   tv_zrun          receiver planes per unit of work (default 32)
+ *   tv_zrun          receiver planes per unit of work (default 8 in csrc/tv_box.hip, 32 in csrc/tv_tiled.hip)
  *   tv_no_replay     csrc/tv_tiled.hip only: every sender plane is listed again for every receiver plane (no reuse within a run)
  *   tv_max_wg        cap on the number of persistent workgroups (tests: forces many units of work per workgroup)
  *   blob_test_cap    tests: capacity the pipelined blob scan pretends to have (exercises its overflow path)

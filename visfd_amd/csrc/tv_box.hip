@@ -1135,7 +1135,8 @@ int dev_tv_box(visfd_hip_ctx* ctx, const float* sal, const float* dir, float* te
   const size_t slice_bytes = sizeof(float4) * (size_t)p.nsl;
   p.tiles_x = (int)((nx + TX - 1) / TX);
   p.tiles_y = (int)((ny + TY - 1) / TY);
-  p.zrun = 32;
+  p.zrun = 8;    // (sweep at 1024^3, tools/tv_sweep.py: 2..8 planes 280-281 ms, 16: 283, 32: 290, 64: 296, 128: 306 -- short runs keep the
+                 //  workgroups of the chip on neighbouring planes, whose lists and slices they then share in L2)
   if (ctx->opt.tv_zrun >= 1 && ctx->opt.tv_zrun <= 4096) p.zrun = ctx->opt.tv_zrun;
   if ((i64)p.zrun > z_out1 - z_out0) p.zrun = (int)(z_out1 - z_out0);
   if (p.zrun < 1) p.zrun = 1;
